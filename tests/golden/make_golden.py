@@ -1,0 +1,286 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference, never runs on the GPU box
+
+What is executed from /root/reference, unmodified:
+  attack.{FGSM,PGD,CWinf,CW2,FAKEBOB,utils}, adaptive_attack.{EOT,NES},
+  model.xv_plda.xv_plda (constructed from files written by speakerguard_amd.synth) driven from
+  MFCC features onward (flag=1), model._xv_plda.{xvecTDNN,xvector_extract,plda}, model.utils.
+
+Harness-side accommodations (disclosed in every fixture's ``meta``):
+  * ``numpy.infty = numpy.inf`` -- the name was removed in NumPy 2 (reference CW2.py:49,
+    FAKEBOB.py:58 use it); it was a pure alias, no reference arithmetic is replaced.
+  * EMPTY placeholder modules for ``torchaudio`` and ``kaldi_io`` in ``sys.modules`` so that
+    ``import`` lines at xv_plda.py:4, iv_plda.py:6, plda.py:13 succeed.  They contain no code, so
+    ``flag=0`` (waveform -> MFCC) raises AttributeError instead of running anything of ours.
+
+Only inputs, expected outputs and metadata are saved (plain arrays); weights are re-created
+from ``speakerguard_amd.synth`` seeds and guarded by a checksum.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+np.infty = np.inf
+for name in ("torchaudio", "kaldi_io"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+from attack.FGSM import FGSM  # noqa: E402
+from attack.PGD import PGD  # noqa: E402
+from attack.CWinf import CWinf  # noqa: E402
+from attack.CW2 import CW2  # noqa: E402
+from attack.FAKEBOB import FAKEBOB  # noqa: E402
+from attack.utils import SEC4SR_CrossEntropy, SEC4SR_MarginLoss  # noqa: E402
+from model.xv_plda import xv_plda  # noqa: E402
+
+from speakerguard_amd import synth  # noqa: E402
+from oracle import kaldi_mfcc  # noqa: E402  (only to produce realistic INPUT features)
+from toy_model import ToyModel, toy_inputs  # noqa: E402
+
+META = {
+    "generator": "tests/golden/make_golden.py",
+    "reference": "SpeakerGuard @ 2024-12-20 (/root/reference)",
+    "torch": torch.__version__,
+    "numpy": np.__version__,
+    "accommodations": ["numpy.infty alias", "empty torchaudio/kaldi_io placeholder modules"],
+}
+
+
+def weights_checksum(w):
+    h = hashlib.sha256()
+    for k in sorted(w["state_dict"]):
+        h.update(np.ascontiguousarray(w["state_dict"][k]).tobytes())
+    for k in ("emb_mean", "lda", "plda_mean", "plda_transform", "plda_psi", "enroll"):
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+def save(name, **arrays):
+    meta = dict(META)
+    meta.update(arrays.pop("meta", {}))
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, meta=json.dumps(meta), **arrays)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+class _Hook:
+    """Capture relu outputs of the reference TDNN via forward hooks on the BN modules' inputs."""
+
+    def __init__(self, net):
+        self.acts = {}
+        for i in range(1, 6):
+            getattr(net, "bn_tdnn%d" % i).register_forward_hook(self._mk(i))
+
+    def _mk(self, i):
+        def hook(mod, inp, out):
+            self.acts["relu%d" % i] = inp[0].detach().clone()
+            self.acts["bn%d" % i] = out.detach().clone()
+        return hook
+
+
+def gen_calibration(tmpdir):
+    """enroll.py-style calibration of the synthetic back-end with the reference model."""
+    w = synth.make_xv_weights(seed=0, D=200, n_spk=10, calibrated=False)
+    paths = synth.write_xv_model_dir(tmpdir, w)
+    model = xv_plda(paths["extractor_file"], paths["plda_file"], paths["mean_file"],
+                    paths["transform_mat_file"], model_file=paths["model_file"])
+    x = torch.from_numpy(synth.make_enroll_waveforms(10)) * 32768.0
+    with torch.no_grad():
+        feats = kaldi_mfcc.mfcc_batch(x)
+        cm = model.cmvn(feats)
+        raw = torch.stack([model.extractor.Extract(c) for c in cm], 0)  # (10, 512)
+        model.emb_mean = raw.mean(0)
+        enroll = torch.stack([model.process_emb(e, num_utt=1, simple_length_norm=False, normalize_length=True)
+                              for e in raw], 0)
+    os.makedirs(os.path.dirname(synth.CALIB_FILE), exist_ok=True)
+    np.savez(synth.CALIB_FILE, emb_mean=model.emb_mean.numpy(), enroll=enroll.numpy())
+    print("wrote", synth.CALIB_FILE)
+
+
+def build_reference_xv(tmpdir, threshold=None):
+    w = synth.make_xv_weights(seed=0, D=200, n_spk=10)
+    paths = synth.write_xv_model_dir(tmpdir, w)
+    model = xv_plda(paths["extractor_file"], paths["plda_file"], paths["mean_file"],
+                    paths["transform_mat_file"], model_file=paths["model_file"], threshold=threshold)
+    return model, w
+
+
+def gen_xv(tmpdir):
+    model, w = build_reference_xv(tmpdir)
+    csum = weights_checksum(w)
+    hook = _Hook(model.extractor.extractor)
+    for tag, T in (("f300", 48000), ("f331", 52960)):
+        B = 2
+        x = torch.from_numpy(synth.make_waveforms(B, T, seed=42)) * 32768.0
+        with torch.no_grad():
+            feats = kaldi_mfcc.mfcc_batch(x).contiguous()  # realistic INPUT only (unpinned stage)
+        feats_in = feats.clone().requires_grad_(True)
+        y = torch.tensor([3, -1][:B]) if tag == "f331" else torch.tensor([3, 7])
+        cmvn = model.cmvn(feats_in)
+        decisions, scores = model.make_decision(feats_in, flag=1)
+        emb = model.embedding(feats_in.detach(), flag=1).detach()
+        tdnn_emb = torch.stack([model.extractor.Extract(c) for c in cmvn.detach()], 0).detach()
+        ce = SEC4SR_CrossEntropy(reduction="none", task="CSI")(scores, y)
+        ce.backward(torch.ones_like(ce))
+        grad_ce = feats_in.grad.clone()
+        feats_in.grad = None
+        decisions2, scores2 = model.make_decision(feats_in, flag=1)
+        mg = SEC4SR_MarginLoss(targeted=False, task="CSI", clip_max=False)(scores2, y)
+        mg.backward(torch.ones_like(mg))
+        grad_margin = feats_in.grad.clone()
+        acts = {}
+        for i in range(1, 6):  # last utterance's activations (hooks keep the most recent call)
+            a = hook.acts["relu%d" % i][0]  # (C, F_i)
+            acts["relu%d_sub" % i] = a[::37, ::11].numpy()
+            acts["relu%d_sum" % i] = np.array([a.double().sum().item(), a.double().abs().sum().item()])
+        save("xv_%s.npz" % tag, feats=feats.numpy(), y=y.numpy(), cmvn=cmvn.detach().numpy(),
+             tdnn_emb=tdnn_emb.numpy(), emb=emb.numpy(), scores=scores.detach().numpy(),
+             decisions=decisions.numpy(), ce=ce.detach().numpy(), margin=mg.detach().numpy(),
+             grad_ce=grad_ce.numpy(), grad_margin=grad_margin.numpy(),
+             meta={"weights_seed": 0, "D": 200, "n_spk": 10, "weights_sha256": csum,
+                   "acts": "relu outputs of the LAST utterance, subsampled [::37, ::11]",
+                   "feats": "INPUT produced by oracle.kaldi_mfcc (unpinned stage); everything after is reference output"},
+             **acts)
+
+    # OSI / SV flavoured decisions + margin losses with a finite threshold (iv_plda.py:189-192)
+    model_t, _ = build_reference_xv(tmpdir, threshold=-10.0)
+    x = torch.from_numpy(synth.make_waveforms(3, 48000, seed=43)) * 32768.0
+    with torch.no_grad():
+        feats = kaldi_mfcc.mfcc_batch(x).contiguous()
+        decisions, scores = model_t.make_decision(feats, flag=1)
+    y = torch.tensor([2, -1, 5])
+    out = {}
+    for task in ("CSI", "OSI"):
+        for targeted in (False, True):
+            for clip in (False, True):
+                l = SEC4SR_MarginLoss(targeted=targeted, confidence=0.5, task=task, threshold=-10.0, clip_max=clip)(scores, y)
+                out["margin_%s_%d_%d" % (task, targeted, clip)] = l.numpy()
+    ysv = torch.tensor([0, -1, 0])
+    for targeted in (False, True):
+        l = SEC4SR_MarginLoss(targeted=targeted, confidence=0.5, task="SV", threshold=-10.0, clip_max=False)(scores[:, :1], ysv)
+        out["margin_SV_%d" % targeted] = l.numpy()
+    save("xv_thresh.npz", feats=feats.numpy(), scores=scores.numpy(), decisions=decisions.numpy(), y=y.numpy(),
+         ysv=ysv.numpy(), meta={"threshold": -10.0, "weights_sha256": weights_checksum(_)}, **out)
+
+
+class FeatLevelAdapter:
+    """Lets the reference attack classes (which need (n,1,T) in [-1,1)) drive xv_plda from flag=1.
+
+    x (n, 1, F*30) is only reshaped and rescaled to MFCC features; every score/grad comes from
+    the reference model.
+    """
+    SCALE = 128.0
+
+    def __init__(self, model, F):
+        self.model, self.F, self.threshold = model, F, model.threshold
+
+    def make_decision(self, x):
+        feats = x.view(x.shape[0], self.F, 30) * self.SCALE
+        return self.model.make_decision(feats, flag=1)
+
+
+def gen_xv_pgd(tmpdir):
+    model, w = build_reference_xv(tmpdir)
+    B, F = 3, 300
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=44)) * 32768.0
+    with torch.no_grad():
+        feats = kaldi_mfcc.mfcc_batch(x)
+    x0 = (feats / FeatLevelAdapter.SCALE).reshape(B, 1, F * 30).contiguous()
+    assert x0.abs().max() < 1
+    adapter = FeatLevelAdapter(model, F)
+    with torch.no_grad():
+        d0, s0 = adapter.make_decision(x0)
+    y = d0.clone()  # attack away from the clean decision
+    out = {}
+    for name, cls, kw in (
+        ("pgd_ce", PGD, dict(loss="Entropy", targeted=False)),
+        ("pgd_ce_t", PGD, dict(loss="Entropy", targeted=True)),
+        ("cwinf", CWinf, dict(targeted=False)),
+    ):
+        yy = (y + 1) % 10 if kw.get("targeted") else y
+        atk = cls(adapter, task="CSI", epsilon=0.002, step_size=0.0004, max_iter=5, batch_size=B, verbose=0, **kw)
+        adv, success = atk.attack(x0.clone(), yy)
+        with torch.no_grad():
+            d1, s1 = adapter.make_decision(adv)
+        out[name + "_adv"] = adv.detach().numpy()
+        out[name + "_success"] = np.array(success)
+        out[name + "_y"] = yy.numpy()
+        out[name + "_scores"] = s1.numpy()
+        out[name + "_decisions"] = d1.numpy()
+    save("xv_pgd_featlevel.npz", x0=x0.numpy(), clean_scores=s0.numpy(), clean_decisions=d0.numpy(),
+         meta={"scale": FeatLevelAdapter.SCALE, "eps": 0.002, "step": 0.0004, "max_iter": 5,
+               "weights_sha256": weights_checksum(w)}, **out)
+
+
+def gen_attacks():
+    out = {}
+    x = toy_inputs(B=4, T=800)
+    for thr, tag in ((None, "csi"), (1.5, "osi")):
+        model = ToyModel(threshold=thr).eval()
+        task = "CSI" if thr is None else "OSI"
+        with torch.no_grad():
+            d0, s0 = model.make_decision(x)
+        y = d0.clone()
+        out["%s_clean_dec" % tag] = d0.numpy()
+        out["%s_clean_scores" % tag] = s0.numpy()
+
+        def run(name, atk, yy):
+            torch.manual_seed(123)
+            np.random.seed(123)
+            adv, success = atk.attack(x.clone(), yy)
+            out["%s_%s_adv" % (tag, name)] = adv.detach().numpy()
+            out["%s_%s_success" % (tag, name)] = np.array(success)
+            out["%s_%s_y" % (tag, name)] = yy.numpy()
+
+        yt = (y + 1) % 4
+        if thr is not None:
+            y = torch.where(y < 0, torch.zeros_like(y), y)
+            yt = (y + 1) % 4
+        run("fgsm", FGSM(model, task=task, epsilon=0.01, batch_size=4, verbose=0), y)
+        run("pgd", PGD(model, task=task, epsilon=0.01, step_size=0.002, max_iter=8, batch_size=3, verbose=0), y)
+        run("pgd_t", PGD(model, task=task, epsilon=0.01, step_size=0.002, max_iter=8, batch_size=2, targeted=True, verbose=0), yt)
+        run("pgd_eot", PGD(model, task=task, epsilon=0.01, step_size=0.002, max_iter=4, batch_size=4,
+                           EOT_size=4, EOT_batch_size=2, verbose=0), y)
+        run("pgd_rand", PGD(model, task=task, epsilon=0.01, step_size=0.002, max_iter=4, batch_size=4,
+                            num_random_init=3, verbose=0), y)
+        run("cwinf", CWinf(model, task=task, epsilon=0.01, step_size=0.002, max_iter=8, batch_size=4, verbose=0), y)
+        run("cw2", CW2(model, task=task, initial_const=0.5, binary_search_steps=4, max_iter=30, stop_early=True,
+                       stop_early_iter=10, lr=5e-3, batch_size=4, verbose=0), y)
+        run("cw2_t", CW2(model, task=task, initial_const=0.5, binary_search_steps=3, max_iter=25, stop_early=False,
+                         lr=5e-3, batch_size=2, targeted=True, confidence=0.1, verbose=0), yt)
+        fb_kw = dict(task=task, epsilon=0.02, max_iter=30, max_lr=0.004, min_lr=1e-4, samples_per_draw=16,
+                     samples_per_draw_batch_size=8, sigma=0.01, stop_early=True, stop_early_iter=10, verbose=0)
+        if thr is not None:
+            fb_kw["threshold"] = thr
+        # batch_size=1 (the reference default): its multi-example early-stop bookkeeping is ill-defined
+        run("fakebob", FAKEBOB(model, batch_size=1, **fb_kw), y)
+        run("fakebob_t", FAKEBOB(model, batch_size=1, targeted=True, confidence=0.05, **fb_kw), yt)
+    save("attack_toy.npz", x=x.numpy(), meta={"seeds": "torch.manual_seed(123); np.random.seed(123) before each attack",
+                                              "toy": "tests/toy_model.py ToyModel(T=800,n_spk=4,seed=7)"}, **out)
+
+
+if __name__ == "__main__":
+    import contextlib
+    import io
+    import tempfile
+    torch.set_num_threads(8)
+    with tempfile.TemporaryDirectory() as tmp:
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference prints per-iteration lines
+            pass
+        gen_calibration(tmp)
+        gen_attacks()
+        gen_xv(tmp)
+        gen_xv_pgd(tmp)
