@@ -1,0 +1,23 @@
+# Builds the gfx950 C-ABI library in-tree (the .so travels to the GPU box, it is git-ignored).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := speakerguard_amd/csrc
+OBJ   := build/obj
+SRCS  := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS))
+LIB   := speakerguard_amd/libspeakerguard_hip.so
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h include/speakerguard_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,182 @@
+/*
+ * speakerguard_hip.h -- C-ABI of the MI355X (gfx950) attack hot path.
+ *
+ * The reference (SpeakerGuard, pure Python/PyTorch) has no native boundary of its own; this is
+ * the boundary a maintainer would bind with ctypes.  Every entry point
+ * names the reference interface it stands in for (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer marked "dev" is a DEVICE pointer owned by the
+ *     caller (e.g. tensor.data_ptr()); pointers marked "host" are host memory.
+ *   - the library owns only the workspace inside sg_ctx (grown on demand, freed by sg_destroy).
+ *   - every call returns 0 on success, non-zero on error; sg_last_error(ctx) gives the text.
+ *     Nothing throws across the ABI.
+ *   - one sg_ctx per device, not thread-safe.  Work is enqueued on `stream` (a hipStream_t passed
+ *     as void*; NULL = the default stream) and is asynchronous unless stated otherwise.
+ *   - all floating point is IEEE fp32 (f32-input MFMA); labels / decisions are int64.
+ *
+ * Tensor shapes use the reference's names: B utterances, T samples, F frames (snip_edges=False:
+ * F = (T + 80) / 160), 30 cepstra, D = back-end dimension (rows of transform.txt), S = enrolled
+ * speakers.
+ */
+#ifndef SPEAKERGUARD_HIP_H
+#define SPEAKERGUARD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sg_ctx sg_ctx;
+
+#define SG_OK 0
+#define SG_ERR_ARG 1
+#define SG_ERR_HIP 2
+#define SG_ERR_STATE 3
+
+/* ---- context ------------------------------------------------------------------------------ */
+int sg_version(void);
+int sg_create(int device, sg_ctx** out);
+void sg_destroy(sg_ctx* ctx);
+const char* sg_last_error(const sg_ctx* ctx);
+/* blocks until everything enqueued on `stream` by this ctx has finished */
+int sg_sync(sg_ctx* ctx, void* stream);
+
+/* ---- x-vector + PLDA model ----------------------------------------------------------------
+ * Replaces the tensors the reference holds after model/xv_plda.py:17-47 ran: the xvecTDNN
+ * state_dict (model/_xv_plda/xvecTDNN.py:16-44), emb_mean (model/utils.py:50-60), the LDA
+ * matrix (model/utils.py:63-80), PLDA mean/transform/psi (model/_xv_plda/plda.py:27-49) and the
+ * enrolled embeddings (model/utils.py:21-47).  All pointers are HOST fp32, PyTorch layouts.
+ * The library folds the eval-mode BatchNorms (affine=False, xvecTDNN.py:17) into the following
+ * layer's weights and re-lays everything out for the kernels. */
+typedef struct sg_xv_weights {
+    const float* tdnn_weight[5]; /* (cout, cin, k): (512,30,5) (512,512,5) (512,512,7) (512,512,1) (1500,512,1) */
+    const float* tdnn_bias[5];   /* (cout) */
+    const float* bn_mean[5];     /* running_mean (cout) */
+    const float* bn_var[5];      /* running_var (cout)  */
+    const float* fc1_weight;     /* (512, 3000) */
+    const float* fc1_bias;       /* (512) */
+    const float* emb_mean;       /* (512) */
+    const float* lda;            /* (D, 513) last column = offset (iv_plda.py:423-435) */
+    const float* plda_mean;      /* (D) */
+    const float* plda_transform; /* (D, D) */
+    const float* plda_psi;       /* (D) */
+    const float* enroll;         /* (S, D) processed enrolment embeddings */
+    int32_t D;
+    int32_t S;
+    float bn_eps;                /* 1e-5 */
+    float threshold;             /* -INFINITY for CSI (xv_plda.py:41) */
+} sg_xv_weights;
+
+int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w);
+/* replace the enrolled speakers / threshold only (model.enroll_embs, model.threshold) */
+int sg_xv_set_enroll(sg_ctx* ctx, const float* enroll_host, int32_t S, float threshold);
+
+/* number of frames / TDNN output frames for T samples (0 if too short) */
+int32_t sg_xv_num_frames(int32_t T);
+
+/* loss selector: attack/utils.py:104-116 resolve_loss */
+#define SG_LOSS_ENTROPY 0 /* SEC4SR_CrossEntropy, attack/utils.py:7-29 */
+#define SG_LOSS_MARGIN 1  /* SEC4SR_MarginLoss,  attack/utils.py:31-102 */
+#define SG_TASK_CSI 0
+#define SG_TASK_SV 1
+#define SG_TASK_OSI 2
+
+typedef struct sg_loss_spec {
+    int32_t loss;       /* SG_LOSS_* */
+    int32_t task;       /* SG_TASK_* */
+    int32_t targeted;   /* 0/1 */
+    int32_t clip_max;   /* Margin: max(0, loss) (attack/utils.py:99-100) */
+    float confidence;   /* Margin kappa */
+    float threshold;    /* SV/OSI threshold used INSIDE the loss */
+} sg_loss_spec;
+
+/* Input levels, reference model/xv_plda.py:45-47 allowed_flags */
+#define SG_FLAG_WAV 0  /* x: (B,1,T) waveform            */
+#define SG_FLAG_RAW 1  /* x: (B,F,30) raw MFCC           */
+#define SG_FLAG_CMVN 2 /* x: (B,F,30) CMVN-normalised    */
+
+/* Dither policy for the MFCC front-end (xv_plda.py:119 hard-codes dither=1.0 from the global
+ * RNG).  dither == 0 disables it.  Otherwise the noise is kaldi's sqrt(-2 ln u) cos(2 pi u) with
+ * u from a counter-based generator keyed by (seed, utterance index + index_base, frame, sample),
+ * so results do not depend on how a batch is sharded over GPUs.  noise_dev, when non-NULL, is an
+ * explicit (B,F,400) tensor that is added instead (parity tests). */
+typedef struct sg_dither {
+    float dither;
+    uint64_t seed;
+    int64_t index_base;
+    const float* noise_dev;
+} sg_dither;
+
+/* ---- per-stage entry points (parity tests; also what model.compute_feat etc. call) --------- */
+
+/* model/utils.py:7-19 check_input_range(range_type='origin'): writes 32768.f or 1.f to
+ * *scale_dev (device float) from the batch max/min; no host sync. */
+int sg_input_scale(sg_ctx* ctx, const float* x_dev, int64_t n, float* scale_dev, void* stream);
+
+/* model/xv_plda.py:107-156 raw() = torchaudio.compliance.kaldi.mfcc per utterance.
+ * x (B,T) dev; scale_dev: device float multiplied into x (NULL = 1); feats (B,F,30) dev. */
+int sg_xv_mfcc(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* scale_dev,
+               const sg_dither* dither, float* feats_dev, void* stream);
+
+/* model/iv_plda.py:296-377 cmvn(): sliding 300-frame centred mean subtraction. (B,F,30)->(B,F,30) */
+int sg_xv_cmvn(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, float* out_dev, void* stream);
+
+/* Forward pass: model.make_decision / score / embedding (iv_plda.py:155-194, xv_plda.py:87-104).
+ * Any output pointer may be NULL.  decisions (B) int64, scores (B,S), emb (B,D) processed
+ * embedding (xv_plda.py:159-174), tdnn_emb (B,512) raw fc1 output (xvecTDNN.py:63). */
+int sg_xv_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag,
+                  const sg_dither* dither, int64_t* decisions_dev, float* scores_dev, float* emb_dev,
+                  float* tdnn_emb_dev, void* stream);
+
+/* TDNN layer activations of the LAST sg_xv_forward / sg_xv_loss_grad call (debug / parity):
+ * layer 1..5 -> relu output (B, F_l, C_l) channel-last, C_5 padded to 1536; copies to out_dev. */
+int sg_xv_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t capacity_floats,
+                           int32_t* rows_per_utt, int32_t* channels, void* stream);
+
+/* The autograd call site the hand-coded backward replaces: adaptive_attack/EOT.py:32-35
+ * (make_decision, loss, loss.backward(ones)).  grad has the shape of x (flag 0: (B,T); 1/2:
+ * (B,F,30)); loss (B); outputs may be NULL. */
+int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32_t B, int32_t T_or_F,
+                    int32_t flag, const sg_loss_spec* loss, const sg_dither* dither,
+                    int64_t* decisions_dev, float* scores_dev, float* loss_dev, float* grad_dev,
+                    void* stream);
+
+/* attack/FGSM.py:65,68: x += step*sign(grad)*grad_sign; x = min(max(x, lower), upper). In place. */
+int sg_pgd_update(sg_ctx* ctx, float* x_dev, const float* grad_dev, const float* lower_dev,
+                  const float* upper_dev, int64_t n, float step_size, int32_t grad_sign, void* stream);
+
+/* ---- fused attack loop ----------------------------------------------------------------------
+ * attack/FGSM.py:38-70 attack_batch for the xv_plda model: max_iter gradient steps plus the final
+ * forward-only pass, entirely on the device (FGSM = max_iter 1, step_size epsilon). */
+typedef struct sg_pgd_params {
+    sg_loss_spec loss;
+    float step_size;
+    int32_t max_iter;
+    int32_t grad_sign;       /* attack/utils.py:114 */
+    int32_t eot_size;        /* EOT_size / EOT_batch_size (EOT.py); repeats draw fresh dither */
+    int32_t eot_batch_size;
+    sg_dither dither;
+} sg_pgd_params;
+
+/* x_adv (B,T) dev: in = start point, out = adversarial audio; lower/upper (B,T) dev.
+ * success (B) uint8, decisions (B) int64, scores (B,S), loss (B): state at the final pass.
+ * loss_trace ((max_iter+1)*B) / decision_trace ((max_iter+1)*B) optional per-pass records. */
+int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev,
+                  const float* upper_dev, int32_t B, int32_t T, const sg_pgd_params* params,
+                  uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev, float* loss_dev,
+                  float* loss_trace_dev, int64_t* decision_trace_dev, void* stream);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * Time `iters` launches of the dominant contraction (TDNN layer `layer` 2..5 forward) with HIP
+ * events on `stream`; returns average milliseconds per launch in *ms_per_launch and the
+ * algorithmic FLOPs of one launch in *flops.  Used by bench.py for the roofline block. */
+int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters,
+                     float* ms_per_launch, double* flops, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEAKERGUARD_HIP_H */

@@ -1,0 +1,134 @@
+"""ctypes binding of ``libspeakerguard_hip.so`` (C-ABI declared in include/speakerguard_hip.h).
+
+There is no fallback: if the library is missing, or a call fails, this module raises.  Torch is
+used by the callers only to own device memory and streams; every pointer handed over here is
+``tensor.data_ptr()``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspeakerguard_hip.so")
+
+SG_LOSS_ENTROPY, SG_LOSS_MARGIN = 0, 1
+SG_TASK = {"CSI": 0, "SV": 1, "OSI": 2}
+SG_FLAG_WAV, SG_FLAG_RAW, SG_FLAG_CMVN = 0, 1, 2
+
+# every symbol include/speakerguard_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "sg_version", "sg_create", "sg_destroy", "sg_last_error", "sg_sync", "sg_xv_load", "sg_xv_set_enroll",
+    "sg_xv_num_frames", "sg_input_scale", "sg_xv_mfcc", "sg_xv_cmvn", "sg_xv_forward", "sg_xv_debug_activation",
+    "sg_xv_loss_grad", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
+)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class XvWeights(C.Structure):
+    _fields_ = [
+        ("tdnn_weight", C.c_void_p * 5), ("tdnn_bias", C.c_void_p * 5),
+        ("bn_mean", C.c_void_p * 5), ("bn_var", C.c_void_p * 5),
+        ("fc1_weight", C.c_void_p), ("fc1_bias", C.c_void_p), ("emb_mean", C.c_void_p), ("lda", C.c_void_p),
+        ("plda_mean", C.c_void_p), ("plda_transform", C.c_void_p), ("plda_psi", C.c_void_p), ("enroll", C.c_void_p),
+        ("D", C.c_int32), ("S", C.c_int32), ("bn_eps", C.c_float), ("threshold", C.c_float),
+    ]
+
+
+class LossSpec(C.Structure):
+    _fields_ = [("loss", C.c_int32), ("task", C.c_int32), ("targeted", C.c_int32), ("clip_max", C.c_int32),
+                ("confidence", C.c_float), ("threshold", C.c_float)]
+
+
+class Dither(C.Structure):
+    _fields_ = [("dither", C.c_float), ("seed", C.c_uint64), ("index_base", C.c_int64), ("noise_dev", C.c_void_p)]
+
+
+class PgdParams(C.Structure):
+    _fields_ = [("loss", LossSpec), ("step_size", C.c_float), ("max_iter", C.c_int32), ("grad_sign", C.c_int32),
+                ("eot_size", C.c_int32), ("eot_batch_size", C.c_int32), ("dither", Dither)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises NativeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "%s is missing: the HIP extension has not been built (run `make` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "sg_version": (C.c_int, []),
+        "sg_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "sg_destroy": (None, [vp]),
+        "sg_last_error": (C.c_char_p, [vp]),
+        "sg_sync": (C.c_int, [vp, vp]),
+        "sg_xv_load": (C.c_int, [vp, C.POINTER(XvWeights)]),
+        "sg_xv_set_enroll": (C.c_int, [vp, vp, i32, f32]),
+        "sg_xv_num_frames": (i32, [i32]),
+        "sg_input_scale": (C.c_int, [vp, vp, i64, vp, vp]),
+        "sg_xv_mfcc": (C.c_int, [vp, vp, i32, i32, vp, C.POINTER(Dither), vp, vp]),
+        "sg_xv_cmvn": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "sg_xv_forward": (C.c_int, [vp, vp, i32, i32, i32, C.POINTER(Dither), vp, vp, vp, vp, vp]),
+        "sg_xv_debug_activation": (C.c_int, [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), vp]),
+        "sg_xv_loss_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, C.POINTER(LossSpec), C.POINTER(Dither),
+                                      vp, vp, vp, vp, vp]),
+        "sg_pgd_update": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, i32, vp]),
+        "sg_xv_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
+        "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    """Device/host pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One ``sg_ctx`` on one GPU."""
+
+    def __init__(self, device_index=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.sg_create(int(device_index), C.byref(h))
+        if rc != 0 or not h:
+            raise NativeError("sg_create(device=%d) failed with code %d (no usable HIP device?)" % (device_index, rc))
+        self.handle = h
+        self.device_index = int(device_index)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.sg_last_error(self.handle)
+            raise NativeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self.handle, *args), name)
+
+
+def current_stream_ptr(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

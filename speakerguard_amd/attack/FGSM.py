@@ -1,0 +1,119 @@
+"""FGSM and the shared PGD inner loop; mirrors reference attack/FGSM.py.
+
+``attack_batch`` is the hot loop (FGSM.py:38-70).  When the model is the native x-vector engine
+and nothing between attack and model needs Python (no defense wrapper, EOT repeats that would
+all be identical), the whole loop -- max_iter x (forward, hand-coded backward, sign step,
+projection) + the final forward-only pass -- is ONE C-ABI call (``model.pgd_run``).  Otherwise
+the same loop runs step by step over ``model.loss_grad`` / ``model.pgd_update``.
+"""
+import numpy as np
+import torch
+
+from ..adaptive_attack.EOT import EOT
+from .Attack import Attack
+from .utils import resolve_loss, resolve_prediction
+
+
+class FGSM(Attack):
+
+    def __init__(self, model, task='CSI', epsilon=0.002, loss='Entropy', targeted=False,
+                 batch_size=1, EOT_size=1, EOT_batch_size=1,
+                 verbose=1):
+        self.model = model  # the engine has no train mode
+        self.task = task
+        self.epsilon = epsilon
+        self.loss_name = loss
+        self.targeted = targeted
+        self.batch_size = batch_size
+        self._init_common(EOT_size, EOT_batch_size, verbose)
+        self.max_iter = 1  # FGSM is the single-step case of PGD (FGSM.py:35-36)
+        self.step_size = epsilon
+
+    def _init_common(self, EOT_size, EOT_batch_size, verbose):
+        EOT_size = max(1, EOT_size)
+        EOT_batch_size = max(1, EOT_batch_size)
+        assert EOT_size % EOT_batch_size == 0, 'EOT size should be divisible by EOT batch size'
+        self.EOT_size = EOT_size
+        self.EOT_batch_size = EOT_batch_size
+        self.verbose = verbose
+        self.threshold = None
+        if self.task in ['SV', 'OSI']:
+            self.threshold = self.model.threshold
+            print('Running white box attack for {} task, directly using the true threshold {}'.format(self.task, self.threshold))
+        self.loss, self.grad_sign = resolve_loss(loss_name=self.loss_name, targeted=self.targeted,
+                                                 task=self.task, threshold=self.threshold, clip_max=False)
+        self.EOT_wrapper = EOT(self.model, self.loss, self.EOT_size, self.EOT_batch_size, True)
+
+    # ---- fused device loop -----------------------------------------------------------------
+    def _can_fuse(self):
+        m = self.model
+        if getattr(m, 'defense', None) is not None:
+            return False
+        base = getattr(m, 'base_model', m)
+        if not hasattr(base, 'pgd_run'):
+            return False
+        # EOT repeats of a deterministic model are identical; with dither they are not
+        return self.EOT_size == 1 or getattr(base, 'dither', 0.0) == 0.0
+
+    def _attack_batch_fused(self, x_batch, y_batch, lower, upper, batch_id):
+        base = getattr(self.model, 'base_model', self.model)
+        x_adv, success, dec, scores, loss, ltr, dtr = base.pgd_run(
+            x_batch, y_batch, lower, upper, self.loss, self.step_size, self.max_iter, self.grad_sign,
+            1, 1, trace=bool(self.verbose))
+        if self.verbose:
+            ltr, dtr = ltr.cpu().numpy(), dtr.cpu().numpy()
+            target = y_batch.detach().cpu().numpy()
+            for it in range(self.max_iter + 1):
+                print("batch:{} iter:{} loss: {} predict: {}, target: {}".format(batch_id, it, ltr[it].tolist(), dtr[it], target))
+        return x_adv, success.bool().tolist()
+
+    # ---- step-by-step loop (FGSM.py:38-70) ---------------------------------------------------
+    def attack_batch(self, x_batch, y_batch, lower, upper, batch_id):
+        if self._can_fuse():
+            return self._attack_batch_fused(x_batch, y_batch, lower, upper, batch_id)
+        x_batch = x_batch.clone()
+        lower = lower.expand_as(x_batch).contiguous()
+        upper = upper.expand_as(x_batch).contiguous()
+        base = getattr(self.model, 'base_model', self.model)
+        success = None
+        for it in range(self.max_iter + 1):
+            EOT_num_batches = int(self.EOT_size // self.EOT_batch_size) if it < self.max_iter else 1
+            real_EOT_batch_size = self.EOT_batch_size if it < self.max_iter else 1
+            use_grad = it < self.max_iter
+            scores, loss, grad, decisions = self.EOT_wrapper(x_batch, y_batch, EOT_num_batches, real_EOT_batch_size, use_grad)
+            loss = loss / EOT_num_batches
+            predict = resolve_prediction(decisions)
+            target = y_batch.detach().cpu().numpy()
+            success = self.compare(target, predict, self.targeted)
+            if self.verbose:
+                print("batch:{} iter:{} loss: {} predict: {}, target: {}".format(batch_id, it, loss.cpu().numpy().tolist(), predict, target))
+            if it < self.max_iter:
+                grad = (grad / EOT_num_batches).contiguous()
+                base.pgd_update(x_batch, grad, lower, upper, self.step_size, self.grad_sign)
+        return x_batch, success
+
+    def _run_batches(self, x, y, lower, upper, tag=None):
+        n_audios = x.shape[0]
+        batch_size = min(self.batch_size, n_audios)
+        n_batches = int(np.ceil(n_audios / float(batch_size)))
+        adver, success = [], []
+        for batch_id in range(n_batches):
+            sl = slice(batch_id * batch_size, (batch_id + 1) * batch_size)
+            bid = batch_id if tag is None else '{}-{}'.format(tag, batch_id)
+            a, s = self.attack_batch(x[sl], y[sl], lower[sl], upper[sl], bid)
+            adver.append(a)
+            success += s
+        return torch.cat(adver, 0), success
+
+    def _check_inputs(self, x, y):
+        lower, upper = -1, 1
+        assert lower <= x.max() < upper, 'generating adversarial examples should be done in [-1, 1) float domain'
+        n_audios, n_channels, _ = x.size()
+        assert n_channels == 1, 'Only Support Mono Audio'
+        assert y.shape[0] == n_audios, 'The number of x and y should be equal'
+
+    def attack(self, x, y):
+        self._check_inputs(x, y)
+        lower = torch.tensor(-1, device=x.device, dtype=x.dtype).expand_as(x)
+        upper = torch.tensor(1, device=x.device, dtype=x.dtype).expand_as(x)
+        return self._run_batches(x, y, lower, upper)

@@ -1,0 +1,227 @@
+// Implicit-GEMM dilated 1-D convolution on f32-input MFMA (gfx950).
+//
+// Replaces torch.nn.functional.conv1d + autograd's conv data-gradient for the x-vector TDNN
+// (reference model/_xv_plda/xvecTDNN.py:16-33,49-53; backward = the loss.backward() call at
+// adaptive_attack/EOT.py:35 restricted to d/d-input -- weight gradients are never formed).
+//
+// Activations are channel-last ("frame-major"): row r = b*T + t holds the C channels of frame
+// t of utterance b.  For output row (b, t) and tap j the K-slice is the contiguous channel
+// vector of input row (b, t + j*tap_step), so no im2col buffer exists: the A tile of a K-chunk
+// is BM rows x 32 channels fetched straight from the activation tensor with one row offset per
+// tap.  The same kernel computes the data gradient by running over d(out) with tap_step = -dil,
+// zero rows where t + j*tap_step falls outside the utterance, and tap-transposed weights.
+//
+//   C[r][n] = epi( sum_j sum_c A[row(r) + j*tap_step][c] * W[j*Kc + c][n] )
+//
+// Tiling: 256 threads = 4 waves (64 lanes).  v_mfma_f32_32x32x2_f32, exact fp32, 64 cycles per
+// instruction per SIMD.  LDS: A chunk stored K-major [32][BM] (register-transposed 4x4 blocks,
+// ds_write_b128), W chunk [32][BN]; MFMA operands are conflict-free ds_read_b32 (lanes 0-31 read
+// 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages, next chunk's global loads
+// are issued before the current chunk's MFMAs and written to LDS after them (one barrier/chunk).
+#include "sg_internal.h"
+
+namespace sg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int mtiles, int ntiles) {
+    constexpr int MI = BM / WM / 32;
+    constexpr int NI = BN / WN / 32;
+    constexpr int A_QUADS = BM / 4;            // row quads in the A tile
+    constexpr int A_ACTIVE = A_QUADS * 8;      // threads that stage A (8 float4 per 32-float row slice)
+    constexpr int B_F4 = BK * BN / 4;          // float4 in the W tile
+    constexpr int B_PER_THREAD = (B_F4 + 255) / 256;
+    static_assert(A_ACTIVE <= 256, "A tile too tall");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    float* As = smem;                 // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+    // run of tiles so the N-tiles that share an A row-panel hit the same L2.
+    const int nblk = mtiles * ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8;
+        const int xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / ntiles, nt = bid % ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- A staging map: lane -> (row quad, 4-float k group); 8 lanes of a group share a k group
+    const int a_r4 = wid * 8 + (lane & 7);   // row quad index (valid if < A_QUADS)
+    const int a_c4 = lane >> 3;              // which float4 of the 32-float slice
+    const bool a_on = a_r4 < A_QUADS;
+    int a_base[4], a_t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = m0 + a_r4 * 4 + i;
+        if (a_on && r < p.M) {
+            const int b = r / p.Tc;
+            const int t = r - b * p.Tc;
+            a_base[i] = b * p.Ta + t;
+            a_t[i] = t;
+        } else {
+            a_base[i] = 0;
+            a_t[i] = -(1 << 28);
+        }
+    }
+    const int kchunks = p.Kc / BK;
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
+
+    float4 ra[4];
+    float4 rb[B_PER_THREAD];
+
+    auto load_chunk = [&](int c) {
+        const int j = c / kchunks;
+        const int kc = (c - j * kchunks) * BK;
+        const int off = j * p.tap_step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tt = a_t[i] + off;
+            if (tt >= 0 && tt < p.Ta) {
+                ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)(a_base[i] + off) * p.lda + kc + a_c4 * 4);
+            } else {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float* wrow = p.W + (size_t)(j * p.Kc + kc) * p.ldw + n0;
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            const int f = tid + i * 256;
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                const int k = f / (BN / 4), n4 = f % (BN / 4);
+                rb[i] = *reinterpret_cast<const float4*>(wrow + (size_t)k * p.ldw + n4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        if (a_on) {
+            float* a = As + buf * BK * BM + (a_c4 * 4) * BM + a_r4 * 4;
+            // register transpose: ra[i] = 4 k-values of row i  ->  one float4 of 4 rows per k
+            *reinterpret_cast<float4*>(a + 0 * BM) = make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x);
+            *reinterpret_cast<float4*>(a + 1 * BM) = make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y);
+            *reinterpret_cast<float4*>(a + 2 * BM) = make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z);
+            *reinterpret_cast<float4*>(a + 3 * BM) = make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            const int f = tid + i * 256;
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                *reinterpret_cast<float4*>(Bs + buf * BK * BN + f * 4) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    const int a_rd = wm * (BM / WM) + l31;
+    const int b_rd = wn * (BN / WN) + l31;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        if (c + 1 < c_end) load_chunk(c + 1);
+        const float* a_s = As + buf * BK * BM + lhi * BM + a_rd;
+        const float* b_s = Bs + buf * BK * BN + lhi * BN + b_rd;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av[mi] = a_s[ks * 2 * BM + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bv[ni] = b_s[ks * 2 * BN + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (c + 1 < c_end) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* Cz = p.C + (size_t)blockIdx.z * p.split_stride;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * (BN / WN) + ni * 32 + l31;
+            float bias = 0.f;
+            if (EPI == EPI_BIAS_RELU) bias = p.bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / WM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (row < p.M) {
+                    float v = acc[mi][ni][e];
+                    const size_t o = (size_t)row * p.ldc + col;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                    if (EPI == EPI_RELU_MASK) v = p.mask[o] > 0.f ? v : 0.f;
+                    Cz[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStream_t s) {
+    const int mtiles = (a.M + BM - 1) / BM;
+    const int ntiles = a.N / BN;
+    dim3 grid(mtiles * ntiles, 1, splits);
+    switch (epi) {
+        case EPI_NONE:
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, EPI_NONE>), grid, dim3(256), 0, s, a, mtiles, ntiles);
+            break;
+        case EPI_BIAS_RELU:
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, EPI_BIAS_RELU>), grid, dim3(256), 0, s, a, mtiles, ntiles);
+            break;
+        case EPI_RELU_MASK:
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, EPI_RELU_MASK>), grid, dim3(256), 0, s, a, mtiles, ntiles);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s) {
+    if (a.Kc % BK != 0 || a.M <= 0) return hipErrorInvalidValue;
+    switch (tile) {
+        case 0:
+            if (a.N % 128) return hipErrorInvalidValue;
+            return launch_tile<128, 128, 2, 2>(a, epi, splits, s);
+        case 1:
+            if (a.N % 32) return hipErrorInvalidValue;
+            return launch_tile<128, 32, 4, 1>(a, epi, splits, s);
+        case 2:
+            if (a.N % 128) return hipErrorInvalidValue;
+            return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace sg

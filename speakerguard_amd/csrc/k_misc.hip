@@ -1,0 +1,260 @@
+// Small memory-bound kernels around the TDNN contractions: input range check, CMVN, statistics
+// pooling (+backward), the fused PGD update.
+#include "sg_internal.h"
+
+namespace sg {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- check_input_range (model/utils.py:7-19)
+// range_type='origin' (xv_plda.py:48): if 0.9*max <= 1 and 0.9*min >= -1 the batch is in the
+// [-1,1] float domain and is multiplied by 2^15, otherwise it is left alone.  Single block; the
+// result stays on the device so no host sync is needed.
+__global__ __launch_bounds__(1024) void input_scale_kernel(const float* __restrict__ x, int64_t n, float* scale) {
+    __shared__ float smax[16], smin[16];
+    float mx = -INFINITY, mn = INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float v = x[i];
+        mx = fmaxf(mx, v);
+        mn = fminf(mn, v);
+    }
+    mx = wave_max_f(mx);
+    mn = wave_min_f(mn);
+    if ((threadIdx.x & 63) == 0) {
+        smax[threadIdx.x >> 6] = mx;
+        smin[threadIdx.x >> 6] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) {
+            mx = fmaxf(mx, smax[i]);
+            mn = fminf(mn, smin[i]);
+        }
+        *scale = (0.9f * mx <= 1.f && 0.9f * mn >= -1.f) ? 32768.f : 1.f;
+    }
+}
+
+hipError_t launch_input_scale(const float* x, int64_t n, float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(input_scale_kernel, dim3(1), dim3(1024), 0, s, x, n, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- PGD update (attack/FGSM.py:65,68)
+__global__ __launch_bounds__(256) void pgd_update_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ lo, const float* __restrict__ hi,
+                                                         int64_t n, float step, int grad_sign) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 xv = *reinterpret_cast<float4*>(x + i4);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i4);
+        const float4 lv = *reinterpret_cast<const float4*>(lo + i4);
+        const float4 hv = *reinterpret_cast<const float4*>(hi + i4);
+        const float s = step * (float)grad_sign;
+#define SG_UPD(c) xv.c = fminf(fmaxf(xv.c + s * (gv.c > 0.f ? 1.f : (gv.c < 0.f ? -1.f : 0.f)), lv.c), hv.c)
+        SG_UPD(x); SG_UPD(y); SG_UPD(z); SG_UPD(w);
+#undef SG_UPD
+        *reinterpret_cast<float4*>(x + i4) = xv;
+    } else {
+        for (int64_t i = i4; i < n; ++i) {
+            const float gv = g[i];
+            const float sg = gv > 0.f ? 1.f : (gv < 0.f ? -1.f : 0.f);
+            x[i] = fminf(fmaxf(x[i] + step * (float)grad_sign * sg, lo[i]), hi[i]);
+        }
+    }
+}
+
+hipError_t launch_pgd_update(float* x, const float* g, const float* lo, const float* hi, int64_t n, float step,
+                             int grad_sign, hipStream_t s) {
+    const int64_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(pgd_update_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, g, lo, hi, n, step, grad_sign);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                        int ld_out, int64_t rows, int ncol) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ld_out) return;
+    const int64_t r = i / ld_out;
+    const int c = (int)(i - r * ld_out);
+    out[i] = c < ncol ? in[r * ld_in + c] : 0.f;
+}
+
+hipError_t launch_copy_cols(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int ncol, hipStream_t s) {
+    const int64_t n = rows * ld_out;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, ld_in, out, ld_out, rows,
+                       ncol);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- CMVN (model/iv_plda.py:296-377)
+// Centred sliding window of 300 frames, mean only.  window(t) = [start, end) as at :321-336.
+__device__ __forceinline__ void cmvn_window(int t, int F, int& start, int& end) {
+    start = t - kCmnWindow / 2;
+    end = start + kCmnWindow;
+    if (start < 0) {
+        end -= start;
+        start = 0;
+    }
+    if (end > F) {
+        start -= end - F;
+        end = F;
+        if (start < 0) start = 0;
+    }
+}
+
+// grid (B), block 256.  out row stride ld_out >= 30; columns 30..ld_out-1 are zeroed (GEMM K pad).
+__global__ __launch_bounds__(256) void cmvn_fwd_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                       int ld_out, int F) {
+    const int b = blockIdx.x;
+    const float* x = in + (size_t)b * F * ld_in;
+    float* y = out + (size_t)b * F * ld_out;
+    __shared__ double total[kCep];
+    if (F <= kCmnWindow) {
+        // every window is the whole utterance: one column sum per cepstrum
+        if (threadIdx.x < kCep) {
+            double acc = 0.0;
+            for (int t = 0; t < F; ++t) acc += (double)x[(size_t)t * ld_in + threadIdx.x];
+            total[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < F * ld_out; i += 256) {
+            const int t = i / ld_out, d = i - t * ld_out;
+            y[i] = d < kCep ? x[(size_t)t * ld_in + d] - (float)(total[d] / (double)F) : 0.f;
+        }
+    } else {
+        for (int i = threadIdx.x; i < F * ld_out; i += 256) {
+            const int t = i / ld_out, d = i - t * ld_out;
+            float v = 0.f;
+            if (d < kCep) {
+                int s, e;
+                cmvn_window(t, F, s, e);
+                double acc = 0.0;
+                for (int u = s; u < e; ++u) acc += (double)x[(size_t)u * ld_in + d];
+                v = x[(size_t)t * ld_in + d] - (float)(acc / (double)(e - s));
+            }
+            y[i] = v;
+        }
+    }
+}
+
+// d_in[u] = d_out[u] - sum_{t : u in window(t)} d_out[t] / |window(t)|
+__global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout,
+                                                       float* __restrict__ din, int ld_din, int F) {
+    const int b = blockIdx.x;
+    const float* g = dout + (size_t)b * F * ld_dout;
+    float* y = din + (size_t)b * F * ld_din;
+    __shared__ double total[kCep];
+    if (F <= kCmnWindow) {
+        if (threadIdx.x < kCep) {
+            double acc = 0.0;
+            for (int t = 0; t < F; ++t) acc += (double)g[(size_t)t * ld_dout + threadIdx.x];
+            total[threadIdx.x] = acc / (double)F;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < F * kCep; i += 256) {
+            const int t = i / kCep, d = i - t * kCep;
+            y[(size_t)t * ld_din + d] = g[(size_t)t * ld_dout + d] - (float)total[d];
+        }
+    } else {
+        for (int i = threadIdx.x; i < F * kCep; i += 256) {
+            const int u = i / kCep, d = i - u * kCep;
+            double acc = 0.0;
+            for (int t = 0; t < F; ++t) {
+                int s, e;
+                cmvn_window(t, F, s, e);
+                if (u >= s && u < e) acc += (double)g[(size_t)t * ld_dout + d] / (double)(e - s);
+            }
+            y[(size_t)u * ld_din + d] = g[(size_t)u * ld_dout + d] - (float)acc;
+        }
+    }
+}
+
+hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, hipStream_t s) {
+    hipLaunchKernelGGL(cmvn_fwd_kernel, dim3(B), dim3(256), 0, s, in, ld_in, out, ld_out, F);
+    return hipGetLastError();
+}
+hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, float* din, int ld_din, int B, int F, hipStream_t s) {
+    hipLaunchKernelGGL(cmvn_bwd_kernel, dim3(B), dim3(256), 0, s, dout, ld_dout, din, ld_din, F);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- statistics pooling (xvecTDNN.py:62)
+// stats = cat(mean_t, std_t (unbiased)) over the tdnn5 relu output (BatchNorm folded into fc1).
+// grid (kPoolC/64, B), block 256: lane = channel, the 4 waves split the frames.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ act, int Tc, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y;
+    const float* a = act + (size_t)b * Tc * kPoolC + c;
+    __shared__ float red[4][64];
+    float s = 0.f;
+    for (int t = wid; t < Tc; t += 4) s += a[(size_t)t * kPoolC];
+    red[wid][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)Tc;
+    __syncthreads();
+    float q = 0.f;
+    for (int t = wid; t < Tc; t += 4) {
+        const float d = a[(size_t)t * kPoolC] - mean;
+        q += d * d;
+    }
+    red[wid][lane] = q;
+    __syncthreads();
+    if (wid == 0) {
+        const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)(Tc - 1);
+        stats[(size_t)b * kStats + c] = mean;
+        stats[(size_t)b * kStats + kPoolC + c] = sqrtf(var);
+    }
+}
+
+// d act[t][c] = relu'(act) * ( dmean[c]/T + dstd[c] * (act - mean) / ((T-1) * std) ), std == 0 -> no std term
+// (torch std_backward masks result == 0).  dstats arrives as `nsplit` split-K partials.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ act, const float* __restrict__ stats,
+                                                       const float* __restrict__ dpart, int nsplit, int B, int Tc,
+                                                       float* __restrict__ dact) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y;
+    float dmean = 0.f, dstd = 0.f;
+    for (int z = 0; z < nsplit; ++z) {
+        dmean += dpart[((size_t)z * B + b) * kStats + c];
+        dstd += dpart[((size_t)z * B + b) * kStats + kPoolC + c];
+    }
+    const float mean = stats[(size_t)b * kStats + c];
+    const float sd = stats[(size_t)b * kStats + kPoolC + c];
+    const float beta = sd > 0.f ? dstd / ((float)(Tc - 1) * sd) : 0.f;
+    const float alpha = dmean / (float)Tc;
+    const float* a = act + (size_t)b * Tc * kPoolC + c;
+    float* d = dact + (size_t)b * Tc * kPoolC + c;
+    for (int t = wid; t < Tc; t += 4) {
+        const float v = a[(size_t)t * kPoolC];
+        d[(size_t)t * kPoolC] = v > 0.f ? alpha + beta * (v - mean) : 0.f;
+    }
+}
+
+hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(kPoolC / 64, B), dim3(256), 0, s, act5, Tc, stats);
+    return hipGetLastError();
+}
+hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit, int B, int Tc,
+                           float* dact5, hipStream_t s) {
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(kPoolC / 64, B), dim3(256), 0, s, act5, stats, dstats_part, nsplit, B, Tc,
+                       dact5);
+    return hipGetLastError();
+}
+
+}  // namespace sg

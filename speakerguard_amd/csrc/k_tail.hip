@@ -1,0 +1,234 @@
+// Per-utterance tail of the x-vector system, forward and backward in one workgroup:
+//   fc1 output (split-K partials + folded bias)          xvecTDNN.py:63
+//   - emb_mean                                            xvector_extract.py:42 / iv_plda.py:419
+//   LDA affine  A[:, :512] e + A[:, 512]                  iv_plda.py:423-435
+//   length normalisation to sqrt(D) (norm is DETACHED: .item() at xvector_extract.py:33)
+//   PLDA transform P (e - mu), normalisation factor sqrt(D / sum e^2/(psi+1))   plda.py:73-97
+//   PLDA log-likelihood-ratio against each enrolled speaker                      plda.py:140-190
+//   decision = argmax, rejected (-1) unless max > threshold                      iv_plda.py:182-194
+//   loss (attack/utils.py:7-102) and d loss/d scores, then the chain back to d loss/d fc1-output.
+// One block of 256 threads per utterance; reductions are wavefront shuffles + a 4-entry LDS pass.
+#include "sg_internal.h"
+
+namespace sg {
+
+constexpr int kMaxD = 512;
+constexpr int kMaxS = 1024;
+
+struct TailModelDev {
+    const float *fc1_b, *emb_mean, *lda, *lda_t, *plda_mean, *plda_p, *plda_pt, *plda_psi, *enroll;
+    int D, S;
+    float threshold, logdet_given, logdet_without;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* __restrict__ fc1_part, int nsplit, int B,
+                                                   const int64_t* __restrict__ y, sg_loss_spec ls, int want_grad,
+                                                   float* __restrict__ tdnn_emb, float* __restrict__ emb_out,
+                                                   float* __restrict__ scores_out, int64_t* __restrict__ dec_out,
+                                                   float* __restrict__ loss_out, float* __restrict__ demb,
+                                                   float* __restrict__ loss_trace, int64_t* __restrict__ dec_trace,
+                                                   uint8_t* __restrict__ success) {
+    __shared__ float e1[kEmb];
+    __shared__ float e2[kMaxD], e4[kMaxD], e5[kMaxD], dv[kMaxD];
+    __shared__ float sc[kMaxS], dsc[kMaxS];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int D = m.D, S = m.S;
+    const float sqrtD = sqrtf((float)D);
+
+    // 1. fc1 output, global-mean subtraction
+    for (int i = tid; i < kEmb; i += 256) {
+        float v = 0.f;
+        for (int z = 0; z < nsplit; ++z) v += fc1_part[((size_t)z * B + b) * kEmb + i];
+        v += m.fc1_b[i];
+        if (tdnn_emb) tdnn_emb[(size_t)b * kEmb + i] = v;
+        e1[i] = v - m.emb_mean[i];
+    }
+    __syncthreads();
+    // 2. LDA
+    float n2 = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < kEmb; ++i) acc += m.lda_t[(size_t)i * D + d] * e1[i];
+        acc += m.lda_t[(size_t)kEmb * D + d];
+        e2[d] = acc;
+        n2 += acc * acc;
+    }
+    // 3. length normalisation (ratio is a constant for the backward pass)
+    const float ratio = sqrtD / sqrtf(block_sum(n2, red));
+    for (int d = tid; d < D; d += 256) e2[d] = e2[d] * ratio - m.plda_mean[d];
+    __syncthreads();
+    // 4. PLDA transform + normalisation factor
+    float qp = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < D; ++j) acc += m.plda_pt[(size_t)j * D + d] * e2[j];
+        e4[d] = acc;
+        qp += acc * acc / (m.plda_psi[d] + 1.f);
+    }
+    const float q = block_sum(qp, red);
+    const float fac = sqrtf((float)D / q);
+    for (int d = tid; d < D; d += 256) {
+        e5[d] = e4[d] * fac;
+        if (emb_out) emb_out[(size_t)b * D + d] = e5[d];
+    }
+    __syncthreads();
+    // 5. PLDA scores: one wave per enrolled speaker
+    {
+        const int lane = tid & 63, wid = tid >> 6;
+        const float l2pi = logf(2.f * 3.1415926f) * (float)D;  // plda.py:179 (cancels in the ratio)
+        float s0 = 0.f;  // sum e5^2 / (psi + 1)
+        for (int d = lane; d < D; d += 64) s0 += e5[d] * e5[d] * (1.f / (m.plda_psi[d] + 1.f));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+        const float without = -0.5f * (m.logdet_without + l2pi + s0);
+        for (int s = wid; s < S; s += 4) {
+            float s1 = 0.f;
+            for (int d = lane; d < D; d += 64) {
+                const float psi = m.plda_psi[d];
+                const float r = psi / (psi + 1.f);
+                const float df = e5[d] - r * m.enroll[(size_t)s * D + d];
+                s1 += df * df * (1.f / (1.f + r));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            if (lane == 0) {
+                const float given = -0.5f * (m.logdet_given + l2pi + s1);
+                sc[s] = given - without;
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += 256) {
+        if (scores_out) scores_out[(size_t)b * S + s] = sc[s];
+        dsc[s] = 0.f;
+    }
+    __syncthreads();
+    // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
+    if (tid == 0) {
+        int ja = 0;
+        float mx = sc[0];
+        for (int s = 1; s < S; ++s)
+            if (sc[s] > mx) { mx = sc[s]; ja = s; }
+        const int64_t dec = mx > m.threshold ? (int64_t)ja : (int64_t)-1;
+        if (dec_out) dec_out[b] = dec;
+        if (dec_trace) dec_trace[b] = dec;
+        float loss = 0.f;
+        if (y) {
+            const int64_t yy = y[b];
+            if (success) success[b] = ls.targeted ? (dec == yy) : (dec != yy);
+            if (ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI) {
+                if (yy >= 0) {
+                    float se = 0.f;
+                    for (int s = 0; s < S; ++s) se += expf(sc[s] - mx);
+                    const float lse = mx + logf(se);
+                    loss = lse - sc[yy];
+                    for (int s = 0; s < S; ++s) dsc[s] = expf(sc[s] - lse);
+                    dsc[yy] -= 1.f;
+                }
+            } else if (ls.task == SG_TASK_SV) {
+                const bool enr = yy == 0;
+                if (enr == (ls.targeted != 0)) { loss = ls.threshold + ls.confidence - sc[0]; dsc[0] = -1.f; }
+                else { loss = sc[0] + ls.confidence - ls.threshold; dsc[0] = 1.f; }
+            } else if (yy >= 0) {
+                const float real = sc[yy];
+                int jo = -1;
+                float other = -10000.f;  // attack/utils.py:72
+                for (int s = 0; s < S; ++s)
+                    if (s != yy && sc[s] > other) { other = sc[s]; jo = s; }
+                if (ls.targeted) {
+                    if (ls.task == SG_TASK_CSI) {
+                        loss = other + ls.confidence - real;
+                        if (jo >= 0) dsc[jo] += 1.f;
+                    } else {
+                        loss = fmaxf(other, ls.threshold) + ls.confidence - real;
+                        if (jo >= 0 && other >= ls.threshold) dsc[jo] += 1.f;
+                    }
+                    dsc[yy] -= 1.f;
+                } else if (ls.task == SG_TASK_CSI) {
+                    loss = real + ls.confidence - other;
+                    dsc[yy] += 1.f;
+                    if (jo >= 0) dsc[jo] -= 1.f;
+                } else {
+                    const float f_rej = mx + ls.confidence - ls.threshold;
+                    const float f_mis = fmaxf(real, ls.threshold) + ls.confidence - other;
+                    loss = fminf(f_rej, f_mis);
+                    const float wr = f_rej < f_mis ? 1.f : (f_rej == f_mis ? 0.5f : 0.f);
+                    dsc[ja] += wr;
+                    if (real >= ls.threshold) dsc[yy] += 1.f - wr;
+                    if (jo >= 0) dsc[jo] -= 1.f - wr;
+                }
+            } else if (ls.task == SG_TASK_OSI) {
+                if (ls.targeted) { loss = mx + ls.confidence - ls.threshold; dsc[ja] = 1.f; }
+                else { loss = ls.threshold + ls.confidence - mx; dsc[ja] = -1.f; }
+            }
+            if (ls.loss == SG_LOSS_MARGIN || ls.task != SG_TASK_CSI) {
+                if (ls.clip_max) {
+                    const float k = loss > 0.f ? 1.f : (loss == 0.f ? 0.5f : 0.f);
+                    for (int s = 0; s < S; ++s) dsc[s] *= k;
+                    loss = fmaxf(loss, 0.f);
+                }
+            }
+        }
+        if (loss_out) loss_out[b] = loss;
+        if (loss_trace) loss_trace[b] = loss;
+    }
+    __syncthreads();
+    if (!want_grad || !demb) return;
+    // 9. d/d e5 of the score combination
+    float dotp = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        const float psi = m.plda_psi[d];
+        const float r = psi / (psi + 1.f);
+        const float iv1 = 1.f / (1.f + r), iv0 = 1.f / (psi + 1.f);
+        float g = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float w = dsc[s];
+            if (w != 0.f) g += w * (-(e5[d] - r * m.enroll[(size_t)s * D + d]) * iv1 + e5[d] * iv0);
+        }
+        dv[d] = g;
+        dotp += g * e4[d];
+    }
+    // 10. through the PLDA normalisation factor (differentiable, plda.py:92-97)
+    const float dot = block_sum(dotp, red);
+    for (int d = tid; d < D; d += 256) dv[d] = fac * dv[d] - dot * (fac / q) * e4[d] / (m.plda_psi[d] + 1.f);
+    __syncthreads();
+    // 11-12. P^T, length-norm ratio
+    for (int j = tid; j < D; j += 256) {
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += m.plda_p[(size_t)d * D + j] * dv[d];
+        e2[j] = acc * ratio;
+    }
+    __syncthreads();
+    // 13. LDA^T -> d loss / d fc1 output
+    for (int i = tid; i < kEmb; i += 256) {
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += m.lda[(size_t)d * (kEmb + 1) + i] * e2[d];
+        demb[(size_t)b * kEmb + i] = acc;
+    }
+}
+
+hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
+    const XvModel& x = *a.m;
+    if (x.D > kMaxD || x.S > kMaxS || x.S < 1) return hipErrorInvalidValue;
+    TailModelDev m;
+    m.fc1_b = x.fc1_b; m.emb_mean = x.emb_mean; m.lda = x.lda; m.lda_t = x.lda_t; m.plda_mean = x.plda_mean;
+    m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi; m.enroll = x.enroll;
+    m.D = x.D; m.S = x.S; m.threshold = x.threshold;
+    m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
+    hipLaunchKernelGGL(tail_kernel, dim3(a.B), dim3(256), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
+                       a.tdnn_emb, a.emb, a.scores, a.decisions, a.loss_out, a.demb, a.loss_trace, a.decision_trace,
+                       a.success);
+    return hipGetLastError();
+}
+
+}  // namespace sg

@@ -1,0 +1,637 @@
+// C-ABI entry points (include/speakerguard_hip.h): context, model load (BatchNorm folding and
+// weight re-layout), workspace, and the kernel sequences of one forward / backward / PGD pass.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "sg_internal.h"
+
+using namespace sg;
+
+namespace {
+
+int fail(sg_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define SG_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, SG_ERR_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                                          hipGetErrorString(e_), __FILE__, __LINE__);                  \
+    } while (0)
+
+template <typename T>
+int dev_alloc(sg_ctx* ctx, std::vector<void*>& pool, T** out, size_t count) {
+    void* p = nullptr;
+    SG_HIP(hipMalloc(&p, count * sizeof(T) + 256));
+    pool.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return SG_OK;
+}
+
+template <typename T>
+int dev_upload(sg_ctx* ctx, std::vector<void*>& pool, T** out, const std::vector<T>& host) {
+    int rc = dev_alloc(ctx, pool, out, host.size());
+    if (rc) return rc;
+    SG_HIP(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// MFCC constant tables (torchaudio kaldi.py v0.6.0: _feature_window_function, get_mel_banks,
+// _get_dct_matrix, _get_lifter_coeffs), computed here in double and rounded once to fp32.
+int build_tables(sg_ctx* ctx) {
+    if (ctx->tables_ready) return SG_OK;
+    const double PI = 3.14159265358979323846;
+    std::vector<float> window(kWin), melw(kMel * 256, 0.f), dct(kMel * kCep), lifter(kCep), w0(256, 0.f), w1(256, 0.f);
+    std::vector<int> lo(kMel), hi(kMel), m0(256, -1);
+    std::vector<float2> tw(256);
+    std::vector<uint16_t> br(kFft);
+    for (int n = 0; n < kWin; ++n) window[n] = (float)std::pow(0.5 - 0.5 * std::cos(2.0 * PI * n / (kWin - 1)), 0.85);
+    auto mel = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
+    const double mel_low = mel(20.0), mel_high = mel(7600.0);
+    const double delta = (mel_high - mel_low) / (kMel + 1);
+    const double bin_width = 16000.0 / kFft;
+    for (int m = 0; m < kMel; ++m) {
+        const double left = mel_low + m * delta, center = left + delta, right = center + delta;
+        lo[m] = 256;
+        hi[m] = 0;
+        for (int k = 0; k < 256; ++k) {
+            const double mk = mel(bin_width * k);
+            const double up = (mk - left) / (center - left), down = (right - mk) / (right - center);
+            const double w = std::fmax(0.0, std::fmin(up, down));
+            melw[m * 256 + k] = (float)w;
+            if (w > 0.0) {
+                if (k < lo[m]) lo[m] = k;
+                hi[m] = k + 1;
+            }
+        }
+        if (lo[m] > hi[m]) lo[m] = hi[m] = 0;
+    }
+    for (int k = 0; k < 256; ++k) {
+        int first = -1, cnt = 0;
+        for (int m = 0; m < kMel; ++m)
+            if (melw[m * 256 + k] > 0.f) {
+                if (first < 0) first = m;
+                ++cnt;
+            }
+        if (cnt > 2 || (cnt == 2 && melw[(first + 1) * 256 + k] <= 0.f))
+            return fail(ctx, SG_ERR_STATE, "mel filterbank is not a two-overlap triangular bank");
+        m0[k] = first;
+        if (first >= 0) {
+            w0[k] = melw[first * 256 + k];
+            w1[k] = first + 1 < kMel ? melw[(first + 1) * 256 + k] : 0.f;
+        }
+    }
+    for (int m = 0; m < kMel; ++m)
+        for (int c = 0; c < kCep; ++c)
+            dct[m * kCep + c] = c == 0 ? (float)std::sqrt(1.0 / kMel)
+                                       : (float)(std::cos(PI / kMel * (m + 0.5) * c) * std::sqrt(2.0 / kMel));
+    for (int c = 0; c < kCep; ++c) lifter[c] = (float)(1.0 + 0.5 * 22.0 * std::sin(PI * c / 22.0));
+    for (int k = 0; k < 256; ++k) tw[k] = make_float2((float)std::cos(2.0 * PI * k / kFft), (float)-std::sin(2.0 * PI * k / kFft));
+    for (int i = 0; i < kFft; ++i) {
+        int r = 0;
+        for (int bit = 0; bit < 9; ++bit)
+            if (i & (1 << bit)) r |= 1 << (8 - bit);
+        br[i] = (uint16_t)r;
+    }
+    MfccTables& t = ctx->tab;
+    int rc = 0;
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.window, window);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_w, melw);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_lo, lo);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_hi, hi);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.bin_m0, m0);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.bin_w0, w0);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.bin_w1, w1);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.dct, dct);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.lifter, lifter);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
+    rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
+    if (rc) return SG_ERR_HIP;
+    ctx->tables_ready = true;
+    return SG_OK;
+}
+
+// TDNN frames after each layer for F input frames
+bool layer_frames(int F, int* Fl) {
+    int f = F;
+    for (int l = 0; l < kLayers; ++l) {
+        f -= (kTaps[l] - 1) * kDil[l];
+        Fl[l] = f;
+    }
+    return f >= 2;  // unbiased std needs two frames
+}
+
+int ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
+    Workspace& w = ctx->ws;
+    if (B <= w.B && F <= w.F && T <= w.T && w.scale) {
+        layer_frames(F, w.Fl);
+        return SG_OK;
+    }
+    (void)hipDeviceSynchronize();
+    free_pool(w.allocs);
+    const int cb = B > w.B ? B : w.B, cf = F > w.F ? F : w.F, ct = T > w.T ? T : w.T;
+    w = Workspace();
+    w.B = cb; w.F = cf; w.T = ct;
+    int Fl[kLayers];
+    layer_frames(cf, Fl);
+    const size_t b = (size_t)cb;
+    int rc = 0;
+    rc |= dev_alloc(ctx, w.allocs, &w.scale, 4);
+    rc |= dev_alloc(ctx, w.allocs, &w.feats_raw, b * cf * kCep);
+    rc |= dev_alloc(ctx, w.allocs, &w.feats, b * cf * kFeatPad);
+    for (int l = 0; l < kLayers; ++l) {
+        const size_t rows = b * (size_t)(Fl[l] > 0 ? Fl[l] : 1);
+        rc |= dev_alloc(ctx, w.allocs, &w.act[l], rows * kCoutPad[l]);
+        rc |= dev_alloc(ctx, w.allocs, &w.dact[l], rows * kCoutPad[l]);
+    }
+    rc |= dev_alloc(ctx, w.allocs, &w.dfeats, b * cf * kFeatPad);
+    rc |= dev_alloc(ctx, w.allocs, &w.dfeats_raw, b * cf * kCep);
+    rc |= dev_alloc(ctx, w.allocs, &w.dframes, b * cf * kWin);
+    rc |= dev_alloc(ctx, w.allocs, &w.stats, b * kStats);
+    rc |= dev_alloc(ctx, w.allocs, &w.fc1_part, (size_t)kFc1SplitK * b * kEmb);
+    rc |= dev_alloc(ctx, w.allocs, &w.demb, b * kEmb);
+    rc |= dev_alloc(ctx, w.allocs, &w.dstats_part, (size_t)kFc1BwdSplitK * b * kStats);
+    rc |= dev_alloc(ctx, w.allocs, &w.tdnn_emb, b * kEmb);
+    rc |= dev_alloc(ctx, w.allocs, &w.emb, b * 512);
+    rc |= dev_alloc(ctx, w.allocs, &w.scores, b * 1024);
+    rc |= dev_alloc(ctx, w.allocs, &w.loss, b);
+    rc |= dev_alloc(ctx, w.allocs, &w.decisions, b);
+    rc |= dev_alloc(ctx, w.allocs, &w.grad, b * (size_t)(ct > 0 ? ct : 1));
+    if (rc) {
+        free_pool(w.allocs);
+        w = Workspace();
+        return SG_ERR_HIP;
+    }
+    layer_frames(F, w.Fl);
+    return SG_OK;
+}
+
+struct PassDims {
+    int B, T, F;
+};
+
+// waveform / features -> padded CMVN features in ws.feats
+int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz, hipStream_t s) {
+    Workspace& w = ctx->ws;
+    if (flag == SG_FLAG_WAV) {
+        SG_HIP(launch_input_scale(x, (int64_t)d.B * d.T, w.scale, s));
+        SG_HIP(launch_mfcc_fwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
+        SG_HIP(launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
+    } else if (flag == SG_FLAG_RAW) {
+        SG_HIP(launch_cmvn_fwd(x, kCep, w.feats, kFeatPad, d.B, d.F, s));
+    } else {
+        SG_HIP(launch_copy_cols(x, kCep, w.feats, kFeatPad, (int64_t)d.B * d.F, kCep, s));
+    }
+    return SG_OK;
+}
+
+ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
+    const Workspace& w = ctx->ws;
+    ConvGemmArgs a{};
+    a.A = l == 0 ? w.feats : w.act[l - 1];
+    a.W = ctx->xv.wf[l];
+    a.C = w.act[l];
+    a.bias = ctx->xv.bias[l];
+    a.mask = nullptr;
+    a.Ta = l == 0 ? F : w.Fl[l - 1];
+    a.Tc = w.Fl[l];
+    a.M = B * a.Tc;
+    a.N = kCoutPad[l];
+    a.Kc = kCinPad[l];
+    a.lda = kCinPad[l];
+    a.ldw = kCoutPad[l];
+    a.ldc = kCoutPad[l];
+    a.taps = kTaps[l];
+    a.tap_step = kDil[l];
+    a.total_chunks = a.taps * (a.Kc / 32);
+    a.chunks_per_split = a.total_chunks;
+    a.split_stride = 0;
+    return a;
+}
+
+int run_tdnn_forward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
+    Workspace& w = ctx->ws;
+    for (int l = 0; l < kLayers; ++l) {
+        ConvGemmArgs a = fwd_layer_args(ctx, l, d.B, d.F);
+        SG_HIP(launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));
+    }
+    SG_HIP(launch_pool_fwd(w.act[4], d.B, w.Fl[4], w.stats, s));
+    // fc1 as a split-K contraction: (B x 3072) x (3072 x 512) -> kFc1SplitK partial slabs
+    ConvGemmArgs a{};
+    a.A = w.stats; a.W = ctx->xv.fc1_w; a.C = w.fc1_part; a.bias = nullptr; a.mask = nullptr;
+    a.M = d.B; a.N = kEmb; a.Ta = 1; a.Tc = 1; a.Kc = kStats; a.lda = kStats; a.ldw = kEmb; a.ldc = kEmb;
+    a.taps = 1; a.tap_step = 0; a.total_chunks = kStats / 32;
+    a.chunks_per_split = a.total_chunks / kFc1SplitK;
+    a.split_stride = (long long)d.B * kEmb;
+    SG_HIP(launch_conv_gemm(a, 2, EPI_NONE, kFc1SplitK, s));
+    return SG_OK;
+}
+
+// d loss / d fc1-output (ws.demb) -> d loss / d padded CMVN features (ws.dfeats)
+int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
+    Workspace& w = ctx->ws;
+    {
+        ConvGemmArgs a{};
+        a.A = w.demb; a.W = ctx->xv.fc1_wt; a.C = w.dstats_part; a.bias = nullptr; a.mask = nullptr;
+        a.M = d.B; a.N = kStats; a.Ta = 1; a.Tc = 1; a.Kc = kEmb; a.lda = kEmb; a.ldw = kStats; a.ldc = kStats;
+        a.taps = 1; a.tap_step = 0; a.total_chunks = kEmb / 32;
+        a.chunks_per_split = a.total_chunks / kFc1BwdSplitK;
+        a.split_stride = (long long)d.B * kStats;
+        SG_HIP(launch_conv_gemm(a, 2, EPI_NONE, kFc1BwdSplitK, s));
+    }
+    SG_HIP(launch_pool_bwd(w.act[4], w.stats, w.dstats_part, kFc1BwdSplitK, d.B, w.Fl[4], w.dact[4], s));
+    for (int l = kLayers - 1; l >= 0; --l) {
+        ConvGemmArgs a{};
+        a.A = w.dact[l];
+        a.W = ctx->xv.wb[l];
+        a.C = l == 0 ? w.dfeats : w.dact[l - 1];
+        a.bias = nullptr;
+        a.mask = l == 0 ? nullptr : w.act[l - 1];
+        a.Ta = w.Fl[l];
+        a.Tc = l == 0 ? d.F : w.Fl[l - 1];
+        a.M = d.B * a.Tc;
+        a.N = kCinPad[l];
+        a.Kc = kCoutPad[l];
+        a.lda = kCoutPad[l];
+        a.ldw = kCinPad[l];
+        a.ldc = kCinPad[l];
+        a.taps = kTaps[l];
+        a.tap_step = -kDil[l];
+        a.total_chunks = a.taps * (a.Kc / 32);
+        a.chunks_per_split = a.total_chunks;
+        a.split_stride = 0;
+        SG_HIP(launch_conv_gemm(a, l == 0 ? 1 : 0, l == 0 ? EPI_NONE : EPI_RELU_MASK, 1, s));
+    }
+    return SG_OK;
+}
+
+int check_dims(sg_ctx* ctx, int B, int TF, int flag, PassDims* d) {
+    if (!ctx) return SG_ERR_ARG;
+    if (!ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no x-vector model loaded (call sg_xv_load)");
+    SG_HIP(hipSetDevice(ctx->device));
+    if (B < 1) return fail(ctx, SG_ERR_ARG, "B must be >= 1");
+    if (flag < 0 || flag > 2) return fail(ctx, SG_ERR_ARG, "flag must be 0 (wav), 1 (raw feat) or 2 (cmvn feat)");
+    d->B = B;
+    if (flag == SG_FLAG_WAV) {
+        if (TF < kWin) return fail(ctx, SG_ERR_ARG, "waveform shorter than one 25 ms window");
+        d->T = TF;
+        d->F = num_frames(TF);
+    } else {
+        d->T = 0;
+        d->F = TF;
+    }
+    int Fl[kLayers];
+    if (!layer_frames(d->F, Fl)) return fail(ctx, SG_ERR_ARG, "%d frames are too few for the TDNN context", d->F);
+    int rc = build_tables(ctx);
+    if (rc) return rc;
+    rc = ensure_workspace(ctx, d->B, d->T, d->F);
+    if (rc) return fail(ctx, rc, "workspace allocation failed: %s", ctx->err.c_str());
+    return SG_OK;
+}
+
+// after the tail produced ws.demb: chain back to the caller's input level
+int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz,
+                          float* grad_out, float* x_update, const float* lower, const float* upper, float step,
+                          int grad_sign, hipStream_t s) {
+    Workspace& w = ctx->ws;
+    int rc = run_tdnn_backward(ctx, d, s);
+    if (rc) return rc;
+    if (flag == SG_FLAG_CMVN) {
+        SG_HIP(launch_copy_cols(w.dfeats, kFeatPad, grad_out, kCep, (int64_t)d.B * d.F, kCep, s));
+    } else if (flag == SG_FLAG_RAW) {
+        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, grad_out, kCep, d.B, d.F, s));
+    } else {
+        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, w.dfeats_raw, kCep, d.B, d.F, s));
+        SG_HIP(launch_mfcc_bwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
+        SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_out, x_update, lower, upper, step, grad_sign, s));
+    }
+    return SG_OK;
+}
+
+}  // namespace
+
+// ============================================================================== C-ABI
+extern "C" {
+
+int sg_version(void) { return 100; }
+
+int sg_create(int device, sg_ctx** out) {
+    if (!out) return SG_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SG_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return SG_ERR_HIP;
+    sg_ctx* ctx = new (std::nothrow) sg_ctx();
+    if (!ctx) return SG_ERR_HIP;
+    ctx->device = device;
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return SG_ERR_HIP;
+    }
+    *out = ctx;
+    return SG_OK;
+}
+
+void sg_destroy(sg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_pool(ctx->ws.allocs);
+    free_pool(ctx->model_allocs);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* sg_last_error(const sg_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sg_sync(sg_ctx* ctx, void* stream) {
+    if (!ctx) return SG_ERR_ARG;
+    SG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SG_OK;
+}
+
+int32_t sg_xv_num_frames(int32_t T) { return T < kWin ? 0 : num_frames(T); }
+
+int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
+    if (!ctx || !w) return SG_ERR_ARG;
+    if (w->D < 1 || w->D > 512 || w->S < 1 || w->S > 1024) return fail(ctx, SG_ERR_ARG, "D must be 1..512 and S 1..1024");
+    for (int l = 0; l < kLayers; ++l)
+        if (!w->tdnn_weight[l] || !w->tdnn_bias[l] || !w->bn_mean[l] || !w->bn_var[l])
+            return fail(ctx, SG_ERR_ARG, "missing TDNN tensor for layer %d", l + 1);
+    if (!w->fc1_weight || !w->fc1_bias || !w->emb_mean || !w->lda || !w->plda_mean || !w->plda_transform ||
+        !w->plda_psi || !w->enroll)
+        return fail(ctx, SG_ERR_ARG, "missing back-end tensor");
+    SG_HIP(hipSetDevice(ctx->device));
+    int rc = build_tables(ctx);
+    if (rc) return rc;
+    XvModel& m = ctx->xv;
+    m = XvModel();
+    std::vector<void*>& pool = ctx->model_allocs;
+    const double eps = w->bn_eps > 0.f ? w->bn_eps : 1e-5;
+
+    // BatchNorm1d(affine=False) in eval mode is y = (a - mean) * r, r = 1/sqrt(var + eps), applied
+    // AFTER the ReLU (xvecTDNN.py:49-53).  It is folded into the NEXT layer: W'[co][ci][j] =
+    // W[co][ci][j] * r[ci], b'[co] = b[co] - sum_{ci,j} W[co][ci][j] * mean[ci] * r[ci]; no padding
+    // is used by the convolutions, so the fold is exact at every frame.  Stored activations are
+    // therefore the ReLU outputs, and the ReLU mask of the backward pass is simply act > 0.
+    std::vector<double> r_prev, m_prev;
+    for (int l = 0; l < kLayers; ++l) {
+        const int cin = kCin[l], cout = kCout[l], k = kTaps[l], cip = kCinPad[l], cop = kCoutPad[l];
+        std::vector<float> wf((size_t)k * cip * cop, 0.f), wb((size_t)k * cop * cip, 0.f), bias(cop, 0.f);
+        for (int co = 0; co < cout; ++co) {
+            double bacc = w->tdnn_bias[l][co];
+            for (int ci = 0; ci < cin; ++ci) {
+                for (int j = 0; j < k; ++j) {
+                    double v = w->tdnn_weight[l][((size_t)co * cin + ci) * k + j];
+                    if (l > 0) {
+                        bacc -= v * m_prev[ci] * r_prev[ci];
+                        v *= r_prev[ci];
+                    }
+                    wf[((size_t)j * cip + ci) * cop + co] = (float)v;
+                    wb[((size_t)j * cop + co) * cip + ci] = (float)v;
+                }
+            }
+            bias[co] = (float)bacc;
+        }
+        rc |= dev_upload(ctx, pool, &m.wf[l], wf);
+        rc |= dev_upload(ctx, pool, &m.wb[l], wb);
+        rc |= dev_upload(ctx, pool, &m.bias[l], bias);
+        r_prev.assign(cout, 0.0);
+        m_prev.assign(cout, 0.0);
+        for (int c = 0; c < cout; ++c) {
+            r_prev[c] = 1.0 / std::sqrt((double)w->bn_var[l][c] + eps);
+            m_prev[c] = w->bn_mean[l][c];
+        }
+    }
+    {
+        // fc1 over stats = [mean | std] of bn5 output: mean_y = (mean_a - m) r, std_y = std_a r
+        std::vector<float> fw((size_t)kStats * kEmb, 0.f), fwt((size_t)kEmb * kStats, 0.f), fb(kEmb);
+        const int c5 = kCout[4];
+        for (int n = 0; n < kEmb; ++n) {
+            double bacc = w->fc1_bias[n];
+            for (int c = 0; c < c5; ++c) {
+                const double wm = w->fc1_weight[(size_t)n * 2 * c5 + c];
+                const double wsd = w->fc1_weight[(size_t)n * 2 * c5 + c5 + c];
+                bacc -= wm * m_prev[c] * r_prev[c];
+                const float fm = (float)(wm * r_prev[c]), fs = (float)(wsd * r_prev[c]);
+                fw[(size_t)c * kEmb + n] = fm;
+                fw[(size_t)(kPoolC + c) * kEmb + n] = fs;
+                fwt[(size_t)n * kStats + c] = fm;
+                fwt[(size_t)n * kStats + kPoolC + c] = fs;
+            }
+            fb[n] = (float)bacc;
+        }
+        rc |= dev_upload(ctx, pool, &m.fc1_w, fw);
+        rc |= dev_upload(ctx, pool, &m.fc1_wt, fwt);
+        rc |= dev_upload(ctx, pool, &m.fc1_b, fb);
+    }
+    const int D = w->D, S = w->S;
+    {
+        std::vector<float> lda(w->lda, w->lda + (size_t)D * (kEmb + 1)), ldat((size_t)(kEmb + 1) * D);
+        for (int d = 0; d < D; ++d)
+            for (int i = 0; i <= kEmb; ++i) ldat[(size_t)i * D + d] = lda[(size_t)d * (kEmb + 1) + i];
+        std::vector<float> p(w->plda_transform, w->plda_transform + (size_t)D * D), pt((size_t)D * D);
+        for (int d = 0; d < D; ++d)
+            for (int j = 0; j < D; ++j) pt[(size_t)j * D + d] = p[(size_t)d * D + j];
+        double ldg = 0.0, ldw = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double psi = w->plda_psi[d];
+            ldg += std::log(1.0 + psi / (psi + 1.0));
+            ldw += std::log(psi + 1.0);
+        }
+        m.logdet_given = (float)ldg;
+        m.logdet_without = (float)ldw;
+        rc |= dev_upload(ctx, pool, &m.emb_mean, std::vector<float>(w->emb_mean, w->emb_mean + kEmb));
+        rc |= dev_upload(ctx, pool, &m.lda, lda);
+        rc |= dev_upload(ctx, pool, &m.lda_t, ldat);
+        rc |= dev_upload(ctx, pool, &m.plda_mean, std::vector<float>(w->plda_mean, w->plda_mean + D));
+        rc |= dev_upload(ctx, pool, &m.plda_p, p);
+        rc |= dev_upload(ctx, pool, &m.plda_pt, pt);
+        rc |= dev_upload(ctx, pool, &m.plda_psi, std::vector<float>(w->plda_psi, w->plda_psi + D));
+        rc |= dev_upload(ctx, pool, &m.enroll, std::vector<float>(w->enroll, w->enroll + (size_t)S * D));
+    }
+    if (rc) return fail(ctx, SG_ERR_HIP, "model upload failed: %s", ctx->err.c_str());
+    m.D = D;
+    m.S = S;
+    m.threshold = w->threshold;
+    m.loaded = true;
+    return SG_OK;
+}
+
+int sg_xv_set_enroll(sg_ctx* ctx, const float* enroll_host, int32_t S, float threshold) {
+    if (!ctx || !ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no model loaded");
+    if (S < 1 || S > 1024) return fail(ctx, SG_ERR_ARG, "S must be 1..1024");
+    if (enroll_host) {
+        SG_HIP(hipDeviceSynchronize());
+        int rc = dev_upload(ctx, ctx->model_allocs, &ctx->xv.enroll,
+                            std::vector<float>(enroll_host, enroll_host + (size_t)S * ctx->xv.D));
+        if (rc) return rc;
+        ctx->xv.S = S;
+    }
+    ctx->xv.threshold = threshold;
+    return SG_OK;
+}
+
+int sg_input_scale(sg_ctx* ctx, const float* x_dev, int64_t n, float* scale_dev, void* stream) {
+    if (!ctx || !x_dev || !scale_dev || n < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_input_scale(x_dev, n, scale_dev, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_xv_mfcc(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* scale_dev, const sg_dither* dither,
+               float* feats_dev, void* stream) {
+    if (!ctx || !x_dev || !feats_dev || B < 1 || T < kWin) return fail(ctx, SG_ERR_ARG, "bad argument");
+    int rc = build_tables(ctx);
+    if (rc) return rc;
+    SG_HIP(launch_mfcc_fwd(ctx->tab, x_dev, B, T, num_frames(T), scale_dev, dither, feats_dev, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_xv_cmvn(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, float* out_dev, void* stream) {
+    if (!ctx || !feats_dev || !out_dev || B < 1 || F < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_cmvn_fwd(feats_dev, kCep, out_dev, kCep, B, F, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_xv_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag, const sg_dither* dither,
+                  int64_t* decisions_dev, float* scores_dev, float* emb_dev, float* tdnn_emb_dev, void* stream) {
+    PassDims d;
+    int rc = check_dims(ctx, B, T_or_F, flag, &d);
+    if (rc) return rc;
+    if (!x_dev) return fail(ctx, SG_ERR_ARG, "x is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = run_frontend(ctx, x_dev, d, flag, dither, s))) return rc;
+    if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
+    Workspace& w = ctx->ws;
+    TailArgs t{};
+    t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = nullptr; t.want_grad = 0;
+    t.tdnn_emb = tdnn_emb_dev; t.emb = emb_dev; t.scores = scores_dev; t.decisions = decisions_dev;
+    SG_HIP(launch_tail(t, s));
+    return SG_OK;
+}
+
+int sg_xv_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t capacity_floats, int32_t* rows_per_utt,
+                           int32_t* channels, void* stream) {
+    if (!ctx || layer < 1 || layer > kLayers || !ctx->ws.scale) return fail(ctx, SG_ERR_ARG, "bad layer or no pass run");
+    const Workspace& w = ctx->ws;
+    const int l = layer - 1;
+    if (rows_per_utt) *rows_per_utt = w.Fl[l];
+    if (channels) *channels = kCoutPad[l];
+    if (out_dev) {
+        if (capacity_floats <= 0) return fail(ctx, SG_ERR_ARG, "capacity must be positive");
+        SG_HIP(hipMemcpyAsync(out_dev, w.act[l], (size_t)capacity_floats * sizeof(float), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+    }
+    return SG_OK;
+}
+
+int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32_t B, int32_t T_or_F, int32_t flag,
+                    const sg_loss_spec* loss, const sg_dither* dither, int64_t* decisions_dev, float* scores_dev,
+                    float* loss_dev, float* grad_dev, void* stream) {
+    PassDims d;
+    int rc = check_dims(ctx, B, T_or_F, flag, &d);
+    if (rc) return rc;
+    if (!x_dev || !y_dev || !loss) return fail(ctx, SG_ERR_ARG, "x, y and loss are required");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = run_frontend(ctx, x_dev, d, flag, dither, s))) return rc;
+    if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
+    Workspace& w = ctx->ws;
+    TailArgs t{};
+    t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = y_dev; t.loss = *loss;
+    t.want_grad = grad_dev != nullptr;
+    t.scores = scores_dev; t.decisions = decisions_dev; t.loss_out = loss_dev; t.demb = w.demb;
+    SG_HIP(launch_tail(t, s));
+    if (grad_dev) {
+        rc = run_backward_to_input(ctx, x_dev, d, flag, dither, grad_dev, nullptr, nullptr, nullptr, 0.f, 0, s);
+        if (rc) return rc;
+    }
+    return SG_OK;
+}
+
+int sg_pgd_update(sg_ctx* ctx, float* x_dev, const float* grad_dev, const float* lower_dev, const float* upper_dev,
+                  int64_t n, float step_size, int32_t grad_sign, void* stream) {
+    if (!ctx || !x_dev || !grad_dev || !lower_dev || !upper_dev || n < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_pgd_update(x_dev, grad_dev, lower_dev, upper_dev, n, step_size, grad_sign, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev, const float* upper_dev,
+                  int32_t B, int32_t T, const sg_pgd_params* p, uint8_t* success_dev, int64_t* decisions_dev,
+                  float* scores_dev, float* loss_dev, float* loss_trace_dev, int64_t* decision_trace_dev, void* stream) {
+    PassDims d;
+    int rc = check_dims(ctx, B, T, SG_FLAG_WAV, &d);
+    if (rc) return rc;
+    if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p) return fail(ctx, SG_ERR_ARG, "NULL argument");
+    if (p->max_iter < 0) return fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
+    const int eot_size = p->eot_size > 0 ? p->eot_size : 1, eot_bs = p->eot_batch_size > 0 ? p->eot_batch_size : 1;
+    if (eot_size % eot_bs) return fail(ctx, SG_ERR_ARG, "EOT size should be divisible by EOT batch size");
+    // Without dither the model is deterministic, every EOT repeat is the same computation and their
+    // mean is the single-pass result; repeats are only materialised when they differ.
+    if (eot_size > 1 && p->dither.dither != 0.f)
+        return fail(ctx, SG_ERR_ARG, "EOT over random dither inside the fused loop is not implemented; use the per-step API");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace& w = ctx->ws;
+    for (int it = 0; it <= p->max_iter; ++it) {
+        const bool last = it == p->max_iter;
+        sg_dither dz = p->dither;
+        dz.seed += (uint64_t)it * 0x9E3779B97F4A7C15ull;
+        if ((rc = run_frontend(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, s))) return rc;
+        if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
+        TailArgs t{};
+        t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = y_dev; t.loss = p->loss;
+        t.want_grad = !last; t.demb = w.demb;
+        t.scores = last ? scores_dev : nullptr;
+        t.decisions = last ? decisions_dev : nullptr;
+        t.loss_out = last ? loss_dev : nullptr;
+        t.success = last ? success_dev : nullptr;
+        t.loss_trace = loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr;
+        t.decision_trace = decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr;
+        SG_HIP(launch_tail(t, s));
+        if (!last) {
+            rc = run_backward_to_input(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, nullptr, x_adv_dev, lower_dev, upper_dev,
+                                       p->step_size, p->grad_sign, s);
+            if (rc) return rc;
+        }
+    }
+    return SG_OK;
+}
+
+int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters, float* ms_per_launch,
+                     double* flops, void* stream) {
+    if (!ctx || !ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no model loaded");
+    if (layer < 1 || layer > kLayers || iters < 1 || !ms_per_launch) return fail(ctx, SG_ERR_ARG, "bad argument");
+    const int F = num_frames(T);
+    if (!ctx->ws.scale || B > ctx->ws.B || F > ctx->ws.F)
+        return fail(ctx, SG_ERR_STATE, "run a forward pass with this (B, T) first so the activations are resident");
+    hipStream_t s = (hipStream_t)stream;
+    layer_frames(F, ctx->ws.Fl);
+    ConvGemmArgs a = fwd_layer_args(ctx, layer - 1, B, F);
+    SG_HIP(launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));  // warm
+    SG_HIP(hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < iters; ++i) SG_HIP(launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));
+    SG_HIP(hipEventRecord(ctx->ev1, s));
+    SG_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    SG_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_per_launch = ms / (float)iters;
+    if (flops) *flops = 2.0 * (double)a.M * (double)kCout[layer - 1] * (double)kCin[layer - 1] * (double)kTaps[layer - 1];
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// Internal declarations shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/speakerguard_hip.h"
+
+namespace sg {
+
+// ---------------------------------------------------------------- front-end constants
+// Kaldi MFCC as called at reference model/xv_plda.py:116-148.
+constexpr int kShift = 160;     // frame_shift 10 ms
+constexpr int kWin = 400;       // frame_length 25 ms
+constexpr int kFft = 512;       // round_to_power_of_two
+constexpr int kMel = 30;        // num_mel_bins
+constexpr int kCep = 30;        // num_ceps
+constexpr int kFeatPad = 32;    // cepstra padded to the GEMM K granule
+constexpr int kCmnWindow = 300; // iv_plda.py:310
+constexpr float kEps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+
+// TDNN geometry, reference model/_xv_plda/xvecTDNN.py:16-33
+constexpr int kLayers = 5;
+constexpr int kCin[kLayers] = {30, 512, 512, 512, 512};
+constexpr int kCout[kLayers] = {512, 512, 512, 512, 1500};
+constexpr int kCinPad[kLayers] = {32, 512, 512, 512, 512};
+constexpr int kCoutPad[kLayers] = {512, 512, 512, 512, 1536};
+constexpr int kTaps[kLayers] = {5, 5, 7, 1, 1};
+constexpr int kDil[kLayers] = {1, 2, 3, 1, 1};
+constexpr int kEmb = 512;
+constexpr int kPoolC = 1536;           // padded tdnn5 channels
+constexpr int kStats = 2 * kPoolC;     // [mean | std], padded
+constexpr int kFc1SplitK = 24;         // fc1 forward split-K (3072 / 128)
+constexpr int kFc1BwdSplitK = 4;
+
+inline int num_frames(int T) { return (T + kShift / 2) / kShift; }
+
+struct MfccTables {          // device pointers
+    float* window;           // [400] povey
+    float* mel_w;            // [30][256] dense triangular weights
+    int* mel_lo;             // [30] first bin with non-zero weight
+    int* mel_hi;             // [30] one past the last
+    int* bin_m0;             // [256] lower mel index touching this bin (-1: none)
+    float* bin_w0;           // [256] weight into mel bin_m0
+    float* bin_w1;           // [256] weight into mel bin_m0+1 (0 if none)
+    float* dct;              // [30 mel][30 cep]
+    float* lifter;           // [30]
+    float2* twiddle;         // [256] exp(-2 pi i k / 512)
+    uint16_t* bitrev;        // [512]
+};
+
+struct XvModel {
+    bool loaded = false;
+    int D = 0, S = 0;
+    float threshold = 0.f;
+    float logdet_given = 0.f, logdet_without = 0.f;  // sum log(1 + psi/(psi+1)), sum log(psi+1)
+    // folded TDNN weights, GEMM layouts
+    float* wf[kLayers] = {};    // forward  [taps*CinPad][CoutPad]
+    float* wb[kLayers] = {};    // backward [taps*CoutPad][CinPad]
+    float* bias[kLayers] = {};  // [CoutPad] folded
+    float* fc1_w = nullptr;     // [kStats][512] folded (K-major)
+    float* fc1_wt = nullptr;    // [512][kStats] folded (for the backward GEMM)
+    float* fc1_b = nullptr;     // [512] folded
+    float* emb_mean = nullptr;  // [512]
+    float* lda = nullptr;       // [D][513]
+    float* lda_t = nullptr;     // [513][D]
+    float* plda_mean = nullptr; // [D]
+    float* plda_p = nullptr;    // [D][D]
+    float* plda_pt = nullptr;   // [D][D] transposed
+    float* plda_psi = nullptr;  // [D]
+    float* enroll = nullptr;    // [S][D]
+};
+
+struct Workspace {
+    int B = 0, T = 0, F = 0;          // capacity the buffers were sized for
+    int Fl[kLayers] = {};              // TDNN output frames per layer
+    float* scale = nullptr;            // [1]
+    float* feats_raw = nullptr;        // [B][F][30]
+    float* feats = nullptr;            // [B][F][32] CMVN output, zero padded
+    float* act[kLayers] = {};          // relu outputs [B][Fl][CoutPad]
+    float* dact[kLayers] = {};         // d loss / d pre-activation [B][Fl][CoutPad]
+    float* dfeats = nullptr;           // [B][F][32]
+    float* dfeats_raw = nullptr;       // [B][F][30]
+    float* dframes = nullptr;          // [B][F][400]
+    float* stats = nullptr;            // [B][kStats]
+    float* fc1_part = nullptr;         // [kFc1SplitK][B][512]
+    float* demb = nullptr;             // [B][512]
+    float* dstats_part = nullptr;      // [kFc1BwdSplitK][B][kStats]
+    float* tdnn_emb = nullptr;         // [B][512]
+    float* emb = nullptr;              // [B][D]
+    float* scores = nullptr;           // [B][S]
+    float* loss = nullptr;             // [B]
+    int64_t* decisions = nullptr;      // [B]
+    float* grad = nullptr;             // [B][T]
+    std::vector<void*> allocs;
+};
+
+}  // namespace sg
+
+struct sg_ctx {
+    int device = 0;
+    std::string err;
+    sg::MfccTables tab{};
+    bool tables_ready = false;
+    sg::XvModel xv;
+    sg::Workspace ws;
+    std::vector<void*> model_allocs;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace sg {
+
+// ---------------------------------------------------------------- kernel launchers (k_*.hip)
+enum Epilogue { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_RELU_MASK = 2 };
+
+struct ConvGemmArgs {
+    const float* A;     // activations [B*Ta][lda]
+    const float* W;     // weights [taps*Kc][ldw]
+    float* C;           // output [B*Tc][ldc] (+ z*split_stride for split-K partials)
+    const float* bias;  // [N]            (EPI_BIAS_RELU)
+    const float* mask;  // [B*Tc][ldc]    (EPI_RELU_MASK: keep where mask > 0)
+    int M, N;           // M = B*Tc rows, N multiple of the tile width
+    int Ta, Tc;         // rows per utterance in A / C
+    int Kc;             // K per tap, multiple of 32
+    int lda, ldw, ldc;
+    int taps, tap_step; // A row offset of tap j = j * tap_step
+    int total_chunks, chunks_per_split;
+    long long split_stride;
+};
+
+// tile: 0 = 128x128 (2x2 waves), 1 = 128x32 (4x1 waves), 2 = 64x128 (2x2 waves)
+hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s);
+
+hipError_t launch_input_scale(const float* x, int64_t n, float* scale, hipStream_t s);
+hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
+                           const sg_dither* dz, float* feats, hipStream_t s);
+hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
+                           const sg_dither* dz, const float* dfeats, float* dframes, hipStream_t s);
+// overlap-add of dframes into d loss / d x; optional fused PGD update of x (in place)
+hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, float* grad_out, float* x_io,
+                                 const float* lower, const float* upper, float step, int grad_sign,
+                                 hipStream_t s);
+hipError_t launch_pgd_update(float* x, const float* g, const float* lo, const float* hi, int64_t n,
+                             float step, int grad_sign, hipStream_t s);
+// out[r][0..ncol) = in[r][0..ncol), out[r][ncol..ld_out) = 0
+hipError_t launch_copy_cols(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int ncol, hipStream_t s);
+hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, hipStream_t s);
+hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, float* din, int ld_din, int B, int F, hipStream_t s);
+hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipStream_t s);
+hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit,
+                           int B, int Tc, float* dact5, hipStream_t s);
+
+struct TailArgs {
+    const float* fc1_part; int nsplit; int B;
+    const XvModel* m;  // host struct with device pointers (copied by value into the launch)
+    const int64_t* y; sg_loss_spec loss; int want_grad;
+    float* tdnn_emb; float* emb; float* scores; int64_t* decisions; float* loss_out; float* demb;
+    // optional per-pass records for the fused loop
+    float* loss_trace; int64_t* decision_trace; uint8_t* success;
+};
+hipError_t launch_tail(const TailArgs& a, hipStream_t s);
+
+}  // namespace sg

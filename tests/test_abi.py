@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports exactly the entry points include/speakerguard_hip.h declares.
+CPU only: no compute call is made (hipcc cross-compiles gfx950 without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from speakerguard_amd import _native
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "speakerguard_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_native.LIB_PATH), "run `make` (or __graft_entry__.build()) first"
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    assert sorted(_native.EXPORTS) == names, "python binding list and header disagree"
+
+
+def test_version_and_loader():
+    lib = _native.load()
+    assert lib.sg_version() == 100
+    assert lib.sg_xv_num_frames(48000) == 300
+    assert lib.sg_xv_num_frames(52960) == 331
+    assert lib.sg_xv_num_frames(100) == 0
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the same structs (x86-64 SysV): catches field-order drift
+    assert ctypes.sizeof(_native.LossSpec) == 24
+    assert ctypes.sizeof(_native.Dither) == 32
+    assert ctypes.sizeof(_native.PgdParams) == 24 + 4 * 5 + 4 + 32
+    assert ctypes.sizeof(_native.XvWeights) == 8 * 28 + 16
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeError):
+        _native.load()
+
+
+def test_model_refuses_cpu_device():
+    from speakerguard_amd import synth
+    from speakerguard_amd.model.xv_plda import xv_plda
+    with pytest.raises(_native.NativeError):
+        xv_plda.from_weights(synth.make_xv_weights(), device="cpu")
