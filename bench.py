@@ -1,0 +1,160 @@
+"""Headline benchmark: PGD attack steps/s on the x-vector/PLDA system (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload per GPU: PGD, L-inf eps 0.002, step 0.0004, cross-entropy, untargeted, EOT 1/1, CSI-E,
+batch 64 x 3 s @ 16 kHz synthetic utterances, synthetic seeded weights (D=200, 10 enrolled
+speakers), dither off.  One "step" = forward + hand-coded backward to d loss/d waveform + fused
+sign/project/clamp update for the whole batch of 64.  The timed region is ONE ``sg_xv_pgd_run``
+call with max_iter = K, i.e. K steps plus the attack's final forward-only evaluation pass
+(reference attack/FGSM.py:44-47) -- the pass is part of every real attack, so it is charged to
+the K steps rather than hidden.  Inputs are resident in HBM before the clock starts.
+
+N > 1: weak scaling, every rank attacks its own batch of 64 (no data-path collective); the only
+exchange is one RCCL all-gather of the per-utterance success flags at the end of the attack,
+inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+B_PER_GPU, T_SAMPLES = 64, 48000
+EPS, STEP = 0.002, 0.0004
+# algorithmic MACs per utterance of the TDNN contractions, forward; data-gradient = same
+FLOP_PER_UTT_STEP = 4.70e9
+
+
+def cpu_baseline(weights, budget_utts=16, steps=3):
+    """Reference-equivalent CPU path = the oracle in its structure-faithful form (per-utterance
+    MFCC/TDNN loops, Python CMVN loop, autograd with parameters requiring grad), timed on this
+    host's cores on a bounded sample of the same workload."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    cores = torch.get_num_threads()
+    model = XvPlda(weights, faithful=True, freeze=False)
+    x = torch.from_numpy(synth.make_waveforms(budget_utts, T_SAMPLES, seed=1234))
+    y = torch.arange(budget_utts) % 10
+    atk = oatk.PGD(model, task="CSI", epsilon=EPS, step_size=STEP, max_iter=steps, batch_size=budget_utts)
+    t0 = time.perf_counter()
+    atk.attack(x, y)
+    dt = time.perf_counter() - t0
+    utt_steps = budget_utts * steps  # (+ one forward-only pass, charged like on the GPU side)
+    return {
+        "value": utt_steps / dt / B_PER_GPU,
+        "unit": "steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "oracle faithful path (per-utterance loops, autograd incl. weight grads), PGD-%d on %d of the 64 "
+                  "utterances = %d utterance-steps in %.1f s; scaled to batch-64 steps" % (steps, budget_utts, utt_steps, dt),
+        "utt_steps_per_s": utt_steps / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.xv_plda import xv_plda
+
+    weights = synth.make_xv_weights(seed=0, D=200, n_spk=10)
+    model = xv_plda.from_weights(weights, device=dev, dither=0.0)
+    x = torch.from_numpy(synth.make_waveforms(B_PER_GPU, T_SAMPLES, seed=1234 + rank)).to(dev)
+    y = (torch.arange(B_PER_GPU) % 10).to(dev)
+    lower, upper = torch.clamp(x - EPS, min=-1), torch.clamp(x + EPS, max=1)
+    spec = SEC4SR_CrossEntropy()
+
+    def attack(k):
+        out = model.pgd_run(x, y, lower, upper, spec, STEP, k, 1)
+        if dist is not None:  # the attack's only exchange: success flags of every shard
+            flags = [torch.empty_like(out[1]) for _ in range(world)]
+            dist.all_gather(flags, out[1])
+            return out, torch.cat(flags)
+        return out, out[1]
+
+    if args.warmup > 0:
+        attack(args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, flags = attack(args.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant kernel: TDNN layer 3 forward contraction (conv_gemm_kernel<128,128,...>),
+    # HIP events on the launch stream inside the library
+    ms, flops, rows = model.time_layer(3, B_PER_GPU, T_SAMPLES, iters=20)
+    achieved = flops / (ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "conv_gemm_kernel<%d,128,..,BIAS_RELU> tdnn3 forward (B=64: M=17280 N=512 K=3584)" % rows,
+                "ms_per_launch": ms, "flop_per_launch": flops}
+
+    steps_per_s = world * args.steps / dt
+    line = {
+        "metric": "PGD attack steps/sec (xv_plda, 3s@16kHz, batch 64)",
+        "value": steps_per_s,
+        "unit": "steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "PGD L-inf eps=0.002 step=0.0004 CE untargeted on xv_plda CSI-E, batch 64 x 3 s @ 16 kHz "
+                               "per GPU, EOT 1/1, dither off; timed = K steps + final forward-only pass",
+                   "batch_per_gpu": B_PER_GPU, "samples": T_SAMPLES, "global_batch": B_PER_GPU * world},
+        "utt_steps_per_s": steps_per_s * B_PER_GPU,
+        "model_tflops": steps_per_s * B_PER_GPU * FLOP_PER_UTT_STEP / 1e12 / world,
+        "success_count": int(flags.sum().item()),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(weights)
+        line["gpu_vs_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,11 +170,12 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
                   float* loss_trace_dev, int64_t* decision_trace_dev, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------
- * Time `iters` launches of the dominant contraction (TDNN layer `layer` 2..5 forward) with HIP
+ * Time `iters` launches of one TDNN contraction (layer 1..5 = forward, -1..-5 = data gradient) with HIP
  * events on `stream`; returns average milliseconds per launch in *ms_per_launch and the
- * algorithmic FLOPs of one launch in *flops.  Used by bench.py for the roofline block. */
+ * algorithmic FLOPs of one launch in *flops, and the tile height (rows) the launcher picked in
+ * *tile_rows.  Used by bench.py for the roofline block. */
 int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters,
-                     float* ms_per_launch, double* flops, void* stream);
+                     float* ms_per_launch, double* flops, int32_t* tile_rows, void* stream);
 
 #ifdef __cplusplus
 }

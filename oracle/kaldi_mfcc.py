@@ -127,6 +127,8 @@ def mfcc(waveform, dither_noise=None):
     here the draw is an explicit input so two implementations can be compared).
     """
     c = constants()
+    if waveform.dtype != torch.float32:  # fp64 "truth" runs: same fp32-rounded constants, wider arithmetic
+        c = {k: v.to(waveform.dtype) for k, v in c.items()}
     if waveform.dim() == 2:
         waveform = waveform[0]
     frames = get_strided(waveform)

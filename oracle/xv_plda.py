@@ -113,6 +113,13 @@ class XvPlda:
         self.num_spks = self.enroll_embs.shape[0]
         self.spk_ids = ["spk%02d" % i for i in range(self.num_spks)]
 
+    def double(self):
+        """Same model evaluated in fp64 -- used by tests as the 'truth' both fp32 paths are measured against."""
+        self.params = {k: v.double() for k, v in self.params.items()}
+        for name in ("emb_mean", "transform_mat", "plda_mean", "plda_transform", "plda_psi", "enroll_embs"):
+            setattr(self, name, getattr(self, name).double())
+        return self
+
     # ------------------------------------------------------------------ features
     def raw(self, x, dither_noise=None):
         """xv_plda.raw :107-156 (dither handled as an explicit tensor, see kaldi_mfcc.mfcc)."""

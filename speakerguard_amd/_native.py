@@ -82,7 +82,7 @@ def load():
                                       vp, vp, vp, vp, vp]),
         "sg_pgd_update": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, i32, vp]),
         "sg_xv_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
-        "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), vp]),
+        "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

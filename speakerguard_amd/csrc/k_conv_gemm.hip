@@ -18,6 +18,8 @@
 // ds_write_b128), W chunk [32][BN]; MFMA operands are conflict-free ds_read_b32 (lanes 0-31 read
 // 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages, next chunk's global loads
 // are issued before the current chunk's MFMAs and written to LDS after them (one barrier/chunk).
+#include <cstdlib>
+
 #include "sg_internal.h"
 
 namespace sg {
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     constexpr int B_F4 = BK * BN / 4;          // float4 in the W tile
     constexpr int B_PER_THREAD = (B_F4 + 255) / 256;
     static_assert(A_ACTIVE <= 256, "A tile too tall");
+    static_assert(B_PER_THREAD <= 4, "W tile too wide");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     float* As = smem;                 // [2][BK][BM]
@@ -80,49 +83,56 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
 
-    float4 ra[4];
-    float4 rb[B_PER_THREAD];
+    // Staging registers are named scalars on purpose: as arrays captured by the helper lambdas hipcc's
+    // promote-alloca pass moved the W-tile registers into LDS (+16 KB, an LDS round trip per chunk).
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    bool ok0, ok1, ok2, ok3;
+    rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // Loads are branch-free: an out-of-range tap row (or a thread that stages nothing) reads row 0
+    // and is zeroed when the registers are written to LDS.  A conditional load makes hipcc wait
+    // vmcnt(0) at every branch join, which serialised four global round trips per chunk in front
+    // of the MFMAs.
+#define SG_LOAD_A(i, r, okv)                                                                              \
+    {                                                                                                     \
+        const int tt = a_t[i] + off;                                                                      \
+        okv = tt >= 0 && tt < p.Ta;                                                                       \
+        const int row = okv ? a_base[i] + off : 0;                                                        \
+        r = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + kc + a_c4 * 4);                  \
+    }
+#define SG_LOAD_B(i, r)                                                                                   \
+    if (i < B_PER_THREAD) {                                                                               \
+        const int f = (tid + i * 256) % B_F4;                                                             \
+        r = *reinterpret_cast<const float4*>(wrow + (size_t)(f / (BN / 4)) * p.ldw + (f % (BN / 4)) * 4); \
+    }
+#define SG_STORE_B(i, r)                                                                                  \
+    if (i < B_PER_THREAD && (B_F4 % 256 == 0 || tid + i * 256 < B_F4))                                    \
+        *reinterpret_cast<float4*>(Bs + buf * BK * BN + (tid + i * 256) * 4) = r;
 
     auto load_chunk = [&](int c) {
         const int j = c / kchunks;
         const int kc = (c - j * kchunks) * BK;
         const int off = j * p.tap_step;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tt = a_t[i] + off;
-            if (tt >= 0 && tt < p.Ta) {
-                ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)(a_base[i] + off) * p.lda + kc + a_c4 * 4);
-            } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        SG_LOAD_A(0, ra0, ok0) SG_LOAD_A(1, ra1, ok1) SG_LOAD_A(2, ra2, ok2) SG_LOAD_A(3, ra3, ok3)
         const float* wrow = p.W + (size_t)(j * p.Kc + kc) * p.ldw + n0;
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int f = tid + i * 256;
-            if (B_F4 % 256 == 0 || f < B_F4) {
-                const int k = f / (BN / 4), n4 = f % (BN / 4);
-                rb[i] = *reinterpret_cast<const float4*>(wrow + (size_t)k * p.ldw + n4 * 4);
-            }
-        }
+        SG_LOAD_B(0, rb0) SG_LOAD_B(1, rb1) SG_LOAD_B(2, rb2) SG_LOAD_B(3, rb3)
     };
     auto store_chunk = [&](int buf) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r0 = ok0 ? ra0 : z, r1 = ok1 ? ra1 : z, r2 = ok2 ? ra2 : z, r3 = ok3 ? ra3 : z;
         if (a_on) {
             float* a = As + buf * BK * BM + (a_c4 * 4) * BM + a_r4 * 4;
-            // register transpose: ra[i] = 4 k-values of row i  ->  one float4 of 4 rows per k
-            *reinterpret_cast<float4*>(a + 0 * BM) = make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x);
-            *reinterpret_cast<float4*>(a + 1 * BM) = make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y);
-            *reinterpret_cast<float4*>(a + 2 * BM) = make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z);
-            *reinterpret_cast<float4*>(a + 3 * BM) = make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w);
+            // register transpose: r_i = 4 k-values of row i  ->  one float4 of 4 rows per k
+            *reinterpret_cast<float4*>(a + 0 * BM) = make_float4(r0.x, r1.x, r2.x, r3.x);
+            *reinterpret_cast<float4*>(a + 1 * BM) = make_float4(r0.y, r1.y, r2.y, r3.y);
+            *reinterpret_cast<float4*>(a + 2 * BM) = make_float4(r0.z, r1.z, r2.z, r3.z);
+            *reinterpret_cast<float4*>(a + 3 * BM) = make_float4(r0.w, r1.w, r2.w, r3.w);
         }
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int f = tid + i * 256;
-            if (B_F4 % 256 == 0 || f < B_F4) {
-                *reinterpret_cast<float4*>(Bs + buf * BK * BN + f * 4) = rb[i];
-            }
-        }
+        SG_STORE_B(0, rb0) SG_STORE_B(1, rb1) SG_STORE_B(2, rb2) SG_STORE_B(3, rb3)
     };
+#undef SG_LOAD_A
+#undef SG_LOAD_B
+#undef SG_STORE_B
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -143,20 +153,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         if (c + 1 < c_end) load_chunk(c + 1);
+        // hipcc otherwise sinks the global loads' consumers (the ds_writes of store_chunk, which touch
+        // the OTHER LDS stage) above the MFMA loop and waits vmcnt there; pin the phase order.
+        __builtin_amdgcn_sched_barrier(0);
         const float* a_s = As + buf * BK * BM + lhi * BM + a_rd;
         const float* b_s = Bs + buf * BK * BN + lhi * BN + b_rd;
+        // register double-buffered operand fetch: the ds_reads of k-step ks+1 are issued before the
+        // MFMAs of ks, so their LDS latency hides under MI*NI x 64 cycles of matrix pipe
+        float av[2][MI], bv[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[0][mi] = a_s[mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[0][ni] = b_s[ni * 32];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            float av[MI], bv[NI];
+            if (ks + 1 < BK / 2) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) av[mi] = a_s[ks * 2 * BM + mi * 32];
+                for (int mi = 0; mi < MI; ++mi) av[(ks + 1) & 1][mi] = a_s[(ks + 1) * 2 * BM + mi * 32];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bv[ni] = b_s[ks * 2 * BN + ni * 32];
+                for (int ni = 0; ni < NI; ++ni) bv[(ks + 1) & 1][ni] = b_s[(ks + 1) * 2 * BN + ni * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][mi], bv[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < c_end) store_chunk(buf ^ 1);
         __syncthreads();
@@ -169,18 +192,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int col = n0 + wn * (BN / WN) + ni * 32 + l31;
+            const int row0 = m0 + wm * (BM / WM) + mi * 32 + 4 * lhi;
             float bias = 0.f;
             if (EPI == EPI_BIAS_RELU) bias = p.bias[col];
+            f32x16 mk;
+            if (EPI == EPI_RELU_MASK) {
+                // all 16 mask loads in flight at once, rows clamped instead of branched around (a
+                // guarded load makes hipcc wait vmcnt(0) per element: 64 serial L2 round trips)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = min(row0 + (e & 3) + 8 * (e >> 2), p.M - 1);
+                    mk[e] = p.mask[(size_t)row * p.ldc + col];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / WM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                if (row < p.M) {
-                    float v = acc[mi][ni][e];
-                    const size_t o = (size_t)row * p.ldc + col;
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-                    if (EPI == EPI_RELU_MASK) v = p.mask[o] > 0.f ? v : 0.f;
-                    Cz[o] = v;
-                }
+                const int row = row0 + (e & 3) + 8 * (e >> 2);
+                float v = acc[mi][ni][e];
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                if (EPI == EPI_RELU_MASK) v = mk[e] > 0.f ? v : 0.f;
+                if (row < p.M) Cz[(size_t)row * p.ldc + col] = v;
             }
         }
     }
@@ -207,18 +238,43 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
+// 128-wide tiles come in three heights.  Measured at B = 64 (tools/layer_bench.py, SG_TILE_ROWS
+// sweep, profiles/): 64 rows 97.5 TFLOP/s over the eight large contractions, 96 rows 85.4, 128 rows
+// 76.5 -- the 48 KB of LDS of the 64-row tile lets three blocks share a CU (3 waves per SIMD), which
+// hides the per-chunk staging/barrier bubble, and the finer tiles shorten the tail of the launch.
+// A "fewest rounds x rows" model preferred 96 rows and was wrong; 64 is the default.
+static int pick_height(int M, int ntiles) {
+    static const int forced = [] {
+        const char* e = getenv("SG_TILE_ROWS");  // tuning aid: force 64 / 96 / 128
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 64 || forced == 96 || forced == 128) return forced;
+    (void)M;
+    (void)ntiles;
+    return 64;
+}
+
+int conv_gemm_tile_rows(int M, int N) { return pick_height(M, N / 128); }
+
 hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s) {
     if (a.Kc % BK != 0 || a.M <= 0) return hipErrorInvalidValue;
     switch (tile) {
-        case 0:
+        case 0: {
             if (a.N % 128) return hipErrorInvalidValue;
+            const int h = splits == 1 ? pick_height(a.M, a.N / 128) : 128;
+            if (h == 96) return launch_tile<96, 128, 1, 4>(a, epi, splits, s);
+            if (h == 64) return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
             return launch_tile<128, 128, 2, 2>(a, epi, splits, s);
+        }
         case 1:
             if (a.N % 32) return hipErrorInvalidValue;
             return launch_tile<128, 32, 4, 1>(a, epi, splits, s);
         case 2:
             if (a.N % 128) return hipErrorInvalidValue;
             return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
+        case 3:  // forced 128x128 (measurement)
+            if (a.N % 128) return hipErrorInvalidValue;
+            return launch_tile<128, 128, 2, 2>(a, epi, splits, s);
         default:
             return hipErrorInvalidValue;
     }

@@ -23,11 +23,15 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // ---------------------------------------------------------------- check_input_range (model/utils.py:7-19)
 // range_type='origin' (xv_plda.py:48): if 0.9*max <= 1 and 0.9*min >= -1 the batch is in the
 // [-1,1] float domain and is multiplied by 2^15, otherwise it is left alone.  Single block; the
-// result stays on the device so no host sync is needed.
-__global__ __launch_bounds__(1024) void input_scale_kernel(const float* __restrict__ x, int64_t n, float* scale) {
-    __shared__ float smax[16], smin[16];
+// result stays on the device so no host sync is needed.  Two stages: 256 blocks -> partial max/min,
+// one block -> the decision (a single-block version cost 0.86 ms at 64 x 3 s, 11 % of a PGD step).
+constexpr int kScaleBlocks = 256;
+
+__global__ __launch_bounds__(256) void input_range_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                                  float* __restrict__ part) {
+    __shared__ float smax[4], smin[4];
     float mx = -INFINITY, mn = INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kScaleBlocks * 256) {
         const float v = x[i];
         mx = fmaxf(mx, v);
         mn = fminf(mn, v);
@@ -40,16 +44,30 @@ __global__ __launch_bounds__(1024) void input_scale_kernel(const float* __restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) {
-            mx = fmaxf(mx, smax[i]);
-            mn = fminf(mn, smin[i]);
-        }
+        part[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        part[kScaleBlocks + blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void input_range_final_kernel(const float* __restrict__ part, float* scale) {
+    __shared__ float smax[4], smin[4];
+    float mx = wave_max_f(part[threadIdx.x]);
+    float mn = wave_min_f(part[kScaleBlocks + threadIdx.x]);
+    if ((threadIdx.x & 63) == 0) {
+        smax[threadIdx.x >> 6] = mx;
+        smin[threadIdx.x >> 6] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
         *scale = (0.9f * mx <= 1.f && 0.9f * mn >= -1.f) ? 32768.f : 1.f;
     }
 }
 
-hipError_t launch_input_scale(const float* x, int64_t n, float* scale, hipStream_t s) {
-    hipLaunchKernelGGL(input_scale_kernel, dim3(1), dim3(1024), 0, s, x, n, scale);
+hipError_t launch_input_scale(const float* x, int64_t n, float* scratch, float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(input_range_partial_kernel, dim3(kScaleBlocks), dim3(256), 0, s, x, n, scratch);
+    hipLaunchKernelGGL(input_range_final_kernel, dim3(1), dim3(256), 0, s, scratch, scale);
     return hipGetLastError();
 }
 

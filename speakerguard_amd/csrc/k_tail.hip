@@ -128,11 +128,23 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
             if (success) success[b] = ls.targeted ? (dec == yy) : (dec != yy);
             if (ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI) {
                 if (yy >= 0) {
-                    float se = 0.f;
-                    for (int s = 0; s < S; ++s) se += expf(sc[s] - mx);
-                    const float lse = mx + logf(se);
-                    loss = lse - sc[yy];
-                    for (int s = 0; s < S; ++s) dsc[s] = expf(sc[s] - lse);
+                    // softmax - onehot exactly as log_softmax + nll compute it in fp32 (the reference's
+                    // F.cross_entropy): d/ds_y = fl(exp(s_y - lse)) - 1.  The cancellation is part of
+                    // the reference's behaviour: for a confidently classified utterance (sum of the
+                    // other probabilities < 6e-8, i.e. a margin > 16.6 -- the normal case for PLDA
+                    // scores) exp() rounds to 1 and d/ds_y is EXACTLY 0, so the reference ascends along
+                    // sum_j p_j grad(s_j) only; an "exact" -(sum of other p_j) would follow a different
+                    // direction (measured: 71 % of the samples differ after 5 steps).  The only liberty
+                    // taken: the non-max terms are summed first and 1 is added last, so `se` carries a
+                    // single rounding instead of up to S-1.
+                    float so = 0.f;
+                    for (int s = 0; s < S; ++s)
+                        if (s != ja) so += expf(sc[s] - mx);
+                    const float lse = logf(1.f + so);  // log-sum-exp RELATIVE to the max: torch's
+                    // log_softmax is (x - max) - log(sum exp(x - max)); adding the max back first would
+                    // round the 4e-5 of a confident utterance to ulp(max) ~ 8e-6 (a 9 % error on d/ds_y)
+                    loss = lse - (sc[yy] - mx);
+                    for (int s = 0; s < S; ++s) dsc[s] = expf((sc[s] - mx) - lse);
                     dsc[yy] -= 1.f;
                 }
             } else if (ls.task == SG_TASK_SV) {

@@ -52,29 +52,44 @@ void free_pool(std::vector<void*>& pool) {
 
 // ------------------------------------------------------------------------------------------
 // MFCC constant tables (torchaudio kaldi.py v0.6.0: _feature_window_function, get_mel_banks,
-// _get_dct_matrix, _get_lifter_coeffs), computed here in double and rounded once to fp32.
+// _get_dct_matrix, _get_lifter_coeffs).  torchaudio builds them with float32 tensor arithmetic,
+// and the float32 rounding of the ARGUMENTS (e.g. pi/30*(n+0.5)*k up to 94 rad) moves the DCT /
+// lifter / mel entries by up to 5e-6 -- 3e-4 on a cepstrum, enough to flip ReLU masks downstream.
+// So the tables are computed here in float32 with the same operation order, not in double.
 int build_tables(sg_ctx* ctx) {
     if (ctx->tables_ready) return SG_OK;
     const double PI = 3.14159265358979323846;
     std::vector<float> window(kWin), melw(kMel * 256, 0.f), dct(kMel * kCep), lifter(kCep), w0(256, 0.f), w1(256, 0.f);
     std::vector<int> lo(kMel), hi(kMel), m0(256, -1);
-    std::vector<float2> tw(256);
+    std::vector<double2> tw(256);
     std::vector<uint16_t> br(kFft);
-    for (int n = 0; n < kWin; ++n) window[n] = (float)std::pow(0.5 - 0.5 * std::cos(2.0 * PI * n / (kWin - 1)), 0.85);
-    auto mel = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
-    const double mel_low = mel(20.0), mel_high = mel(7600.0);
+    {   // torch.hann_window(400, periodic=False): arange * (2 pi / 399) -> cos -> * -0.5 + 0.5; then pow 0.85
+        const float step = (float)(PI * 2.0 / (double)(kWin - 1));
+        for (int n = 0; n < kWin; ++n) {
+            const float c = cosf((float)n * step);
+            const float h = c * -0.5f + 0.5f;
+            window[n] = powf(h, 0.85f);
+        }
+    }
+    // get_mel_banks: python-double scalars, float32 tensors
+    auto mel_scalar = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
+    const double mel_low = mel_scalar(20.0), mel_high = mel_scalar(7600.0);
     const double delta = (mel_high - mel_low) / (kMel + 1);
-    const double bin_width = 16000.0 / kFft;
+    const float bin_width = (float)(16000.0 / kFft);
     for (int m = 0; m < kMel; ++m) {
-        const double left = mel_low + m * delta, center = left + delta, right = center + delta;
+        const float fm = (float)m;
+        const float left = (float)mel_low + fm * (float)delta;
+        const float center = (float)mel_low + (fm + 1.0f) * (float)delta;
+        const float right = (float)mel_low + (fm + 2.0f) * (float)delta;
         lo[m] = 256;
         hi[m] = 0;
         for (int k = 0; k < 256; ++k) {
-            const double mk = mel(bin_width * k);
-            const double up = (mk - left) / (center - left), down = (right - mk) / (right - center);
-            const double w = std::fmax(0.0, std::fmin(up, down));
-            melw[m * 256 + k] = (float)w;
-            if (w > 0.0) {
+            const float fr = bin_width * (float)k;
+            const float mk = 1127.0f * logf(1.0f + fr / 700.0f);
+            const float up = (mk - left) / (center - left), down = (right - mk) / (right - center);
+            const float w = fmaxf(0.f, fminf(up, down));
+            melw[m * 256 + k] = w;
+            if (w > 0.f) {
                 if (k < lo[m]) lo[m] = k;
                 hi[m] = k + 1;
             }
@@ -96,12 +111,20 @@ int build_tables(sg_ctx* ctx) {
             w1[k] = first + 1 < kMel ? melw[(first + 1) * 256 + k] : 0.f;
         }
     }
-    for (int m = 0; m < kMel; ++m)
-        for (int c = 0; c < kCep; ++c)
-            dct[m * kCep + c] = c == 0 ? (float)std::sqrt(1.0 / kMel)
-                                       : (float)(std::cos(PI / kMel * (m + 0.5) * c) * std::sqrt(2.0 / kMel));
-    for (int c = 0; c < kCep; ++c) lifter[c] = (float)(1.0 + 0.5 * 22.0 * std::sin(PI * c / 22.0));
-    for (int k = 0; k < 256; ++k) tw[k] = make_float2((float)std::cos(2.0 * PI * k / kFft), (float)-std::sin(2.0 * PI * k / kFft));
+    {   // _get_dct_matrix: cos(pi/N * (n + 0.5) * k), row 0 * 1/sqrt(2), all * sqrt(2/N), transposed,
+        // first column overwritten by sqrt(1/N)
+        const float a = (float)(PI / (double)kMel);
+        for (int m = 0; m < kMel; ++m)
+            for (int c = 0; c < kCep; ++c) {
+                float v = cosf((a * ((float)m + 0.5f)) * (float)c);
+                if (c == 0) v *= (float)(1.0 / std::sqrt(2.0));
+                v *= (float)std::sqrt(2.0 / (double)kMel);
+                dct[m * kCep + c] = c == 0 ? (float)std::sqrt(1.0 / (double)kMel) : v;
+            }
+        // _get_lifter_coeffs: 1 + 0.5 * Q * sin(pi * i / Q)
+        for (int c = 0; c < kCep; ++c) lifter[c] = 1.0f + 11.0f * sinf(((float)PI * (float)c) / 22.0f);
+    }
+    for (int k = 0; k < 256; ++k) tw[k] = make_double2(std::cos(2.0 * PI * k / kFft), -std::sin(2.0 * PI * k / kFft));
     for (int i = 0; i < kFft; ++i) {
         int r = 0;
         for (int bit = 0; bit < 9; ++bit)
@@ -121,6 +144,7 @@ int build_tables(sg_ctx* ctx) {
     rc |= dev_upload(ctx, ctx->model_allocs, &t.lifter, lifter);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
+    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->range_scratch, 512);
     if (rc) return SG_ERR_HIP;
     ctx->tables_ready = true;
     return SG_OK;
@@ -183,13 +207,14 @@ int ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
 
 struct PassDims {
     int B, T, F;
+    bool keep_scale = false;  // reuse ws.scale from the previous pass (fused loop: x stays in [-1, 1])
 };
 
 // waveform / features -> padded CMVN features in ws.feats
 int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz, hipStream_t s) {
     Workspace& w = ctx->ws;
     if (flag == SG_FLAG_WAV) {
-        SG_HIP(launch_input_scale(x, (int64_t)d.B * d.T, w.scale, s));
+        if (!d.keep_scale) SG_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, s));
         SG_HIP(launch_mfcc_fwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
         SG_HIP(launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else if (flag == SG_FLAG_RAW) {
@@ -490,7 +515,9 @@ int sg_xv_set_enroll(sg_ctx* ctx, const float* enroll_host, int32_t S, float thr
 
 int sg_input_scale(sg_ctx* ctx, const float* x_dev, int64_t n, float* scale_dev, void* stream) {
     if (!ctx || !x_dev || !scale_dev || n < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
-    SG_HIP(launch_input_scale(x_dev, n, scale_dev, (hipStream_t)stream));
+    int rc = build_tables(ctx);
+    if (rc) return rc;
+    SG_HIP(launch_input_scale(x_dev, n, ctx->range_scratch, scale_dev, (hipStream_t)stream));
     return SG_OK;
 }
 
@@ -591,6 +618,9 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
         const bool last = it == p->max_iter;
         sg_dither dz = p->dither;
         dz.seed += (uint64_t)it * 0x9E3779B97F4A7C15ull;
+        // every iterate is clamped into [lower, upper] within [-1, 1], so check_input_range takes the
+        // same branch as for the start point: decide once
+        d.keep_scale = it > 0;
         if ((rc = run_frontend(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, s))) return rc;
         if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
         TailArgs t{};
@@ -613,24 +643,38 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
 }
 
 int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters, float* ms_per_launch,
-                     double* flops, void* stream) {
+                     double* flops, int32_t* tile_rows, void* stream) {
     if (!ctx || !ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no model loaded");
-    if (layer < 1 || layer > kLayers || iters < 1 || !ms_per_launch) return fail(ctx, SG_ERR_ARG, "bad argument");
+    const int l = (layer < 0 ? -layer : layer) - 1;
+    if (l < 0 || l >= kLayers || iters < 1 || !ms_per_launch) return fail(ctx, SG_ERR_ARG, "bad argument");
     const int F = num_frames(T);
-    if (!ctx->ws.scale || B > ctx->ws.B || F > ctx->ws.F)
+    Workspace& w = ctx->ws;
+    if (!w.scale || B > w.B || F > w.F)
         return fail(ctx, SG_ERR_STATE, "run a forward pass with this (B, T) first so the activations are resident");
     hipStream_t s = (hipStream_t)stream;
-    layer_frames(F, ctx->ws.Fl);
-    ConvGemmArgs a = fwd_layer_args(ctx, layer - 1, B, F);
-    SG_HIP(launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));  // warm
+    layer_frames(F, w.Fl);
+    ConvGemmArgs a = fwd_layer_args(ctx, l, B, F);
+    int tile = 0, epi = EPI_BIAS_RELU;
+    if (layer < 0) {  // data-gradient contraction of the same layer (reads d(out), writes d(in))
+        a = ConvGemmArgs{};
+        a.A = w.dact[l]; a.W = ctx->xv.wb[l]; a.C = l == 0 ? w.dfeats : w.dact[l - 1];
+        a.mask = l == 0 ? nullptr : w.act[l - 1];
+        a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
+        a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];
+        a.total_chunks = a.taps * (a.Kc / 32); a.chunks_per_split = a.total_chunks;
+        tile = l == 0 ? 1 : 0;
+        epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;
+    }
+    SG_HIP(launch_conv_gemm(a, tile, epi, 1, s));  // warm
     SG_HIP(hipEventRecord(ctx->ev0, s));
-    for (int i = 0; i < iters; ++i) SG_HIP(launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));
+    for (int i = 0; i < iters; ++i) SG_HIP(launch_conv_gemm(a, tile, epi, 1, s));
     SG_HIP(hipEventRecord(ctx->ev1, s));
     SG_HIP(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
     SG_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_per_launch = ms / (float)iters;
-    if (flops) *flops = 2.0 * (double)a.M * (double)kCout[layer - 1] * (double)kCin[layer - 1] * (double)kTaps[layer - 1];
+    if (tile_rows) *tile_rows = tile == 0 ? conv_gemm_tile_rows(a.M, a.N) : 128;
+    if (flops) *flops = 2.0 * (double)a.M * (double)kCout[l] * (double)kCin[l] * (double)kTaps[l];
     return SG_OK;
 }
 

@@ -46,7 +46,7 @@ struct MfccTables {          // device pointers
     float* bin_w1;           // [256] weight into mel bin_m0+1 (0 if none)
     float* dct;              // [30 mel][30 cep]
     float* lifter;           // [30]
-    float2* twiddle;         // [256] exp(-2 pi i k / 512)
+    double2* twiddle;        // [256] exp(-2 pi i k / 512), fp64 (forward FFT runs in fp64)
     uint16_t* bitrev;        // [512]
 };
 
@@ -103,6 +103,7 @@ struct sg_ctx {
     std::string err;
     sg::MfccTables tab{};
     bool tables_ready = false;
+    float* range_scratch = nullptr;  // [512] partial max/min of check_input_range
     sg::XvModel xv;
     sg::Workspace ws;
     std::vector<void*> model_allocs;
@@ -131,8 +132,9 @@ struct ConvGemmArgs {
 
 // tile: 0 = 128x128 (2x2 waves), 1 = 128x32 (4x1 waves), 2 = 64x128 (2x2 waves)
 hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s);
+int conv_gemm_tile_rows(int M, int N);  // tile height launch_conv_gemm(tile 0) picks
 
-hipError_t launch_input_scale(const float* x, int64_t n, float* scale, hipStream_t s);
+hipError_t launch_input_scale(const float* x, int64_t n, float* scratch512, float* scale, hipStream_t s);
 hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, float* feats, hipStream_t s);
 hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,

@@ -315,6 +315,6 @@ class xv_plda:
         return x
 
     def time_layer(self, layer, B, T, iters=20):
-        ms, fl = C.c_float(), C.c_double()
-        self.ctx.call("sg_xv_time_layer", layer, B, T, iters, C.byref(ms), C.byref(fl), self._stream())
-        return ms.value, fl.value
+        ms, fl, rows = C.c_float(), C.c_double(), C.c_int32()
+        self.ctx.call("sg_xv_time_layer", layer, B, T, iters, C.byref(ms), C.byref(fl), C.byref(rows), self._stream())
+        return ms.value, fl.value, rows.value

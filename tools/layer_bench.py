@@ -1,0 +1,44 @@
+"""Per-layer timing of the TDNN contractions (forward and data-gradient) on one GPU.
+
+    python tools/layer_bench.py [--batch 64] [--iters 20]
+
+Prints ms / TFLOP/s / fraction of the 157.3 TFLOP/s f32-MFMA peak per launch.  Used for kernel
+tuning and as the workload of the rocprofv3 --pmc passes kept under profiles/.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from speakerguard_amd import synth  # noqa: E402
+from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy  # noqa: E402
+from speakerguard_amd.model.xv_plda import xv_plda  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--layers", type=str, default="1,2,3,4,5,-5,-4,-3,-2,-1")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    model = xv_plda.from_weights(synth.make_xv_weights(), device=dev, dither=0.0)
+    x = torch.from_numpy(synth.make_waveforms(args.batch, 48000, seed=1234)).to(dev)
+    y = (torch.arange(args.batch) % 10).to(dev)
+    model.loss_grad(x, y, SEC4SR_CrossEntropy())  # fills activations and gradients
+    torch.cuda.synchronize()
+    tot_ms, tot_fl = 0.0, 0.0
+    for l in [int(v) for v in args.layers.split(",")]:
+        ms, fl, rows = model.time_layer(l, args.batch, 48000, args.iters)
+        tf = fl / (ms * 1e-3) / 1e12
+        tot_ms += ms
+        tot_fl += fl
+        print("layer %+d  tile_rows %3d  %8.3f ms  %7.2f TFLOP/s  %5.1f %% of 157.3" % (l, rows, ms, tf, 100 * tf / 157.3))
+    print("sum        %8.3f ms  %7.2f TFLOP/s" % (tot_ms, tot_fl / (tot_ms * 1e-3) / 1e12))
+
+
+if __name__ == "__main__":
+    main()
