@@ -99,6 +99,7 @@ def resolve_loss(loss_name='Entropy', targeted=False, confidence=0., task='CSI',
             warnings.warn('You are targeting {} task. Force using Margin Loss.'.format(task))
     else:
         loss = SEC4SR_CrossEntropy(reduction='none', task='CSI')
+        loss.targeted = targeted  # the formula ignores it; the fused loop needs it for the success flag
     grad_sign = (1 - 2 * int(targeted)) if loss_name == 'Entropy' else -1
     return loss, grad_sign
 

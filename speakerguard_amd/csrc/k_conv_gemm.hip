@@ -16,8 +16,8 @@
 // Tiling: 256 threads = 4 waves (64 lanes).  v_mfma_f32_32x32x2_f32, exact fp32, 64 cycles per
 // instruction per SIMD.  LDS: A chunk stored K-major [32][BM] (register-transposed 4x4 blocks,
 // ds_write_b128), W chunk [32][BN]; MFMA operands are conflict-free ds_read_b32 (lanes 0-31 read
-// 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages, next chunk's global loads
-// are issued before the current chunk's MFMAs and written to LDS after them (one barrier/chunk).
+// 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages + one register stage; the
+// staging of chunk c+1 / c+2 is issued in the middle of chunk c's MFMA stream (one barrier/chunk).
 #include <cstdlib>
 
 #include "sg_internal.h"
@@ -28,18 +28,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int mtiles, int ntiles) {
+// ------------------------------------------------------------------------------------------
+// One K-segment of one output tile: acc += A[m0.., chunks c_begin..c_end) * W[.., n0..).
+// Ends with a barrier, so the LDS stages can be reused immediately by the caller.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_segment(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+                                             int c_end, f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
     constexpr int A_QUADS = BM / 4;            // row quads in the A tile
-    constexpr int A_ACTIVE = A_QUADS * 8;      // threads that stage A (8 float4 per 32-float row slice)
     constexpr int B_F4 = BK * BN / 4;          // float4 in the W tile
     constexpr int B_PER_THREAD = (B_F4 + 255) / 256;
-    static_assert(A_ACTIVE <= 256, "A tile too tall");
+    static_assert(A_QUADS * 8 <= 256, "A tile too tall");
     static_assert(B_PER_THREAD <= 4, "W tile too wide");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     float* As = smem;                 // [2][BK][BM]
     float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
 
@@ -49,39 +51,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
-    // run of tiles so the N-tiles that share an A row-panel hit the same L2.
-    const int nblk = mtiles * ntiles;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk / 8, r = nblk % 8;
-        const int xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int mt = bid / ntiles, nt = bid % ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-
     // ---- A staging map: lane -> (row quad, 4-float k group); 8 lanes of a group share a k group
     const int a_r4 = wid * 8 + (lane & 7);   // row quad index (valid if < A_QUADS)
     const int a_c4 = lane >> 3;              // which float4 of the 32-float slice
     const bool a_on = a_r4 < A_QUADS;
-    int a_base[4], a_t[4];
+    const float* a_ptr[4];
+    int a_t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = m0 + a_r4 * 4 + i;
         if (a_on && r < p.M) {
             const int b = r / p.Tc;
             const int t = r - b * p.Tc;
-            a_base[i] = b * p.Ta + t;
+            a_ptr[i] = p.A + (size_t)(b * p.Ta + t) * p.lda + a_c4 * 4;
             a_t[i] = t;
         } else {
-            a_base[i] = 0;
+            a_ptr[i] = p.A;
             a_t[i] = -(1 << 28);
         }
     }
     const int kchunks = p.Kc / BK;
-    const int c_begin = blockIdx.z * p.chunks_per_split;
-    const int c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
+    // W tile: thread -> float4 f = tid + i*256 of the [BK][BN] chunk image
+    const float* b_ptr[B_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+        const int f = (tid + i * 256) % B_F4;
+        b_ptr[i] = p.W + (size_t)(f / (BN / 4)) * p.ldw + n0 + (f % (BN / 4)) * 4;
+    }
 
     // Staging registers are named scalars on purpose: as arrays captured by the helper lambdas hipcc's
     // promote-alloca pass moved the W-tile registers into LDS (+16 KB, an LDS round trip per chunk).
@@ -89,32 +85,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     bool ok0, ok1, ok2, ok3;
     rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // Loads are branch-free: an out-of-range tap row (or a thread that stages nothing) reads row 0
-    // and is zeroed when the registers are written to LDS.  A conditional load makes hipcc wait
-    // vmcnt(0) at every branch join, which serialised four global round trips per chunk in front
-    // of the MFMAs.
-#define SG_LOAD_A(i, r, okv)                                                                              \
-    {                                                                                                     \
-        const int tt = a_t[i] + off;                                                                      \
-        okv = tt >= 0 && tt < p.Ta;                                                                       \
-        const int row = okv ? a_base[i] + off : 0;                                                        \
-        r = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + kc + a_c4 * 4);                  \
+    // Loads are branch-free: an out-of-range tap row (or a thread that stages nothing) reads the first
+    // row and is zeroed when the registers are written to LDS.  A conditional load makes hipcc wait
+    // vmcnt(0) at every branch join, which serialised four global round trips per chunk in front of
+    // the MFMAs.  Per chunk only a wave-uniform element offset is added to per-thread base pointers.
+#define SG_LOAD_A(i, r, okv)                                                        \
+    {                                                                               \
+        const int tt = a_t[i] + off;                                                \
+        okv = tt >= 0 && tt < p.Ta;                                                 \
+        r = *reinterpret_cast<const float4*>(okv ? a_ptr[i] + a_off : p.A);         \
     }
-#define SG_LOAD_B(i, r)                                                                                   \
-    if (i < B_PER_THREAD) {                                                                               \
-        const int f = (tid + i * 256) % B_F4;                                                             \
-        r = *reinterpret_cast<const float4*>(wrow + (size_t)(f / (BN / 4)) * p.ldw + (f % (BN / 4)) * 4); \
-    }
-#define SG_STORE_B(i, r)                                                                                  \
-    if (i < B_PER_THREAD && (B_F4 % 256 == 0 || tid + i * 256 < B_F4))                                    \
+#define SG_LOAD_B(i, r) \
+    if (i < B_PER_THREAD) r = *reinterpret_cast<const float4*>(b_ptr[i < B_PER_THREAD ? i : 0] + b_off);
+#define SG_STORE_B(i, r)                                                            \
+    if (i < B_PER_THREAD && (B_F4 % 256 == 0 || tid + i * 256 < B_F4))              \
         *reinterpret_cast<float4*>(Bs + buf * BK * BN + (tid + i * 256) * 4) = r;
 
     auto load_chunk = [&](int c) {
         const int j = c / kchunks;
         const int kc = (c - j * kchunks) * BK;
         const int off = j * p.tap_step;
+        const long a_off = (long)off * p.lda + kc;
+        const long b_off = (long)(j * p.Kc + kc) * p.ldw;
         SG_LOAD_A(0, ra0, ok0) SG_LOAD_A(1, ra1, ok1) SG_LOAD_A(2, ra2, ok2) SG_LOAD_A(3, ra3, ok3)
-        const float* wrow = p.W + (size_t)(j * p.Kc + kc) * p.ldw + n0;
         SG_LOAD_B(0, rb0) SG_LOAD_B(1, rb1) SG_LOAD_B(2, rb2) SG_LOAD_B(3, rb3)
     };
     auto store_chunk = [&](int buf) {
@@ -134,27 +127,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 #undef SG_LOAD_B
 #undef SG_STORE_B
 
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
+    // Software pipeline over K-chunks, two LDS stages, one register stage:
+    //   chunk c computes from LDS stage c&1; in the MIDDLE of its MFMA stream the registers holding
+    //   chunk c+1 (loaded half a chunk earlier) are written to the other LDS stage and the loads of
+    //   chunk c+2 are issued.  The staging instructions (address VALU, ds_write, global_load) thus
+    //   issue in the shadow of this wave's own MFMAs; only the barrier remains at the chunk boundary.
     if (c_begin < c_end) {
         load_chunk(c_begin);
         store_chunk(0);
+        if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
     }
     __syncthreads();
 
     const int a_rd = wm * (BM / WM) + l31;
     const int b_rd = wn * (BN / WN) + l31;
+    constexpr int KS_STAGE = 5;  // k-step after which the next chunk is staged
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) load_chunk(c + 1);
-        // hipcc otherwise sinks the global loads' consumers (the ds_writes of store_chunk, which touch
-        // the OTHER LDS stage) above the MFMA loop and waits vmcnt there; pin the phase order.
         __builtin_amdgcn_sched_barrier(0);
         const float* a_s = As + buf * BK * BM + lhi * BM + a_rd;
         const float* b_s = Bs + buf * BK * BN + lhi * BN + b_rd;
@@ -180,13 +169,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][mi], bv[ks & 1][ni], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (ks == KS_STAGE) {
+                if (c + 1 < c_end && !(p.ablate & 2)) store_chunk(buf ^ 1);
+                if (c + 2 < c_end && !(p.ablate & 1)) load_chunk(c + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (c + 1 < c_end) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (!(p.ablate & 4)) __syncthreads();
     }
+}
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    float* Cz = p.C + (size_t)blockIdx.z * p.split_stride;
+// Walk the accumulator fragments of a tile.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (e&3) + 8*(e>>2) + 4*(lane>>5).  fn(mi, ni, row0, col) handles one 16-value fragment.
+template <int BM, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void tile_store(const ConvGemmArgs& p, float* C, int m0, int n0,
+                                           f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
+    constexpr int MI = BM / WM / 32;
+    constexpr int NI = BN / WN / 32;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -211,9 +213,134 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
                 float v = acc[mi][ni][e];
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
                 if (EPI == EPI_RELU_MASK) v = mk[e] > 0.f ? v : 0.f;
-                if (row < p.M) Cz[(size_t)row * p.ldc + col] = v;
+                if (row < p.M) C[(size_t)row * p.ldc + col] = v;
             }
         }
+    }
+}
+
+template <int MI, int NI>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[MI][NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Data-parallel launch: one block per output tile (x optional split-K slabs along blockIdx.z).
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int mtiles, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+    // run of tiles so the N-tiles that share an A row-panel hit the same L2.
+    const int nblk = mtiles * ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8;
+        const int xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / ntiles, nt = bid % ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
+    f32x16 acc[BM / WM / 32][BN / WN / 32];
+    acc_zero(acc);
+    gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, c_begin, c_end, acc);
+    tile_store<BM, BN, WM, WN, EPI>(p, p.C + (size_t)blockIdx.z * p.split_stride, m0, n0, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stream-K launch (64 x 128 tiles): `workers` persistent blocks, all co-resident (3 per CU), each
+// owning an equal contiguous range of (tile, K-chunk) iterations, so every block does the same
+// number of MFMAs and the launch has no tail (the data-parallel launch of 1080 tiles on 768
+// slots idles ~16 % of the matrix pipes in its last round).  A tile whose chunks straddle two
+// workers is combined deterministically: the worker that owns the tile's FIRST chunks computes
+// them first thing and parks the accumulators in its slab; the worker that owns the LAST chunks
+// handles them last, starting from the parked accumulators (same fmaf chain as an unsplit tile,
+// so the result is bit-identical to the data-parallel launch) and runs the epilogue.
+// The waiting side always has the higher block index, so under in-order dispatch the block it
+// waits for is resident or already finished.  Hand-off = agent-scope release/acquire on one flag
+// per worker (cdna guide G16); flags are zeroed by a memset node in front of every launch.
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+                                                                   int iters_per_worker, float* slabs,
+                                                                   unsigned* flags) {
+    constexpr int BM = 64, BN = 128, WM = 2, WN = 2;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    const int C = p.total_chunks;
+    const long total = (long)tiles * C;
+    const int w = blockIdx.x;
+    const long it_begin = (long)w * iters_per_worker;
+    const long it_end = min(total, it_begin + iters_per_worker);
+    if (it_begin >= it_end) return;
+    float* my_slab = slabs + (size_t)w * BM * BN;
+    f32x16 acc[1][2];
+
+    const int first_tile = (int)(it_begin / C), first_c0 = (int)(it_begin % C);
+    const int last_tile = (int)((it_end - 1) / C), last_c1 = (int)((it_end - 1) % C) + 1;
+    const bool head_piece = last_c1 < C;                   // my range stops inside last_tile
+    const bool tail_piece = first_c0 > 0;                  // my range starts inside first_tile
+    auto tile_origin = [&](int tile, int& m0, int& n0) {
+        m0 = (tile / ntiles) * BM;
+        n0 = (tile % ntiles) * BN;
+    };
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+    // 1. the head piece of my last tile (chunks [0, last_c1)): park it for worker w+1
+    if (head_piece && !(last_tile == first_tile && tail_piece)) {
+        int m0, n0;
+        tile_origin(last_tile, m0, n0);
+        acc_zero(acc);
+        gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, 0, last_c1, acc);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) my_slab[((wid * 2 + ni) * 16 + e) * 64 + lane] = acc[0][ni][e];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // 2. whole tiles
+    const int whole_begin = tail_piece ? first_tile + 1 : first_tile;
+    const int whole_end = head_piece ? last_tile : last_tile + 1;
+    for (int tile = whole_begin; tile < whole_end; ++tile) {
+        int m0, n0;
+        tile_origin(tile, m0, n0);
+        acc_zero(acc);
+        gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, 0, C, acc);
+        tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
+    }
+    // 3. the tail piece of my first tile (chunks [first_c0, C)): RESUME from the accumulators worker
+    //    w-1 parked, so every output element sees exactly the fmaf chain of an unsplit tile -- the
+    //    result is bit-identical to the one-block-per-tile launch and does not depend on the batch.
+    if (tail_piece) {
+        int m0, n0;
+        tile_origin(first_tile, m0, n0);
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(flags + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 26)) break;  // bounded: a lost hand-off shows up as a parity failure
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* slab = slabs + (size_t)(w - 1) * BM * BN;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][ni][e] = slab[((wid * 2 + ni) * 16 + e) * 64 + lane];
+        const int c1 = first_tile == last_tile ? last_c1 : C;  // (host guarantees == C, see launcher)
+        gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, first_c0, c1, acc);
+        tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
     }
 }
 
@@ -231,6 +358,38 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
             break;
         case EPI_RELU_MASK:
             hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, EPI_RELU_MASK>), grid, dim3(256), 0, s, a, mtiles, ntiles);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+constexpr int kStreamKWorkers = 768;  // 256 CUs x 3 resident blocks (48 KB LDS, <= 128 VGPRs)
+
+// returns hipErrorNotSupported when the shape does not qualify (caller falls back to the tile launch)
+static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, unsigned* flags, hipStream_t s) {
+    const int mtiles = (a.M + 63) / 64, ntiles = a.N / 128;
+    const int tiles = mtiles * ntiles;
+    const long total = (long)tiles * a.total_chunks;
+    const int ipw = (int)((total + kStreamKWorkers - 1) / kStreamKWorkers);
+    // every range must span at least one full tile's worth of chunks, so a tile is shared by at most
+    // two workers and never lies strictly inside one range
+    // Short-K contractions (tdnn1/4/5 forward: <= 16 chunks) are faster one block per tile (measured).
+    if (!slabs || !flags || tiles < kStreamKWorkers || ipw < a.total_chunks || a.total_chunks < 40)
+        return hipErrorNotSupported;
+    hipError_t e = hipMemsetAsync(flags, 0, kStreamKWorkers * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    dim3 grid(kStreamKWorkers);
+    switch (epi) {
+        case EPI_NONE:
+            hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI_NONE>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw, slabs, flags);
+            break;
+        case EPI_BIAS_RELU:
+            hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI_BIAS_RELU>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw, slabs, flags);
+            break;
+        case EPI_RELU_MASK:
+            hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI_RELU_MASK>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw, slabs, flags);
             break;
         default:
             return hipErrorInvalidValue;
@@ -256,11 +415,25 @@ static int pick_height(int M, int ntiles) {
 
 int conv_gemm_tile_rows(int M, int N) { return pick_height(M, N / 128); }
 
-hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s) {
+hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int splits, hipStream_t s) {
+    static const int ablate = [] {
+        const char* e = getenv("SG_ABLATE");  // timing experiments only (results become wrong)
+        return e ? atoi(e) : 0;
+    }();
+    static const int use_streamk = [] {
+        const char* e = getenv("SG_STREAMK");  // 0 = always one block per tile
+        return e ? atoi(e) : 1;
+    }();
+    ConvGemmArgs a = a_in;
+    a.ablate = ablate;
     if (a.Kc % BK != 0 || a.M <= 0) return hipErrorInvalidValue;
     switch (tile) {
         case 0: {
             if (a.N % 128) return hipErrorInvalidValue;
+            if (splits == 1 && use_streamk) {
+                const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
+                if (e != hipErrorNotSupported) return e;
+            }
             const int h = splits == 1 ? pick_height(a.M, a.N / 128) : 128;
             if (h == 96) return launch_tile<96, 128, 1, 4>(a, epi, splits, s);
             if (h == 64) return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
@@ -272,9 +445,6 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits
         case 2:
             if (a.N % 128) return hipErrorInvalidValue;
             return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
-        case 3:  // forced 128x128 (measurement)
-            if (a.N % 128) return hipErrorInvalidValue;
-            return launch_tile<128, 128, 2, 2>(a, epi, splits, s);
         default:
             return hipErrorInvalidValue;
     }

@@ -145,6 +145,8 @@ int build_tables(sg_ctx* ctx) {
     rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->range_scratch, 512);
+    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_slabs, (size_t)768 * 64 * 128);
+    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_flags, 768);
     if (rc) return SG_ERR_HIP;
     ctx->tables_ready = true;
     return SG_OK;
@@ -246,6 +248,8 @@ ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
     a.total_chunks = a.taps * (a.Kc / 32);
     a.chunks_per_split = a.total_chunks;
     a.split_stride = 0;
+    a.sk_slabs = ctx->sk_slabs;
+    a.sk_flags = ctx->sk_flags;
     return a;
 }
 
@@ -300,6 +304,8 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.total_chunks = a.taps * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
         a.split_stride = 0;
+        a.sk_slabs = ctx->sk_slabs;
+        a.sk_flags = ctx->sk_flags;
         SG_HIP(launch_conv_gemm(a, l == 0 ? 1 : 0, l == 0 ? EPI_NONE : EPI_RELU_MASK, 1, s));
     }
     return SG_OK;
@@ -662,6 +668,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
         a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
         a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];
         a.total_chunks = a.taps * (a.Kc / 32); a.chunks_per_split = a.total_chunks;
+        a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags;
         tile = l == 0 ? 1 : 0;
         epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;
     }

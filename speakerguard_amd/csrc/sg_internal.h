@@ -104,6 +104,8 @@ struct sg_ctx {
     sg::MfccTables tab{};
     bool tables_ready = false;
     float* range_scratch = nullptr;  // [512] partial max/min of check_input_range
+    float* sk_slabs = nullptr;       // stream-K scratch (k_conv_gemm.hip)
+    unsigned* sk_flags = nullptr;
     sg::XvModel xv;
     sg::Workspace ws;
     std::vector<void*> model_allocs;
@@ -128,6 +130,9 @@ struct ConvGemmArgs {
     int taps, tap_step; // A row offset of tap j = j * tap_step
     int total_chunks, chunks_per_split;
     long long split_stride;
+    int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
+    float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
+    unsigned* sk_flags; // stream-K: [768] hand-off flags
 };
 
 // tile: 0 = 128x128 (2x2 waves), 1 = 128x32 (4x1 waves), 2 = 64x128 (2x2 waves)
