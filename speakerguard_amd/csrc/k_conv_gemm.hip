@@ -179,6 +179,121 @@ __device__ __forceinline__ void gemm_segment(const ConvGemmArgs& p, float* smem,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 8-wave variant: 128 x 128 tile, 512 threads as 2 (M) x 4 (N) waves, each wave 64 x 32.
+// Staging is role-split: waves 0-3 fetch and transpose the A chunk (4 rows x 4 k per thread),
+// waves 4-7 copy the W chunk -- 4 global loads + 4 LDS stores per thread per chunk, half of the
+// 4-wave 64 x 128 block, and a third less L2 traffic per MAC.  64 KB of LDS -> two blocks per CU
+// = 4 waves per SIMD.  Loads stay branch-free: both roles issue the same four loads through
+// role-selected pointers.
+__device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+                                              int c_end, f32x16 (&acc)[2][1]) {
+    constexpr int BM = 128, BN = 128;
+    float* As = smem;                 // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const bool role_a = wid < 4;
+
+    const int a_r4 = (wid & 3) * 8 + (lane & 7);  // A role: row quad 0..31
+    const int a_c4 = lane >> 3;                   //         float4 of the 32-float slice
+    const float* ptr[4];
+    int a_t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (role_a) {
+            const int r = m0 + a_r4 * 4 + i;
+            if (r < p.M) {
+                const int b = r / p.Tc;
+                const int t = r - b * p.Tc;
+                ptr[i] = p.A + (size_t)(b * p.Ta + t) * p.lda + a_c4 * 4;
+                a_t[i] = t;
+            } else {
+                ptr[i] = p.A;
+                a_t[i] = -(1 << 28);
+            }
+        } else {
+            const int f = (tid - 256) + i * 256;  // float4 index in the [32][128] W chunk
+            ptr[i] = p.W + (size_t)(f >> 5) * p.ldw + n0 + (f & 31) * 4;
+            a_t[i] = 0;
+        }
+    }
+    const int kchunks = p.Kc / BK;
+    float4 r0, r1, r2, r3;
+    bool ok0, ok1, ok2, ok3;
+#define SG_LD(i, r, okv)                                                              \
+    {                                                                                 \
+        const int tt = a_t[i] + off;                                                  \
+        okv = !role_a || (tt >= 0 && tt < p.Ta);                                      \
+        r = *reinterpret_cast<const float4*>(okv ? ptr[i] + eoff : p.A);              \
+    }
+    auto load_chunk = [&](int c) {
+        const int j = c / kchunks;
+        const int kc = (c - j * kchunks) * BK;
+        const int off = role_a ? j * p.tap_step : 0;
+        const long eoff = role_a ? (long)off * p.lda + kc : (long)(j * p.Kc + kc) * p.ldw;
+        SG_LD(0, r0, ok0) SG_LD(1, r1, ok1) SG_LD(2, r2, ok2) SG_LD(3, r3, ok3)
+    };
+#undef SG_LD
+    auto store_chunk = [&](int buf) {
+        if (role_a) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 q0 = ok0 ? r0 : z, q1 = ok1 ? r1 : z, q2 = ok2 ? r2 : z, q3 = ok3 ? r3 : z;
+            float* a = As + buf * BK * BM + (a_c4 * 4) * BM + a_r4 * 4;
+            *reinterpret_cast<float4*>(a + 0 * BM) = make_float4(q0.x, q1.x, q2.x, q3.x);
+            *reinterpret_cast<float4*>(a + 1 * BM) = make_float4(q0.y, q1.y, q2.y, q3.y);
+            *reinterpret_cast<float4*>(a + 2 * BM) = make_float4(q0.z, q1.z, q2.z, q3.z);
+            *reinterpret_cast<float4*>(a + 3 * BM) = make_float4(q0.w, q1.w, q2.w, q3.w);
+        } else {
+            float* b = Bs + buf * BK * BN + (tid - 256) * 4;
+            *reinterpret_cast<float4*>(b + 0 * 1024) = r0;
+            *reinterpret_cast<float4*>(b + 1 * 1024) = r1;
+            *reinterpret_cast<float4*>(b + 2 * 1024) = r2;
+            *reinterpret_cast<float4*>(b + 3 * 1024) = r3;
+        }
+    };
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
+    }
+    __syncthreads();
+    const int a_rd = wm * 64 + l31;
+    const int b_rd = wn * 32 + l31;
+    constexpr int KS_STAGE = 5;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* a_s = As + buf * BK * BM + lhi * BM + a_rd;
+        const float* b_s = Bs + buf * BK * BN + lhi * BN + b_rd;
+        float av[2][2], bv[2];
+        av[0][0] = a_s[0];
+        av[0][1] = a_s[32];
+        bv[0] = b_s[0];
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            if (ks + 1 < BK / 2) {
+                av[(ks + 1) & 1][0] = a_s[(ks + 1) * 2 * BM];
+                av[(ks + 1) & 1][1] = a_s[(ks + 1) * 2 * BM + 32];
+                bv[(ks + 1) & 1] = b_s[(ks + 1) * 2 * BN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][0], bv[ks & 1], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][1], bv[ks & 1], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == KS_STAGE) {
+                if (c + 1 < c_end) store_chunk(buf ^ 1);
+                if (c + 2 < c_end) load_chunk(c + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Walk the accumulator fragments of a tile.  C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5).  fn(mi, ni, row0, col) handles one 16-value fragment.
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -265,11 +380,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 // The waiting side always has the higher block index, so under in-order dispatch the block it
 // waits for is resident or already finished.  Hand-off = agent-scope release/acquire on one flag
 // per worker (cdna guide G16); flags are zeroed by a memset node in front of every launch.
-template <int EPI>
-__global__ __launch_bounds__(256, 3) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+template <int EPI, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                    int iters_per_worker, float* slabs,
                                                                    unsigned* flags) {
-    constexpr int BM = 64, BN = 128, WM = 2, WN = 2;
+    constexpr int BM = W8 ? 128 : 64, BN = 128, WM = 2, WN = W8 ? 4 : 2;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 1x2 (4 waves) or 2x1 (8 waves)
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int C = p.total_chunks;
     const long total = (long)tiles * C;
@@ -278,7 +394,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_streamk_kernel(ConvGemmArgs 
     const long it_end = min(total, it_begin + iters_per_worker);
     if (it_begin >= it_end) return;
     float* my_slab = slabs + (size_t)w * BM * BN;
-    f32x16 acc[1][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    f32x16 acc[MI][NI];
+    auto segment = [&](int m0, int n0, int c0, int c1) {
+        if constexpr (W8) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
+        else gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, c0, c1, acc);
+    };
+    auto frag = [&](int mi, int ni, int e) { return (((wid * MI + mi) * NI + ni) * 16 + e) * 64 + lane; };
 
     const int first_tile = (int)(it_begin / C), first_c0 = (int)(it_begin % C);
     const int last_tile = (int)((it_end - 1) / C), last_c1 = (int)((it_end - 1) % C) + 1;
@@ -288,18 +410,19 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_streamk_kernel(ConvGemmArgs 
         m0 = (tile / ntiles) * BM;
         n0 = (tile % ntiles) * BN;
     };
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
     // 1. the head piece of my last tile (chunks [0, last_c1)): park it for worker w+1
     if (head_piece && !(last_tile == first_tile && tail_piece)) {
         int m0, n0;
         tile_origin(last_tile, m0, n0);
         acc_zero(acc);
-        gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, 0, last_c1, acc);
+        segment(m0, n0, 0, last_c1);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) my_slab[((wid * 2 + ni) * 16 + e) * 64 + lane] = acc[0][ni][e];
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) my_slab[frag(mi, ni, e)] = acc[mi][ni][e];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -315,7 +438,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_streamk_kernel(ConvGemmArgs 
         int m0, n0;
         tile_origin(tile, m0, n0);
         acc_zero(acc);
-        gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, 0, C, acc);
+        segment(m0, n0, 0, C);
         tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
     }
     // 3. the tail piece of my first tile (chunks [first_c0, C)): RESUME from the accumulators worker
@@ -335,11 +458,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_streamk_kernel(ConvGemmArgs 
         __syncthreads();
         const float* slab = slabs + (size_t)(w - 1) * BM * BN;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[0][ni][e] = slab[((wid * 2 + ni) * 16 + e) * 64 + lane];
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = slab[frag(mi, ni, e)];
         const int c1 = first_tile == last_tile ? last_c1 : C;  // (host guarantees == C, see launcher)
-        gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, first_c0, c1, acc);
+        segment(m0, n0, first_c0, c1);
         tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
     }
 }
@@ -365,35 +490,39 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
-constexpr int kStreamKWorkers = 768;  // 256 CUs x 3 resident blocks (48 KB LDS, <= 128 VGPRs)
+constexpr int kStreamKWorkers4 = 768;  // 4-wave 64x128 blocks: 256 CUs x 3 (48 KB LDS, <= 168 VGPRs)
+constexpr int kStreamKWorkers8 = 512;  // 8-wave 128x128 blocks: 256 CUs x 2 (64 KB LDS, <= 128 VGPRs)
 
 // returns hipErrorNotSupported when the shape does not qualify (caller falls back to the tile launch)
 static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, unsigned* flags, hipStream_t s) {
-    const int mtiles = (a.M + 63) / 64, ntiles = a.N / 128;
+    static const int w8 = [] {
+        const char* e = getenv("SG_STREAMK_W8");  // tuning aid: 0 = 4-wave 64x128 blocks
+        return e ? atoi(e) : 1;
+    }();
+    const int bm = w8 ? 128 : 64, workers = w8 ? kStreamKWorkers8 : kStreamKWorkers4;
+    const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
     const int tiles = mtiles * ntiles;
     const long total = (long)tiles * a.total_chunks;
-    const int ipw = (int)((total + kStreamKWorkers - 1) / kStreamKWorkers);
+    const int ipw = (int)((total + workers - 1) / workers);
     // every range must span at least one full tile's worth of chunks, so a tile is shared by at most
-    // two workers and never lies strictly inside one range
+    // two workers and never lies strictly inside one range.
     // Short-K contractions (tdnn1/4/5 forward: <= 16 chunks) are faster one block per tile (measured).
-    if (!slabs || !flags || tiles < kStreamKWorkers || ipw < a.total_chunks || a.total_chunks < 40)
-        return hipErrorNotSupported;
-    hipError_t e = hipMemsetAsync(flags, 0, kStreamKWorkers * sizeof(unsigned), s);
+    if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < 40) return hipErrorNotSupported;
+    hipError_t e = hipMemsetAsync(flags, 0, 1024 * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    dim3 grid(kStreamKWorkers);
+    dim3 grid(workers);
+#define SG_SK(EPI)                                                                                              \
+    if (w8) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw, \
+                               slabs, flags);                                                                   \
+    else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw,   \
+                            slabs, flags);
     switch (epi) {
-        case EPI_NONE:
-            hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI_NONE>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw, slabs, flags);
-            break;
-        case EPI_BIAS_RELU:
-            hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI_BIAS_RELU>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw, slabs, flags);
-            break;
-        case EPI_RELU_MASK:
-            hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI_RELU_MASK>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw, slabs, flags);
-            break;
-        default:
-            return hipErrorInvalidValue;
+        case EPI_NONE: SG_SK(EPI_NONE) break;
+        case EPI_BIAS_RELU: SG_SK(EPI_BIAS_RELU) break;
+        case EPI_RELU_MASK: SG_SK(EPI_RELU_MASK) break;
+        default: return hipErrorInvalidValue;
     }
+#undef SG_SK
     return hipGetLastError();
 }
 

@@ -118,6 +118,27 @@ hipError_t launch_copy_cols(const float* in, int ld_in, float* out, int ld_out, 
     return hipGetLastError();
 }
 
+// out[r][0..ncol) = sum_z in[z][r][0..ncol)  (split-K slabs, fixed order)
+__global__ __launch_bounds__(256) void sum_cols_kernel(const float* __restrict__ in, int ld_in, int nsplit,
+                                                       long long slab_stride, float* __restrict__ out, int ld_out,
+                                                       int64_t rows, int ncol) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ncol) return;
+    const int64_t r = i / ncol;
+    const int c = (int)(i - r * ncol);
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += in[(size_t)z * slab_stride + r * ld_in + c];
+    out[r * ld_out + c] = v;
+}
+
+hipError_t launch_sum_cols(const float* in, int ld_in, int nsplit, long long slab_stride, float* out, int ld_out,
+                           int64_t rows, int ncol, hipStream_t s) {
+    const int64_t n = rows * ncol;
+    hipLaunchKernelGGL(sum_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, ld_in, nsplit, slab_stride,
+                       out, ld_out, rows, ncol);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- CMVN (model/iv_plda.py:296-377)
 // Centred sliding window of 300 frames, mean only.  window(t) = [start, end) as at :321-336.
 __device__ __forceinline__ void cmvn_window(int t, int F, int& start, int& end) {
@@ -141,11 +162,21 @@ __global__ __launch_bounds__(256) void cmvn_fwd_kernel(const float* __restrict__
     const float* x = in + (size_t)b * F * ld_in;
     float* y = out + (size_t)b * F * ld_out;
     __shared__ double total[kCep];
+    __shared__ double part[8][32];
     if (F <= kCmnWindow) {
-        // every window is the whole utterance: one column sum per cepstrum
+        // every window is the whole utterance: one column sum per cepstrum, 8 row-strided partial
+        // sums per column combined in a fixed order
+        {
+            const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
+            double acc = 0.0;
+            if (d < kCep)
+                for (int t = r; t < F; t += 8) acc += (double)x[(size_t)t * ld_in + d];
+            part[r][d] = acc;
+        }
+        __syncthreads();
         if (threadIdx.x < kCep) {
             double acc = 0.0;
-            for (int t = 0; t < F; ++t) acc += (double)x[(size_t)t * ld_in + threadIdx.x];
+            for (int r = 0; r < 8; ++r) acc += part[r][threadIdx.x];
             total[threadIdx.x] = acc;
         }
         __syncthreads();
@@ -170,22 +201,38 @@ __global__ __launch_bounds__(256) void cmvn_fwd_kernel(const float* __restrict__
 }
 
 // d_in[u] = d_out[u] - sum_{t : u in window(t)} d_out[t] / |window(t)|
-__global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout,
-                                                       float* __restrict__ din, int ld_din, int F) {
+// d_out arrives as `nsplit` split-K slabs of the tdnn1 data-gradient contraction (summed in order).
+__global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout, int nsplit,
+                                                       long long slab_stride, float* __restrict__ din, int ld_din,
+                                                       int F) {
     const int b = blockIdx.x;
     const float* g = dout + (size_t)b * F * ld_dout;
     float* y = din + (size_t)b * F * ld_din;
+    auto gsum = [&](int t, int d) {
+        float v = 0.f;
+        for (int z = 0; z < nsplit; ++z) v += g[(size_t)z * slab_stride + (size_t)t * ld_dout + d];
+        return v;
+    };
     __shared__ double total[kCep];
+    __shared__ double part[8][32];
     if (F <= kCmnWindow) {
+        {
+            const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
+            double acc = 0.0;
+            if (d < kCep)
+                for (int t = r; t < F; t += 8) acc += (double)gsum(t, d);
+            part[r][d] = acc;
+        }
+        __syncthreads();
         if (threadIdx.x < kCep) {
             double acc = 0.0;
-            for (int t = 0; t < F; ++t) acc += (double)g[(size_t)t * ld_dout + threadIdx.x];
+            for (int r = 0; r < 8; ++r) acc += part[r][threadIdx.x];
             total[threadIdx.x] = acc / (double)F;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < F * kCep; i += 256) {
             const int t = i / kCep, d = i - t * kCep;
-            y[(size_t)t * ld_din + d] = g[(size_t)t * ld_dout + d] - (float)total[d];
+            y[(size_t)t * ld_din + d] = gsum(t, d) - (float)total[d];
         }
     } else {
         for (int i = threadIdx.x; i < F * kCep; i += 256) {
@@ -194,9 +241,9 @@ __global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__
             for (int t = 0; t < F; ++t) {
                 int s, e;
                 cmvn_window(t, F, s, e);
-                if (u >= s && u < e) acc += (double)g[(size_t)t * ld_dout + d] / (double)(e - s);
+                if (u >= s && u < e) acc += (double)gsum(t, d) / (double)(e - s);
             }
-            y[(size_t)u * ld_din + d] = g[(size_t)u * ld_dout + d] - (float)acc;
+            y[(size_t)u * ld_din + d] = gsum(u, d) - (float)acc;
         }
     }
 }
@@ -205,8 +252,9 @@ hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, i
     hipLaunchKernelGGL(cmvn_fwd_kernel, dim3(B), dim3(256), 0, s, in, ld_in, out, ld_out, F);
     return hipGetLastError();
 }
-hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, float* din, int ld_din, int B, int F, hipStream_t s) {
-    hipLaunchKernelGGL(cmvn_bwd_kernel, dim3(B), dim3(256), 0, s, dout, ld_dout, din, ld_din, F);
+hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long slab_stride, float* din, int ld_din,
+                           int B, int F, hipStream_t s) {
+    hipLaunchKernelGGL(cmvn_bwd_kernel, dim3(B), dim3(256), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
     return hipGetLastError();
 }
 
@@ -219,16 +267,38 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     const int b = blockIdx.y;
     const float* a = act + (size_t)b * Tc * kPoolC + c;
     __shared__ float red[4][64];
+    // two-pass variance (like torch.std); the <= 96 frames a wave owns stay in registers between the
+    // passes so the activation tensor is read once (longer utterances re-read from L2)
+    constexpr int kKeep = 96;
+    float keep[kKeep];
+    const bool fits = Tc <= 4 * kKeep;
     float s = 0.f;
-    for (int t = wid; t < Tc; t += 4) s += a[(size_t)t * kPoolC];
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < kKeep; ++i) {
+            const int t = wid + 4 * i;
+            keep[i] = t < Tc ? a[(size_t)t * kPoolC] : 0.f;
+            s += keep[i];
+        }
+    } else {
+        for (int t = wid; t < Tc; t += 4) s += a[(size_t)t * kPoolC];
+    }
     red[wid][lane] = s;
     __syncthreads();
     const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)Tc;
     __syncthreads();
     float q = 0.f;
-    for (int t = wid; t < Tc; t += 4) {
-        const float d = a[(size_t)t * kPoolC] - mean;
-        q += d * d;
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < kKeep; ++i) {
+            const float d = keep[i] - mean;
+            q += (wid + 4 * i < Tc) ? d * d : 0.f;
+        }
+    } else {
+        for (int t = wid; t < Tc; t += 4) {
+            const float d = a[(size_t)t * kPoolC] - mean;
+            q += d * d;
+        }
     }
     red[wid][lane] = q;
     __syncthreads();

@@ -8,6 +8,9 @@
 //   decision = argmax, rejected (-1) unless max > threshold                      iv_plda.py:182-194
 //   loss (attack/utils.py:7-102) and d loss/d scores, then the chain back to d loss/d fc1-output.
 // One block of 256 threads per utterance; reductions are wavefront shuffles + a 4-entry LDS pass.
+// The matrix-vector loops are unrolled 8-16x: with one block per utterance they are bound by the
+// latency of the (L2-resident) matrix loads, and un-unrolled they issued one dependent load at a
+// time (measured 157 us for the kernel).
 #include "sg_internal.h"
 
 namespace sg {
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     float n2 = 0.f;
     for (int d = tid; d < D; d += 256) {
         float acc = 0.f;
+#pragma unroll 16
         for (int i = 0; i < kEmb; ++i) acc += m.lda_t[(size_t)i * D + d] * e1[i];
         acc += m.lda_t[(size_t)kEmb * D + d];
         e2[d] = acc;
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     float qp = 0.f;
     for (int d = tid; d < D; d += 256) {
         float acc = 0.f;
+#pragma unroll 8
         for (int j = 0; j < D; ++j) acc += m.plda_pt[(size_t)j * D + d] * e2[j];
         e4[d] = acc;
         qp += acc * acc / (m.plda_psi[d] + 1.f);
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     // 11-12. P^T, length-norm ratio
     for (int j = tid; j < D; j += 256) {
         float acc = 0.f;
+#pragma unroll 8
         for (int d = 0; d < D; ++d) acc += m.plda_p[(size_t)d * D + j] * dv[d];
         e2[j] = acc * ratio;
     }
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     // 13. LDA^T -> d loss / d fc1 output
     for (int i = tid; i < kEmb; i += 256) {
         float acc = 0.f;
+#pragma unroll 8
         for (int d = 0; d < D; ++d) acc += m.lda[(size_t)d * (kEmb + 1) + i] * e2[d];
         demb[(size_t)b * kEmb + i] = acc;
     }

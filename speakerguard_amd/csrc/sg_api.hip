@@ -145,8 +145,8 @@ int build_tables(sg_ctx* ctx) {
     rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->range_scratch, 512);
-    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_slabs, (size_t)768 * 64 * 128);
-    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_flags, 768);
+    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_slabs, (size_t)512 * 128 * 128);  // >= 768 * 64 * 128
+    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_flags, 1024);
     if (rc) return SG_ERR_HIP;
     ctx->tables_ready = true;
     return SG_OK;
@@ -185,7 +185,7 @@ int ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
         rc |= dev_alloc(ctx, w.allocs, &w.act[l], rows * kCoutPad[l]);
         rc |= dev_alloc(ctx, w.allocs, &w.dact[l], rows * kCoutPad[l]);
     }
-    rc |= dev_alloc(ctx, w.allocs, &w.dfeats, b * cf * kFeatPad);
+    rc |= dev_alloc(ctx, w.allocs, &w.dfeats, (size_t)kL1BwdSplitK * b * cf * kFeatPad);
     rc |= dev_alloc(ctx, w.allocs, &w.dfeats_raw, b * cf * kCep);
     rc |= dev_alloc(ctx, w.allocs, &w.dframes, b * cf * kWin);
     rc |= dev_alloc(ctx, w.allocs, &w.stats, b * kStats);
@@ -306,7 +306,13 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.split_stride = 0;
         a.sk_slabs = ctx->sk_slabs;
         a.sk_flags = ctx->sk_flags;
-        SG_HIP(launch_conv_gemm(a, l == 0 ? 1 : 0, l == 0 ? EPI_NONE : EPI_RELU_MASK, 1, s));
+        int splits = 1;
+        if (l == 0) {  // 32 output columns: 148 tiles at B = 64 -- split K per tap to fill the chip
+            splits = kL1BwdSplitK;
+            a.chunks_per_split = a.total_chunks / kL1BwdSplitK;
+            a.split_stride = (long long)d.B * d.F * kFeatPad;
+        }
+        SG_HIP(launch_conv_gemm(a, l == 0 ? 1 : 0, l == 0 ? EPI_NONE : EPI_RELU_MASK, splits, s));
     }
     return SG_OK;
 }
@@ -343,11 +349,14 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
     int rc = run_tdnn_backward(ctx, d, s);
     if (rc) return rc;
     if (flag == SG_FLAG_CMVN) {
-        SG_HIP(launch_copy_cols(w.dfeats, kFeatPad, grad_out, kCep, (int64_t)d.B * d.F, kCep, s));
+        SG_HIP(launch_sum_cols(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep,
+                               (int64_t)d.B * d.F, kCep, s));
     } else if (flag == SG_FLAG_RAW) {
-        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, grad_out, kCep, d.B, d.F, s));
+        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep, d.B,
+                               d.F, s));
     } else {
-        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, w.dfeats_raw, kCep, d.B, d.F, s));
+        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, w.dfeats_raw, kCep,
+                               d.B, d.F, s));
         SG_HIP(launch_mfcc_bwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
         SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_out, x_update, lower, upper, step, grad_sign, s));
     }
@@ -660,7 +669,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
     hipStream_t s = (hipStream_t)stream;
     layer_frames(F, w.Fl);
     ConvGemmArgs a = fwd_layer_args(ctx, l, B, F);
-    int tile = 0, epi = EPI_BIAS_RELU;
+    int tile = 0, epi = EPI_BIAS_RELU, splits = 1;
     if (layer < 0) {  // data-gradient contraction of the same layer (reads d(out), writes d(in))
         a = ConvGemmArgs{};
         a.A = w.dact[l]; a.W = ctx->xv.wb[l]; a.C = l == 0 ? w.dfeats : w.dact[l - 1];
@@ -671,10 +680,15 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
         a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags;
         tile = l == 0 ? 1 : 0;
         epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;
+        if (l == 0) {
+            splits = kL1BwdSplitK;
+            a.chunks_per_split = a.total_chunks / kL1BwdSplitK;
+            a.split_stride = (long long)B * F * kFeatPad;
+        }
     }
-    SG_HIP(launch_conv_gemm(a, tile, epi, 1, s));  // warm
+    SG_HIP(launch_conv_gemm(a, tile, epi, splits, s));  // warm
     SG_HIP(hipEventRecord(ctx->ev0, s));
-    for (int i = 0; i < iters; ++i) SG_HIP(launch_conv_gemm(a, tile, epi, 1, s));
+    for (int i = 0; i < iters; ++i) SG_HIP(launch_conv_gemm(a, tile, epi, splits, s));
     SG_HIP(hipEventRecord(ctx->ev1, s));
     SG_HIP(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;

@@ -33,6 +33,7 @@ constexpr int kPoolC = 1536;           // padded tdnn5 channels
 constexpr int kStats = 2 * kPoolC;     // [mean | std], padded
 constexpr int kFc1SplitK = 24;         // fc1 forward split-K (3072 / 128)
 constexpr int kFc1BwdSplitK = 4;
+constexpr int kL1BwdSplitK = 5;        // tdnn1 data gradient: one K-slab per tap (N = 32 gives only 148 tiles)
 
 inline int num_frames(int T) { return (T + kShift / 2) / kShift; }
 
@@ -80,7 +81,7 @@ struct Workspace {
     float* feats = nullptr;            // [B][F][32] CMVN output, zero padded
     float* act[kLayers] = {};          // relu outputs [B][Fl][CoutPad]
     float* dact[kLayers] = {};         // d loss / d pre-activation [B][Fl][CoutPad]
-    float* dfeats = nullptr;           // [B][F][32]
+    float* dfeats = nullptr;           // [kL1BwdSplitK][B][F][32] split-K slabs of the tdnn1 data gradient
     float* dfeats_raw = nullptr;       // [B][F][30]
     float* dframes = nullptr;          // [B][F][400]
     float* stats = nullptr;            // [B][kStats]
@@ -152,8 +153,11 @@ hipError_t launch_pgd_update(float* x, const float* g, const float* lo, const fl
                              float step, int grad_sign, hipStream_t s);
 // out[r][0..ncol) = in[r][0..ncol), out[r][ncol..ld_out) = 0
 hipError_t launch_copy_cols(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int ncol, hipStream_t s);
+hipError_t launch_sum_cols(const float* in, int ld_in, int nsplit, long long slab_stride, float* out, int ld_out,
+                           int64_t rows, int ncol, hipStream_t s);
 hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, hipStream_t s);
-hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, float* din, int ld_din, int B, int F, hipStream_t s);
+hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long slab_stride, float* din, int ld_din,
+                           int B, int F, hipStream_t s);
 hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipStream_t s);
 hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit,
                            int B, int Tc, float* dact5, hipStream_t s);
