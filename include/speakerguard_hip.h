@@ -148,6 +148,38 @@ int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
 int sg_pgd_update(sg_ctx* ctx, float* x_dev, const float* grad_dev, const float* lower_dev,
                   const float* upper_dev, int64_t n, float step_size, int32_t grad_sign, void* stream);
 
+/* ---- attack-state updates around the model call (config 3: CW2, config 5: FAKEBOB/NES) -------
+ * attack/CW2.py:72-82.  One pass over (B,T): if grad1 != NULL, the Adam update (torch.optim.Adam
+ * defaults, step_t = 1-based step count) of `modifier` from grad1 = d loss1/d input_cur, where the full
+ * objective is const[b]*loss1 + ||input_cur - x||^2 and input = tanh(modifier + atanh(0.999999 x));
+ * then input_next = tanh(modifier + atanh(0.999999 x)) and loss2[b] = sum_t (input_next - x)^2.
+ * Call with grad1 == NULL to produce the first input from a fresh modifier. */
+int sg_cw2_step(sg_ctx* ctx, float* modifier_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                const float* x_dev, const float* input_cur_dev, const float* grad1_dev,
+                const float* const_dev, int32_t B, int32_t T, float lr, int32_t step_t,
+                float* input_next_dev, float* loss2_dev, void* stream);
+
+/* adaptive_attack/NES.py:19-25: queries (n, 2*half + with_clean, T) = [x] , x + sigma z_p , x - sigma z_p.
+ * z_p comes from noise_in (n, half, T) when given, else from a counter-based generator keyed by
+ * (seed, example index + index_base, pair_base + p, t) -- the same noise is regenerated by
+ * sg_nes_grad, so it is never stored.  noise_out (optional) receives the draws (parity tests). */
+int sg_nes_queries(sg_ctx* ctx, const float* x_dev, int32_t n, int32_t T, int32_t half, int32_t with_clean,
+                   float sigma, uint64_t seed, int64_t index_base, int32_t pair_base,
+                   const float* noise_in_dev, float* queries_dev, float* noise_out_dev, void* stream);
+
+/* adaptive_attack/NES.py:47,52,54: grad (n,T) (+)= mean over the 2*half noisy queries of loss * noise;
+ * loss (n, 2*half + with_clean) in query order.  On the last chunk pass final_sigma = sigma (> 0) and
+ * final_batches = number of chunks to apply NES.py:54's grad / sigma / num_batches. */
+int sg_nes_grad(sg_ctx* ctx, const float* loss_dev, int32_t n, int32_t T, int32_t half, int32_t with_clean,
+                uint64_t seed, int64_t index_base, int32_t pair_base, const float* noise_in_dev,
+                int32_t accumulate, float final_sigma, int32_t final_batches, float* grad_dev, void* stream);
+
+/* attack/FAKEBOB.py:93-104: grad <- momentum*prev + one_minus_momentum*grad (in place);
+ * x <- min(max(x + grad_sign*lr[e]*sign(grad), lower), upper).  lr (n) per example. */
+int sg_fakebob_step(sg_ctx* ctx, float* x_dev, float* grad_dev, const float* prev_grad_dev,
+                    const float* lr_dev, const float* lower_dev, const float* upper_dev, int32_t n, int32_t T,
+                    float momentum, float one_minus_momentum, int32_t grad_sign, void* stream);
+
 /* ---- fused attack loop ----------------------------------------------------------------------
  * attack/FGSM.py:38-70 attack_batch for the xv_plda model: max_iter gradient steps plus the final
  * forward-only pass, entirely on the device (FGSM = max_iter 1, step_size epsilon). */

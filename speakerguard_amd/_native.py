@@ -19,6 +19,7 @@ EXPORTS = (
     "sg_version", "sg_create", "sg_destroy", "sg_last_error", "sg_sync", "sg_xv_load", "sg_xv_set_enroll",
     "sg_xv_num_frames", "sg_input_scale", "sg_xv_mfcc", "sg_xv_cmvn", "sg_xv_forward", "sg_xv_debug_activation",
     "sg_xv_loss_grad", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
+    "sg_cw2_step", "sg_nes_queries", "sg_nes_grad", "sg_fakebob_step",
 )
 
 
@@ -82,6 +83,10 @@ def load():
                                       vp, vp, vp, vp, vp]),
         "sg_pgd_update": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, i32, vp]),
         "sg_xv_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
+        "sg_cw2_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]),
+        "sg_nes_queries": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i64, i32, vp, vp, vp, vp]),
+        "sg_nes_grad": (C.c_int, [vp, vp, i32, i32, i32, i32, C.c_uint64, i64, i32, vp, i32, f32, i32, vp, vp]),
+        "sg_fakebob_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp]),
         "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32), vp]),
     }
     for name, (res, args) in sig.items():

@@ -2,7 +2,7 @@
 
 Per iteration (CW2.py:67-111): input_x = tanh(modifier + atanh(0.999999 x)); margin loss with
 clip and d loss1 / d input_x from one native ``model.loss_grad`` call; the chain through tanh, the
-L2 term and torch.optim.Adam's update are applied to the modifier on the device.  The
+L2 term, torch.optim.Adam's update and the next input_x are one more native pass (``cw2_step``).  The
 per-example bookkeeping (best_l2 / best_score / global best, CW2.py:102-111) is kept on the
 device as masks, so the host only synchronises for the early-stop test every
 ``stop_early_iter`` iterations (the reference synchronises every iteration).
@@ -56,33 +56,27 @@ class CW2(FGSM):
         global_best_l2 = inf.clone()
         global_best_adver_x = x_batch.clone()
         global_best_score = torch.full((n_audios,), -2, dtype=torch.int64, device=dev)  # -2: never succeeded (CW2.py:52)
-        x_atanh = torch.atanh(x_batch * 0.999999)
-        b1, b2, eps = 0.9, 0.999, 1e-8  # torch.optim.Adam defaults (CW2.py:57)
+        base = getattr(self.model, 'base_model', self.model)
+        x_batch = x_batch.contiguous()
 
         for _ in range(self.binary_search_steps):
-            modifier = torch.zeros_like(x_batch)
+            modifier = torch.zeros_like(x_batch)      # fresh modifier + Adam state per search step (CW2.py:56-57)
             exp_avg = torch.zeros_like(x_batch)
             exp_avg_sq = torch.zeros_like(x_batch)
             best_l2 = inf.clone()
             best_score = torch.full((n_audios,), -2, dtype=torch.int64, device=dev)
             continue_flag = True
             prev_loss = np.inf
+            input_x, loss2 = base.cw2_step(modifier, None, None, x_batch, None, None, const, self.lr, 0)
             for n_iter in range(self.max_iter + 1):
                 if not continue_flag:
                     break
-                input_x = torch.tanh(modifier + x_atanh)
                 want_grad = n_iter < self.max_iter
                 decisions, scores, loss1, g1 = self.model.loss_grad(input_x, y_batch, self.loss, want_grad=want_grad)
-                diff = input_x - x_batch
-                loss2 = torch.sum(torch.square(diff), dim=(1, 2))
                 loss = const * loss1 + loss2
-                if want_grad:
-                    g = (const.view(-1, 1, 1) * g1 + 2.0 * diff) * (1.0 - input_x * input_x)
-                    t = n_iter + 1
-                    exp_avg.mul_(b1).add_(g, alpha=1 - b1)
-                    exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
-                    denom = (exp_avg_sq.sqrt() / np.sqrt(1 - b2 ** t)).add_(eps)
-                    modifier.addcdiv_(exp_avg, denom, value=-self.lr / (1 - b1 ** t))
+                if want_grad:  # chain through tanh + L2 term + Adam, and the next input, in one native pass
+                    input_next, loss2_next = base.cw2_step(modifier, exp_avg, exp_avg_sq, x_batch, input_x, g1, const,
+                                                           self.lr, n_iter + 1)
                 if self.verbose:
                     print("batch: {}, c: {}, iter: {}, loss: {}, loss1: {}, loss2: {}, y_pred: {}, y: {}".format(
                         batch_id, const.cpu().numpy(), n_iter, loss.cpu().numpy().tolist(), loss1.cpu().numpy().tolist(),
@@ -101,6 +95,8 @@ class CW2(FGSM):
                 global_best_l2 = torch.where(c2, loss2, global_best_l2)
                 global_best_score = torch.where(c2, decisions, global_best_score)
                 global_best_adver_x = torch.where(c2.view(-1, 1, 1), input_x, global_best_adver_x)
+                if want_grad:
+                    input_x, loss2 = input_next, loss2_next
 
             # binary search on const (CW2.py:113-123)
             succeeded = best_score != -2

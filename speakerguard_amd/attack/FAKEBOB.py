@@ -28,8 +28,9 @@ class FAKEBOB(Attack):
                  samples_per_draw=50, samples_per_draw_batch_size=50, sigma=0.001, momentum=0.9,
                  plateau_length=5, plateau_drop=2.,
                  stop_early=True, stop_early_iter=100,
-                 batch_size=1, EOT_size=1, EOT_batch_size=1, verbose=1):
+                 batch_size=1, EOT_size=1, EOT_batch_size=1, verbose=1, noise_fn=None):
         self.model = model
+        self.noise_fn = noise_fn  # optional explicit NES noise source (tests); default: engine generator
         self.threshold = threshold
         self.task = task
         self.targeted = targeted
@@ -61,7 +62,8 @@ class FAKEBOB(Attack):
         return [t.index_select(0, idx) for t in tensors], [[l[i] for i in keep] for l in lists]
 
     def get_grad(self, x, y):
-        NES_wrapper = NES(self.samples_per_draw, self.samples_per_draw_batch_size, self.sigma, self.EOT_wrapper)
+        NES_wrapper = NES(self.samples_per_draw, self.samples_per_draw_batch_size, self.sigma, self.EOT_wrapper,
+                          noise_fn=self.noise_fn)
         return NES_wrapper(x, y)
 
     def attack_batch(self, x_batch, y_batch, lower, upper, batch_id):
@@ -76,6 +78,7 @@ class FAKEBOB(Attack):
         consider_index = list(range(n_audios))
         lower = lower.expand_as(x_batch)
         upper = upper.expand_as(x_batch)
+        base = getattr(self.model, 'base_model', self.model)
 
         for it in range(self.max_iter + 1):
             prev_grad = grad.clone()
@@ -98,7 +101,6 @@ class FAKEBOB(Attack):
             consider_index, last_ls, lr, prev_loss, loss_h = ls
 
             if it < self.max_iter:
-                grad = self.momentum * prev_grad + (1.0 - self.momentum) * grad
                 for jj, loss_ in enumerate(loss_h):
                     last_ls[jj].append(loss_)
                     last_ls[jj] = last_ls[jj][-self.plateau_length:]
@@ -106,9 +108,11 @@ class FAKEBOB(Attack):
                         if lr[jj] > self.min_lr:
                             lr[jj] = max(lr[jj] / self.plateau_drop, self.min_lr)
                         last_ls[jj] = []
-                lr_t = torch.tensor(lr, device=adver_x.device, dtype=torch.float).unsqueeze(1).unsqueeze(2)
-                adver_x = adver_x + self.grad_sign * lr_t * torch.sign(grad)
-                adver_x = torch.min(torch.max(adver_x, lower), upper)
+                lr_t = torch.tensor(lr, device=adver_x.device, dtype=torch.float)
+                # momentum mix (:93) + per-example sign step (:103) + epsilon-ball clamp (:104): one native pass
+                adver_x, grad = adver_x.contiguous(), grad.contiguous()
+                base.fakebob_step(adver_x, grad, prev_grad.contiguous(), lr_t, lower.contiguous(), upper.contiguous(),
+                                  self.momentum, self.grad_sign)
 
                 if self.stop_early and it % self.stop_early_iter == 0:
                     loss_np = np.array(loss_h)

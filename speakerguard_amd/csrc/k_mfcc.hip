@@ -38,6 +38,16 @@ struct FrameLds {
     float tmp[32];
 };
 
+// Every LDS buffer in this file is private to one wave, and a wave's DS instructions execute in
+// program order, so cross-lane hand-offs through LDS need no s_barrier -- only a fence that stops
+// the compiler from moving LDS accesses across it (a block-wide __syncthreads() here coupled the
+// four independent waves at ~25 points per frame).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -70,7 +80,7 @@ __device__ __forceinline__ float dither_draw(uint64_t seed, int64_t utt, int fra
 }
 
 // In-place radix-2 FFTs of 512 complex fp64 points held in LDS.  All four waves of the block run
-// them in lockstep on their own buffers (barrier per stage).
+// them on its own buffer (wave-level sync per stage).
 // Forward: decimation in time, input scattered in bit-reversed order, output in natural order.
 __device__ __forceinline__ void fft512_dit(double2* buf, const double2* __restrict__ tw, int lane) {
 #pragma unroll 1
@@ -89,7 +99,7 @@ __device__ __forceinline__ void fft512_dit(double2* buf, const double2* __restri
             buf[i0] = make_double2(a.x + tr, a.y + ti);
             buf[i1] = make_double2(a.x - tr, a.y - ti);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -111,7 +121,7 @@ __device__ __forceinline__ void ifft512_dif(double2* buf, const double2* __restr
             buf[i0] = make_double2(a.x + b.x, a.y + b.y);
             buf[i1] = make_double2(dx * w.x + dy * w.y, dy * w.x - dx * w.y);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -152,7 +162,7 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, 
         }
     }
     st.energy = wave_sum(e);
-    __syncthreads();
+    wave_sync();
     // pre-emphasis (replicate pad on the left), povey window, bit-reversed scatter into the FFT buffer
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -164,7 +174,7 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, 
         }
         L.spec[t.bitrev[n]] = make_double2((double)w, 0.0);
     }
-    __syncthreads();
+    wave_sync();
     fft512_dit(L.spec, t.twiddle, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -172,7 +182,7 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, 
         const double2 c = L.spec[k];
         L.power[k] = (float)(c.x * c.x + c.y * c.y);
     }
-    __syncthreads();
+    wave_sync();
     if (lane < kMel) {
         float acc = 0.f;
         const int lo = t.mel_lo[lane], hi = t.mel_hi[lane];
@@ -180,7 +190,7 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, 
         L.mel[lane] = acc;
         L.lmel[lane] = logf(fmaxf(acc, kEps));
     }
-    __syncthreads();
+    wave_sync();
     cep_out = 0.f;
     if (lane < kCep) {
         float v = 0.f;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
         float cep;
         frame_forward(t, L, x, T, F, b, active ? f : 0, active, scale, dz, lane, st, cep);
         if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
         if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];
         const float denergy = __shfl(dc, 0, 64);
         if (lane < 32) L.tmp[lane] = (lane == 0 || lane >= kCep) ? 0.f : dc * t.lifter[lane];
-        __syncthreads();
+        wave_sync();
         if (lane < 32) {
             float dm = 0.f;
             if (lane < kMel) {
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             }
             L.lmel[lane] = dm;  // d loss / d mel energy (entries 30,31 = 0)
         }
-        __syncthreads();
+        wave_sync();
         // ---- mel -> power -> spectrum gradient G[k] = 2 X[k] dP[k], in place, bins 256..511 zero
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             }
             L.spec[k] = g;
         }
-        __syncthreads();
+        wave_sync();
         ifft512_dif(L.spec, t.twiddle, lane);
         // ---- window, pre-emphasis, energy, DC removal
 #pragma unroll
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             const int n = lane + 64 * i;
             if (n < kWin) L.samp[n] = (float)L.spec[t.bitrev[n]].x * t.window[n];
         }
-        __syncthreads();
+        wave_sync();
         float ds[7];
         float sum = 0.f;
         const float einv = st.energy > kEps ? 2.f * denergy / st.energy : 0.f;
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
                 if (n < kWin) dframes[((size_t)b * F + f) * kWin + n] = (ds[i] - mean) * scale;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

@@ -210,17 +210,24 @@ __global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__
     float* y = din + (size_t)b * F * ld_din;
     auto gsum = [&](int t, int d) {
         float v = 0.f;
+#pragma unroll 5
         for (int z = 0; z < nsplit; ++z) v += g[(size_t)z * slab_stride + (size_t)t * ld_dout + d];
         return v;
     };
     __shared__ double total[kCep];
     __shared__ double part[8][32];
+    __shared__ float stage[kCmnWindow * kCep];  // summed slabs of one utterance (<= 300 frames)
     if (F <= kCmnWindow) {
+        for (int i = threadIdx.x; i < F * kCep; i += 256) {
+            const int t = i / kCep, d = i - t * kCep;
+            stage[i] = gsum(t, d);
+        }
+        __syncthreads();
         {
             const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
             double acc = 0.0;
             if (d < kCep)
-                for (int t = r; t < F; t += 8) acc += (double)gsum(t, d);
+                for (int t = r; t < F; t += 8) acc += (double)stage[t * kCep + d];
             part[r][d] = acc;
         }
         __syncthreads();
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__
         __syncthreads();
         for (int i = threadIdx.x; i < F * kCep; i += 256) {
             const int t = i / kCep, d = i - t * kCep;
-            y[(size_t)t * ld_din + d] = gsum(t, d) - (float)total[d];
+            y[(size_t)t * ld_din + d] = stage[i] - (float)total[d];
         }
     } else {
         for (int i = threadIdx.x; i < F * kCep; i += 256) {

@@ -145,6 +145,7 @@ int build_tables(sg_ctx* ctx) {
     rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->range_scratch, 512);
+    rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->cw2_scratch, 1024 * 32);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_slabs, (size_t)512 * 128 * 128);  // >= 768 * 64 * 128
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_flags, 1024);
     if (rc) return SG_ERR_HIP;
@@ -610,6 +611,48 @@ int sg_pgd_update(sg_ctx* ctx, float* x_dev, const float* grad_dev, const float*
                   int64_t n, float step_size, int32_t grad_sign, void* stream) {
     if (!ctx || !x_dev || !grad_dev || !lower_dev || !upper_dev || n < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
     SG_HIP(launch_pgd_update(x_dev, grad_dev, lower_dev, upper_dev, n, step_size, grad_sign, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_cw2_step(sg_ctx* ctx, float* modifier_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* x_dev,
+                const float* input_cur_dev, const float* grad1_dev, const float* const_dev, int32_t B, int32_t T, float lr,
+                int32_t step_t, float* input_next_dev, float* loss2_dev, void* stream) {
+    if (!ctx || !modifier_dev || !x_dev || !input_next_dev || !loss2_dev || B < 1 || B > 1024 || T < 1)
+        return fail(ctx, SG_ERR_ARG, "bad argument");
+    if (grad1_dev && (!exp_avg_dev || !exp_avg_sq_dev || !input_cur_dev || !const_dev || step_t < 1))
+        return fail(ctx, SG_ERR_ARG, "an update needs the Adam state, the current input, const and step >= 1");
+    int rc = build_tables(ctx);
+    if (rc) return rc;
+    SG_HIP(launch_cw2_step(modifier_dev, exp_avg_dev, exp_avg_sq_dev, x_dev, input_cur_dev, grad1_dev, const_dev, B, T, lr,
+                           step_t, input_next_dev, loss2_dev, ctx->cw2_scratch, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_nes_queries(sg_ctx* ctx, const float* x_dev, int32_t n, int32_t T, int32_t half, int32_t with_clean, float sigma,
+                   uint64_t seed, int64_t index_base, int32_t pair_base, const float* noise_in_dev, float* queries_dev,
+                   float* noise_out_dev, void* stream) {
+    if (!ctx || !x_dev || !queries_dev || n < 1 || T < 1 || half < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_nes_queries(x_dev, n, T, half, with_clean != 0, sigma, seed, index_base, pair_base, noise_in_dev,
+                              queries_dev, noise_out_dev, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_nes_grad(sg_ctx* ctx, const float* loss_dev, int32_t n, int32_t T, int32_t half, int32_t with_clean, uint64_t seed,
+                int64_t index_base, int32_t pair_base, const float* noise_in_dev, int32_t accumulate, float final_sigma,
+                int32_t final_batches, float* grad_dev, void* stream) {
+    if (!ctx || !loss_dev || !grad_dev || n < 1 || T < 1 || half < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_nes_grad(loss_dev, n, T, half, with_clean != 0, seed, index_base, pair_base, noise_in_dev, accumulate,
+                           final_sigma, final_batches > 0 ? final_batches : 1, grad_dev, (hipStream_t)stream));
+    return SG_OK;
+}
+
+int sg_fakebob_step(sg_ctx* ctx, float* x_dev, float* grad_dev, const float* prev_grad_dev, const float* lr_dev,
+                    const float* lower_dev, const float* upper_dev, int32_t n, int32_t T, float momentum,
+                    float one_minus_momentum, int32_t grad_sign, void* stream) {
+    if (!ctx || !x_dev || !grad_dev || !prev_grad_dev || !lr_dev || !lower_dev || !upper_dev || n < 1 || T < 1)
+        return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_fakebob_step(x_dev, grad_dev, prev_grad_dev, lr_dev, lower_dev, upper_dev, n, T, momentum,
+                               one_minus_momentum, grad_sign, (hipStream_t)stream));
     return SG_OK;
 }
 

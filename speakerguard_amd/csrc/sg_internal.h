@@ -105,6 +105,7 @@ struct sg_ctx {
     sg::MfccTables tab{};
     bool tables_ready = false;
     float* range_scratch = nullptr;  // [512] partial max/min of check_input_range
+    float* cw2_scratch = nullptr;    // [1024][32] loss2 partials
     float* sk_slabs = nullptr;       // stream-K scratch (k_conv_gemm.hip)
     unsigned* sk_flags = nullptr;
     sg::XvModel xv;
@@ -161,6 +162,19 @@ hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long
 hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipStream_t s);
 hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit,
                            int B, int Tc, float* dact5, hipStream_t s);
+
+hipError_t launch_cw2_step(float* modifier, float* exp_avg, float* exp_avg_sq, const float* x, const float* input_cur,
+                           const float* grad1, const float* const_c, int B, int T, float lr, int step_t,
+                           float* input_next, float* loss2, float* scratch, hipStream_t s);
+hipError_t launch_nes_queries(const float* x, int n, int T, int half, int with_clean, float sigma, uint64_t seed,
+                              int64_t index_base, int pair_base, const float* noise_in, float* queries, float* noise_out,
+                              hipStream_t s);
+hipError_t launch_nes_grad(const float* loss, int n, int T, int half, int with_clean, uint64_t seed, int64_t index_base,
+                           int pair_base, const float* noise_in, int accumulate, float final_sigma, int final_batches,
+                           float* grad, hipStream_t s);
+hipError_t launch_fakebob_step(float* x, float* grad, const float* prev_grad, const float* lr, const float* lower,
+                               const float* upper, int n, int T, float momentum, float one_m_momentum, int grad_sign,
+                               hipStream_t s);
 
 struct TailArgs {
     const float* fc1_part; int nsplit; int B;

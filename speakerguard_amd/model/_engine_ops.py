@@ -1,0 +1,55 @@
+"""Native attack-state updates shared by every engine-backed model (C-ABI: sg_pgd_update, sg_cw2_step,
+sg_nes_queries, sg_nes_grad, sg_fakebob_step).  The attack classes call these through the model so
+that the only implementation in the product is the HIP one (tests substitute a CPU double)."""
+import ctypes as C
+
+import torch
+
+from .. import _native as N
+
+
+class EngineOps:
+    """Mixin: expects ``self.ctx`` (N.Context) and ``self.device``."""
+
+    def _stream(self):
+        return N.current_stream_ptr(self.device)
+
+    def pgd_update(self, x, grad, lower, upper, step_size, grad_sign):
+        """x <- min(max(x + step*sign(grad)*grad_sign, lower), upper) in place (attack/FGSM.py:65,68)."""
+        self.ctx.call("sg_pgd_update", N._ptr(x), N._ptr(grad), N._ptr(lower), N._ptr(upper), x.numel(),
+                      float(step_size), int(grad_sign), self._stream())
+        return x
+
+    def cw2_step(self, modifier, exp_avg, exp_avg_sq, x, input_cur, grad1, const, lr, step_t):
+        """attack/CW2.py:72-82.  Updates modifier/Adam state in place when grad1 is given; returns the
+        next (input_x, loss2)."""
+        B, _, T = x.shape
+        input_next = torch.empty_like(x)
+        loss2 = torch.empty(B, device=x.device, dtype=torch.float32)
+        self.ctx.call("sg_cw2_step", N._ptr(modifier), N._ptr(exp_avg), N._ptr(exp_avg_sq), N._ptr(x), N._ptr(input_cur),
+                      N._ptr(grad1), N._ptr(const), B, T, float(lr), int(step_t), N._ptr(input_next), N._ptr(loss2),
+                      self._stream())
+        return input_next, loss2
+
+    def nes_queries(self, x, half, with_clean, sigma, seed, pair_base, noise_in=None, want_noise=False):
+        """adaptive_attack/NES.py:19-25 -> queries (n*(2*half+with_clean), 1, T) [, noise (n, half, 1, T)]."""
+        n, _, T = x.shape
+        Q = 2 * half + int(with_clean)
+        queries = torch.empty(n * Q, 1, T, device=x.device, dtype=torch.float32)
+        noise = torch.empty(n, half, 1, T, device=x.device, dtype=torch.float32) if want_noise else None
+        self.ctx.call("sg_nes_queries", N._ptr(x), n, T, half, int(with_clean), float(sigma), C.c_uint64(seed), 0,
+                      int(pair_base), N._ptr(noise_in), N._ptr(queries), N._ptr(noise), self._stream())
+        return queries, noise
+
+    def nes_grad(self, loss, grad, n, T, half, with_clean, seed, pair_base, noise_in, accumulate, final_sigma, final_batches):
+        """adaptive_attack/NES.py:47-54; accumulates into `grad` (n,1,T)."""
+        self.ctx.call("sg_nes_grad", N._ptr(loss), n, T, half, int(with_clean), C.c_uint64(seed), 0, int(pair_base),
+                      N._ptr(noise_in), int(accumulate), float(final_sigma), int(final_batches), N._ptr(grad), self._stream())
+        return grad
+
+    def fakebob_step(self, x, grad, prev_grad, lr, lower, upper, momentum, grad_sign):
+        """attack/FAKEBOB.py:93-104; grad and x are updated in place."""
+        n, _, T = x.shape
+        self.ctx.call("sg_fakebob_step", N._ptr(x), N._ptr(grad), N._ptr(prev_grad), N._ptr(lr), N._ptr(lower), N._ptr(upper),
+                      n, T, float(momentum), float(1.0 - momentum), int(grad_sign), self._stream())
+        return x, grad

@@ -110,3 +110,15 @@ class defended_model:
 
     def pgd_update(self, *a, **k):
         return self.base_model.pgd_update(*a, **k)
+
+    def cw2_step(self, *a, **k):
+        return self.base_model.cw2_step(*a, **k)
+
+    def nes_queries(self, *a, **k):
+        return self.base_model.nes_queries(*a, **k)
+
+    def nes_grad(self, *a, **k):
+        return self.base_model.nes_grad(*a, **k)
+
+    def fakebob_step(self, *a, **k):
+        return self.base_model.fakebob_step(*a, **k)

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from ._engine_ops import EngineOps
 
 BITS = 16
 _TDNN = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5")
@@ -76,7 +77,7 @@ def _f32(a):
     return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
 
 
-class xv_plda:
+class xv_plda(EngineOps):
     allowed_flags = [0, 1, 2]  # 0: wav; 1: raw feat; 2: cmvn feat (xv_plda.py:45-47)
     range_type = "origin"
 
@@ -157,9 +158,6 @@ class xv_plda:
         if torch.device(device) != self.device and torch.device(device).index not in (None, self.device.index):
             raise N.NativeError("the engine context is bound to %s" % self.device)
         return self
-
-    def _stream(self):
-        return N.current_stream_ptr(self.device)
 
     def _dither(self, noise=None):
         d = N.Dither()
@@ -307,12 +305,6 @@ class xv_plda:
                       N._ptr(success), N._ptr(dec), N._ptr(scores), N._ptr(loss), N._ptr(ltr), N._ptr(dtr),
                       self._stream())
         return x_adv, success, dec, scores, loss, ltr, dtr
-
-    def pgd_update(self, x, grad, lower, upper, step_size, grad_sign):
-        """x <- min(max(x + step*sign(grad)*grad_sign, lower), upper) in place (FGSM.py:65,68)."""
-        self.ctx.call("sg_pgd_update", N._ptr(x), N._ptr(grad), N._ptr(lower), N._ptr(upper), x.numel(),
-                      float(step_size), int(grad_sign), self._stream())
-        return x
 
     def time_layer(self, layer, B, T, iters=20):
         ms, fl, rows = C.c_float(), C.c_double(), C.c_int32()

@@ -47,3 +47,40 @@ class AutogradEngine:
         x += step_size * torch.sign(grad) * grad_sign
         x.copy_(torch.min(torch.max(x, lower), upper))
         return x
+
+    # ---- attack-state updates: plain torch restatements of the reference lines (CPU double only)
+    def cw2_step(self, modifier, exp_avg, exp_avg_sq, x, input_cur, grad1, const, lr, step_t):
+        if grad1 is not None:  # CW2.py:75-82 + torch.optim.Adam single-tensor update
+            g = (const.view(-1, 1, 1) * grad1 + 2.0 * (input_cur - x)) * (1.0 - input_cur * input_cur)
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            exp_avg.lerp_(g, 1 - b1)
+            exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (exp_avg_sq.sqrt() / (1 - b2 ** step_t) ** 0.5).add_(eps)
+            modifier.addcdiv_(exp_avg, denom, value=-lr / (1 - b1 ** step_t))
+        nxt = torch.tanh(modifier + torch.atanh(x * 0.999999))
+        return nxt, torch.sum(torch.square(nxt - x), dim=(1, 2))
+
+    def nes_queries(self, x, half, with_clean, sigma, seed, pair_base, noise_in=None, want_noise=False):
+        assert noise_in is not None, "the CPU double has no counter-based generator: pass noise_fn"
+        noise = torch.cat((noise_in, -noise_in), 1)
+        if with_clean:
+            noise = torch.cat((torch.zeros_like(x).unsqueeze(1), noise), 1)
+        q = (noise * sigma + x.unsqueeze(1)).view(-1, x.shape[1], x.shape[2])
+        return q, (noise_in if want_noise else None)
+
+    def nes_grad(self, loss, grad, n, T, half, with_clean, seed, pair_base, noise_in, accumulate, final_sigma, final_batches):
+        l = loss[:, 1:] if with_clean else loss
+        noise = torch.cat((noise_in, -noise_in), 1)
+        g = torch.mean(l.unsqueeze(2).unsqueeze(3) * noise, 1)
+        if accumulate:
+            g = grad + g
+        if final_sigma > 0:
+            g = g / final_sigma / final_batches
+        grad.copy_(g)
+        return grad
+
+    def fakebob_step(self, x, grad, prev_grad, lr, lower, upper, momentum, grad_sign):
+        g = momentum * prev_grad + (1.0 - momentum) * grad
+        grad.copy_(g)
+        x.copy_(torch.min(torch.max(x + grad_sign * lr.view(-1, 1, 1) * torch.sign(g), lower), upper))
+        return x, grad

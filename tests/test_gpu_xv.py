@@ -450,3 +450,143 @@ def test_gradient_is_a_descent_direction_at_full_size(hip_model, dev):
     log("directional derivative / predicted over 64 utterances: min %.3f median %.3f max %.3f"
         % (ratio.min(), np.median(ratio), ratio.max()))
     assert np.all(ratio > 0.7) and np.all(ratio < 1.3)
+
+
+# ------------------------------------------------------------------------------ CW2 / FAKEBOB on the engine
+def test_cw2_matches_oracle(hip_model, oracle_model, dev, capsys):
+    """attack/CW2.py loop (tanh box, margin loss with clip, Adam, binary search) driven by the engine
+    vs the same loop driven by the oracle's autograd.  Adam divides by sqrt(v): a gradient entry that
+    differs in the last bits moves the modifier by the same relative amount only, so the tolerance is a
+    plain allclose on the adversarial audio."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.CW2 import CW2
+    x = torch.from_numpy(synth.make_waveforms(2, 16000, seed=31))
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    kw = dict(task="CSI", initial_const=1e-2, binary_search_steps=2, max_iter=6, stop_early=True, stop_early_iter=3,
+              lr=2e-3, batch_size=2)
+    oadv, osucc = oatk.CW2(oracle_model, **kw).attack(x.clone(), y)
+    adv, succ = CW2(hip_model, verbose=0, **kw).attack(x.to(dev), y.to(dev))
+    diff = (adv.cpu() - oadv).abs().max().item()
+    log("CW2 (2 search steps x 6 iters): max |x_adv - oracle| = %.3e, success hip=%s oracle=%s" % (diff, succ, osucc))
+    assert succ == osucc
+    # Adam's first update is lr * g / (|g| + eps) ~ lr * sign(g): an entry whose gradient is round-off
+    # noise moves by +-lr on either side, so a handful of samples may differ by up to 2 * lr per step.
+    d = (adv.cpu() - oadv).abs().numpy()
+    assert (d > 2e-4).mean() < 1e-3 and d.max() <= 2 * 2e-3 * 6 + 1e-6
+
+
+def test_fakebob_matches_oracle_with_shared_noise(hip_model, oracle_model, dev):
+    """FAKEBOB / NES (forward-only queries): both sides draw the NES noise from the same seeded CPU
+    generator so the trajectories are comparable."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    x = torch.from_numpy(synth.make_waveforms(2, 16000, seed=32))
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    kw = dict(task="CSI", epsilon=0.002, max_iter=4, max_lr=0.0005, min_lr=1e-6, samples_per_draw=8,
+              samples_per_draw_batch_size=4, sigma=0.001, stop_early=True, stop_early_iter=2, batch_size=1)
+    g = torch.Generator().manual_seed(5)
+    oadv, osucc = oatk.FAKEBOB(oracle_model, noise_fn=lambda shape: torch.randn(shape, generator=g), **kw).attack(x.clone(), y)
+    g2 = torch.Generator().manual_seed(5)
+    adv, succ = FAKEBOB(hip_model, verbose=0, noise_fn=lambda shape: torch.randn(shape, generator=g2), **kw).attack(
+        x.to(dev), y.to(dev))
+    diff = (adv.cpu() - oadv).abs()
+    frac = float((diff > 1e-7).float().mean())
+    log("FAKEBOB-4: samples differing %.3f%%, success hip=%s oracle=%s" % (100 * frac, succ, osucc))
+    assert succ == osucc
+    assert frac < 0.05 and diff.max().item() <= 2 * 0.002 + 1e-6
+
+
+def test_defended_model_passthrough_and_sharded_wrapper(hip_model, dev):
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.defended_model import defended_model
+    from speakerguard_amd.shard import ShardedAttack
+    x = torch.from_numpy(synth.make_waveforms(3, 16000, seed=33)).to(dev)
+    dm = defended_model(hip_model)
+    d0, s0 = hip_model.make_decision(x)
+    d1, s1 = dm.make_decision(x)
+    assert torch.equal(d0, d1) and torch.equal(s0, s1)
+    a = PGD(hip_model, max_iter=3, batch_size=3, verbose=0).attack(x, d0)
+    b = PGD(dm, max_iter=3, batch_size=3, verbose=0).attack(x, d0)
+    c = ShardedAttack(PGD(hip_model, max_iter=3, batch_size=3, verbose=0)).attack(x, d0)  # world size 1
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    assert torch.equal(a[0], c[0]) and a[1] == c[1]
+    lam = lambda t: t * 1.0
+    with pytest.raises(NotImplementedError):
+        PGD(defended_model(hip_model, defense=[(0, lam)]), max_iter=1, verbose=0).attack(x, d0)
+
+
+# ------------------------------------------------------------------------------ native attack-state kernels
+def test_cw2_step_kernel_matches_torch_adam(hip_model, dev):
+    """sg_cw2_step vs torch.tanh/atanh + torch.optim.Adam on the same numbers (CW2.py:72-82)."""
+    g = torch.Generator().manual_seed(2)
+    B, T = 3, 16000
+    x = (torch.rand(B, 1, T, generator=g) * 1.9 - 0.95).to(dev)
+    const = torch.tensor([1e-3, 0.5, 20.0], device=dev)
+    modifier = torch.zeros_like(x)
+    m, v = torch.zeros_like(x), torch.zeros_like(x)
+    ref_mod = torch.zeros_like(x, requires_grad=True)
+    opt = torch.optim.Adam([ref_mod], lr=1e-2)
+    inp, l2 = hip_model.cw2_step(modifier, None, None, x, None, None, const, 1e-2, 0)
+    ref_inp = torch.tanh(ref_mod + torch.atanh(x * 0.999999))
+    np.testing.assert_allclose(inp.cpu().numpy(), ref_inp.detach().cpu().numpy(), rtol=0, atol=2e-7)
+    for t in range(1, 4):
+        g1 = torch.randn(B, 1, T, generator=g).to(dev) * 1e-3
+        ref_inp = torch.tanh(ref_mod + torch.atanh(x * 0.999999))
+        (const * (ref_inp * g1).sum((1, 2)) + ((ref_inp - x) ** 2).sum((1, 2))).sum().backward()
+        opt.step()
+        opt.zero_grad()
+        inp, l2 = hip_model.cw2_step(modifier, m, v, x, inp, g1, const, 1e-2, t)
+        want = torch.tanh(ref_mod + torch.atanh(x * 0.999999)).detach()
+        err = (inp - want).abs().max().item()
+        assert err < 5e-6, (t, err)
+        np.testing.assert_allclose(l2.cpu().numpy(), ((want - x) ** 2).sum((1, 2)).cpu().numpy(), rtol=2e-5)
+    log("cw2_step vs torch Adam after 3 steps: max |input diff| %.2e" % err)
+
+
+def test_nes_and_fakebob_kernels(hip_model, dev):
+    g = torch.Generator().manual_seed(3)
+    n, T, half, sigma = 2, 16000, 4, 0.001
+    x = (torch.rand(n, 1, T, generator=g) * 1.8 - 0.9).to(dev)
+    noise = torch.randn(n, half, 1, T, generator=g).to(dev)
+    for with_clean in (True, False):
+        q, _ = hip_model.nes_queries(x, half, with_clean, sigma, 7, 0, noise)
+        full = torch.cat((noise, -noise), 1)
+        if with_clean:
+            full = torch.cat((torch.zeros_like(x).unsqueeze(1), full), 1)
+        want = (full * sigma + x.unsqueeze(1)).view(-1, 1, T)
+        assert torch.equal(q, want)
+        Q = 2 * half + int(with_clean)
+        loss = torch.randn(n, Q, generator=g).to(dev)
+        grad = torch.zeros_like(x)
+        hip_model.nes_grad(loss, grad, n, T, half, with_clean, 7, 0, noise, False, sigma, 2)
+        l = loss[:, 1:] if with_clean else loss
+        ref = torch.mean(l.unsqueeze(2).unsqueeze(3) * torch.cat((noise, -noise), 1), 1) / sigma / 2
+        np.testing.assert_allclose(grad.cpu().numpy(), ref.cpu().numpy(), rtol=2e-6, atol=3e-4)  # |grad| ~ 300; sum order differs
+    # internal generator: reproducible, N(0,1), and nes_grad regenerates exactly what nes_queries used
+    q1, z1 = hip_model.nes_queries(x, half, True, sigma, 11, 4, None, want_noise=True)
+    q2, z2 = hip_model.nes_queries(x, half, True, sigma, 11, 4, None, want_noise=True)
+    assert torch.equal(q1, q2) and torch.equal(z1, z2)
+    assert not torch.equal(z1, hip_model.nes_queries(x, half, True, sigma, 12, 4, None, want_noise=True)[1])
+    assert abs(z1.mean().item()) < 0.01 and abs(z1.std().item() - 1.0) < 0.01
+    loss = torch.randn(n, 2 * half + 1, generator=g).to(dev)
+    ga, gb = torch.zeros_like(x), torch.zeros_like(x)
+    hip_model.nes_grad(loss, ga, n, T, half, True, 11, 4, None, False, 0.0, 1)
+    hip_model.nes_grad(loss, gb, n, T, half, True, 11, 4, z1.contiguous(), False, 0.0, 1)
+    assert torch.equal(ga, gb)
+    # FAKEBOB.py:93-104
+    prev = torch.randn(n, 1, T, generator=g).to(dev)
+    grad = torch.randn(n, 1, T, generator=g).to(dev)
+    grad[:, :, ::5] = 0.0
+    prev[:, :, ::5] = 0.0
+    lr = torch.tensor([1e-3, 2.5e-4], device=dev)
+    lower, upper = torch.clamp(x - 0.002, min=-1), torch.clamp(x + 0.002, max=1)
+    mg = 0.9 * prev + (1.0 - 0.9) * grad
+    want_x = torch.min(torch.max(x + (-1) * lr.view(-1, 1, 1) * torch.sign(mg), lower), upper)
+    xx, gg = x.clone(), grad.clone()
+    hip_model.fakebob_step(xx, gg, prev, lr, lower, upper, 0.9, -1)
+    assert torch.equal(xx, want_x) and torch.equal(gg, mg)

@@ -53,8 +53,11 @@ def test_attacks_match_reference_trajectories(tag, thr, task, capsys):
               samples_per_draw_batch_size=8, sigma=0.01, stop_early=True, stop_early_iter=10, verbose=0)
     if thr is not None:
         fb["threshold"] = thr
-    check("fakebob", FAKEBOB(model, batch_size=1, **fb))
-    check("fakebob_t", FAKEBOB(model, batch_size=1, targeted=True, confidence=0.05, **fb))
+    # the reference draws NES noise with torch.randn from the global RNG (seeded by check()); the
+    # product takes it through noise_fn so that the same stream is consumed in the same order
+    rn = lambda shape: torch.randn(shape)
+    check("fakebob", FAKEBOB(model, batch_size=1, noise_fn=rn, **fb))
+    check("fakebob_t", FAKEBOB(model, batch_size=1, targeted=True, confidence=0.05, noise_fn=rn, **fb))
 
 
 def test_attack_asserts_follow_reference():
