@@ -201,6 +201,51 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
                   uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev, float* loss_dev,
                   float* loss_trace_dev, int64_t* decision_trace_dev, void* stream);
 
+/* ---- AudioNet CSI-NE model (model/audionet_csine.py) ----------------------------------------
+ * log-mel(32) front-end (model/_audionet/Preprocessor.py:85-112) -> 5x5 pre-filter -> seven
+ * Conv1d/BatchNorm/ReLU(/MaxPool) blocks -> max over time -> Linear(32, num_class).  Input levels:
+ * flag 0 = wav (B,1,T) in [-1,1] (int16-scaled input is divided by 32768, model/utils.py:15-16),
+ * flag 1 = log-mel features (B,F,32).  All pointers in sg_an_weights are HOST fp32 tensors in the
+ * reference's state_dict layout (keys convN.0.weight/bias, convN.1.weight/bias/running_mean/
+ * running_var, fc.weight/bias); the BatchNorms are folded into the convolutions at load time. */
+typedef struct sg_an_weights {
+    const float* conv1_weight;   /* (1,1,5,5) */
+    const float* conv1_bias;     /* (1) */
+    const float* bn1[4];         /* conv1.1 weight, bias, running_mean, running_var (1 each) */
+    const float* conv_weight[7]; /* conv2..conv8 .0.weight (cout, cin, 3) */
+    const float* conv_bias[7];
+    const float* bn_weight[7];
+    const float* bn_bias[7];
+    const float* bn_mean[7];
+    const float* bn_var[7];
+    const float* fc_weight;      /* (num_class, 32) */
+    const float* fc_bias;        /* (num_class) */
+    int32_t num_class;
+    float bn_eps;                /* 1e-5 */
+} sg_an_weights;
+
+int sg_an_load(sg_ctx* ctx, const sg_an_weights* w);
+/* frames of the centred STFT: 1 + (T-1)/160 (0 if T < 1024) */
+int32_t sg_an_num_frames(int32_t T);
+/* Preprocessor.forward: x (B,T) dev -> log-mel (B,F,32) dev (channel-last) */
+int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* feats_dev, void* stream);
+/* audionet_csine.make_decision / score / embedding (:149-257): decisions (B), scores (B,num_class), emb (B,32) */
+int sg_an_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag,
+                  int64_t* decisions_dev, float* scores_dev, float* emb_dev, void* stream);
+/* activations of the last pass (parity): layer 1 = pre-filter output, 2..8 = conv2..conv8 block outputs
+ * (after pooling where the block has one), channel-last (B, rows, C) */
+int sg_an_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t capacity_floats,
+                           int32_t* rows_per_utt, int32_t* channels, void* stream);
+/* adaptive_attack/EOT.py:32-35 for AudioNet: make_decision + loss + d loss/d x (hand-coded backward) */
+int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32_t B, int32_t T_or_F,
+                    int32_t flag, const sg_loss_spec* loss, int64_t* decisions_dev, float* scores_dev,
+                    float* loss_dev, float* grad_dev, void* stream);
+/* attack/FGSM.py:38-70 attack_batch on AudioNet, whole loop on the device (params->dither ignored) */
+int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev,
+                  const float* upper_dev, int32_t B, int32_t T, const sg_pgd_params* params,
+                  uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev, float* loss_dev,
+                  float* loss_trace_dev, int64_t* decision_trace_dev, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * Time `iters` launches of one TDNN contraction (layer 1..5 = forward, -1..-5 = data gradient) with HIP
  * events on `stream`; returns average milliseconds per launch in *ms_per_launch and the

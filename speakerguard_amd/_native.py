@@ -20,6 +20,8 @@ EXPORTS = (
     "sg_xv_num_frames", "sg_input_scale", "sg_xv_mfcc", "sg_xv_cmvn", "sg_xv_forward", "sg_xv_debug_activation",
     "sg_xv_loss_grad", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
     "sg_cw2_step", "sg_nes_queries", "sg_nes_grad", "sg_fakebob_step",
+    "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
+    "sg_an_pgd_run",
 )
 
 
@@ -34,6 +36,15 @@ class XvWeights(C.Structure):
         ("fc1_weight", C.c_void_p), ("fc1_bias", C.c_void_p), ("emb_mean", C.c_void_p), ("lda", C.c_void_p),
         ("plda_mean", C.c_void_p), ("plda_transform", C.c_void_p), ("plda_psi", C.c_void_p), ("enroll", C.c_void_p),
         ("D", C.c_int32), ("S", C.c_int32), ("bn_eps", C.c_float), ("threshold", C.c_float),
+    ]
+
+
+class AnWeights(C.Structure):
+    _fields_ = [
+        ("conv1_weight", C.c_void_p), ("conv1_bias", C.c_void_p), ("bn1", C.c_void_p * 4),
+        ("conv_weight", C.c_void_p * 7), ("conv_bias", C.c_void_p * 7), ("bn_weight", C.c_void_p * 7),
+        ("bn_bias", C.c_void_p * 7), ("bn_mean", C.c_void_p * 7), ("bn_var", C.c_void_p * 7),
+        ("fc_weight", C.c_void_p), ("fc_bias", C.c_void_p), ("num_class", C.c_int32), ("bn_eps", C.c_float),
     ]
 
 
@@ -87,6 +98,13 @@ def load():
         "sg_nes_queries": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i64, i32, vp, vp, vp, vp]),
         "sg_nes_grad": (C.c_int, [vp, vp, i32, i32, i32, i32, C.c_uint64, i64, i32, vp, i32, f32, i32, vp, vp]),
         "sg_fakebob_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp]),
+        "sg_an_load": (C.c_int, [vp, C.POINTER(AnWeights)]),
+        "sg_an_num_frames": (i32, [i32]),
+        "sg_an_logmel": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "sg_an_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+        "sg_an_debug_activation": (C.c_int, [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), vp]),
+        "sg_an_loss_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, C.POINTER(LossSpec), vp, vp, vp, vp, vp]),
+        "sg_an_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
         "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32), vp]),
     }
     for name, (res, args) in sig.items():

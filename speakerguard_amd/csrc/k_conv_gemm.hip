@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_segment(const ConvGemmArgs& p, float* smem,
     auto load_chunk = [&](int c) {
         const int j = c / kchunks;
         const int kc = (c - j * kchunks) * BK;
-        const int off = j * p.tap_step;
+        const int off = p.tap_base + j * p.tap_step;
         const long a_off = (long)off * p.lda + kc;
         const long b_off = (long)(j * p.Kc + kc) * p.ldw;
         SG_LOAD_A(0, ra0, ok0) SG_LOAD_A(1, ra1, ok1) SG_LOAD_A(2, ra2, ok2) SG_LOAD_A(3, ra3, ok3)
@@ -233,7 +233,7 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
     auto load_chunk = [&](int c) {
         const int j = c / kchunks;
         const int kc = (c - j * kchunks) * BK;
-        const int off = role_a ? j * p.tap_step : 0;
+        const int off = role_a ? p.tap_base + j * p.tap_step : 0;
         const long eoff = role_a ? (long)off * p.lda + kc : (long)(j * p.Kc + kc) * p.ldw;
         SG_LD(0, r0, ok0) SG_LD(1, r1, ok1) SG_LD(2, r2, ok2) SG_LD(3, r3, ok3)
     };

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void input_range_partial_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void input_range_final_kernel(const float* __restrict__ part, float* scale) {
+__global__ __launch_bounds__(256) void input_range_final_kernel(const float* __restrict__ part, float* scale, int mode) {
     __shared__ float smax[4], smin[4];
     float mx = wave_max_f(part[threadIdx.x]);
     float mn = wave_min_f(part[kScaleBlocks + threadIdx.x]);
@@ -61,13 +61,14 @@ __global__ __launch_bounds__(256) void input_range_final_kernel(const float* __r
     if (threadIdx.x == 0) {
         mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
         mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-        *scale = (0.9f * mx <= 1.f && 0.9f * mn >= -1.f) ? 32768.f : 1.f;
+        const bool unit = 0.9f * mx <= 1.f && 0.9f * mn >= -1.f;  // ori_type == 'scale'
+        *scale = mode == 0 ? (unit ? 32768.f : 1.f) : (unit ? 1.f : 1.f / 32768.f);
     }
 }
 
-hipError_t launch_input_scale(const float* x, int64_t n, float* scratch, float* scale, hipStream_t s) {
+hipError_t launch_input_scale(const float* x, int64_t n, float* scratch, float* scale, int mode, hipStream_t s) {
     hipLaunchKernelGGL(input_range_partial_kernel, dim3(kScaleBlocks), dim3(256), 0, s, x, n, scratch);
-    hipLaunchKernelGGL(input_range_final_kernel, dim3(1), dim3(256), 0, s, scratch, scale);
+    hipLaunchKernelGGL(input_range_final_kernel, dim3(1), dim3(256), 0, s, scratch, scale, mode);
     return hipGetLastError();
 }
 

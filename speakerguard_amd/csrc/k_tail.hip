@@ -11,12 +11,13 @@
 // The matrix-vector loops are unrolled 8-16x: with one block per utterance they are bound by the
 // latency of the (L2-resident) matrix loads, and un-unrolled they issued one dependent load at a
 // time (measured 157 us for the kernel).
+#include "loss_device.h"
 #include "sg_internal.h"
 
 namespace sg {
 
 constexpr int kMaxD = 512;
-constexpr int kMaxS = 1024;
+constexpr int kMaxS = kLossMaxS;
 
 struct TailModelDev {
     const float *fc1_b, *emb_mean, *lda, *lda_t, *plda_mean, *plda_p, *plda_pt, *plda_psi, *enroll;
@@ -120,82 +121,11 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     __syncthreads();
     // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
     if (tid == 0) {
-        int ja = 0;
-        float mx = sc[0];
-        for (int s = 1; s < S; ++s)
-            if (sc[s] > mx) { mx = sc[s]; ja = s; }
-        const int64_t dec = mx > m.threshold ? (int64_t)ja : (int64_t)-1;
+        int64_t dec;
+        const float loss = loss_and_dscores(sc, dsc, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec);
         if (dec_out) dec_out[b] = dec;
         if (dec_trace) dec_trace[b] = dec;
-        float loss = 0.f;
-        if (y) {
-            const int64_t yy = y[b];
-            if (success) success[b] = ls.targeted ? (dec == yy) : (dec != yy);
-            if (ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI) {
-                if (yy >= 0) {
-                    // softmax - onehot exactly as log_softmax + nll compute it in fp32 (the reference's
-                    // F.cross_entropy): d/ds_y = fl(exp(s_y - lse)) - 1.  The cancellation is part of
-                    // the reference's behaviour: for a confidently classified utterance (sum of the
-                    // other probabilities < 6e-8, i.e. a margin > 16.6 -- the normal case for PLDA
-                    // scores) exp() rounds to 1 and d/ds_y is EXACTLY 0, so the reference ascends along
-                    // sum_j p_j grad(s_j) only; an "exact" -(sum of other p_j) would follow a different
-                    // direction (measured: 71 % of the samples differ after 5 steps).  The only liberty
-                    // taken: the non-max terms are summed first and 1 is added last, so `se` carries a
-                    // single rounding instead of up to S-1.
-                    float so = 0.f;
-                    for (int s = 0; s < S; ++s)
-                        if (s != ja) so += expf(sc[s] - mx);
-                    const float lse = logf(1.f + so);  // log-sum-exp RELATIVE to the max: torch's
-                    // log_softmax is (x - max) - log(sum exp(x - max)); adding the max back first would
-                    // round the 4e-5 of a confident utterance to ulp(max) ~ 8e-6 (a 9 % error on d/ds_y)
-                    loss = lse - (sc[yy] - mx);
-                    for (int s = 0; s < S; ++s) dsc[s] = expf((sc[s] - mx) - lse);
-                    dsc[yy] -= 1.f;
-                }
-            } else if (ls.task == SG_TASK_SV) {
-                const bool enr = yy == 0;
-                if (enr == (ls.targeted != 0)) { loss = ls.threshold + ls.confidence - sc[0]; dsc[0] = -1.f; }
-                else { loss = sc[0] + ls.confidence - ls.threshold; dsc[0] = 1.f; }
-            } else if (yy >= 0) {
-                const float real = sc[yy];
-                int jo = -1;
-                float other = -10000.f;  // attack/utils.py:72
-                for (int s = 0; s < S; ++s)
-                    if (s != yy && sc[s] > other) { other = sc[s]; jo = s; }
-                if (ls.targeted) {
-                    if (ls.task == SG_TASK_CSI) {
-                        loss = other + ls.confidence - real;
-                        if (jo >= 0) dsc[jo] += 1.f;
-                    } else {
-                        loss = fmaxf(other, ls.threshold) + ls.confidence - real;
-                        if (jo >= 0 && other >= ls.threshold) dsc[jo] += 1.f;
-                    }
-                    dsc[yy] -= 1.f;
-                } else if (ls.task == SG_TASK_CSI) {
-                    loss = real + ls.confidence - other;
-                    dsc[yy] += 1.f;
-                    if (jo >= 0) dsc[jo] -= 1.f;
-                } else {
-                    const float f_rej = mx + ls.confidence - ls.threshold;
-                    const float f_mis = fmaxf(real, ls.threshold) + ls.confidence - other;
-                    loss = fminf(f_rej, f_mis);
-                    const float wr = f_rej < f_mis ? 1.f : (f_rej == f_mis ? 0.5f : 0.f);
-                    dsc[ja] += wr;
-                    if (real >= ls.threshold) dsc[yy] += 1.f - wr;
-                    if (jo >= 0) dsc[jo] -= 1.f - wr;
-                }
-            } else if (ls.task == SG_TASK_OSI) {
-                if (ls.targeted) { loss = mx + ls.confidence - ls.threshold; dsc[ja] = 1.f; }
-                else { loss = ls.threshold + ls.confidence - mx; dsc[ja] = -1.f; }
-            }
-            if (ls.loss == SG_LOSS_MARGIN || ls.task != SG_TASK_CSI) {
-                if (ls.clip_max) {
-                    const float k = loss > 0.f ? 1.f : (loss == 0.f ? 0.5f : 0.f);
-                    for (int s = 0; s < S; ++s) dsc[s] *= k;
-                    loss = fmaxf(loss, 0.f);
-                }
-            }
-        }
+        if (y && success) success[b] = ls.targeted ? (dec == y[b]) : (dec != y[b]);
         if (loss_out) loss_out[b] = loss;
         if (loss_trace) loss_trace[b] = loss;
     }

@@ -1,0 +1,93 @@
+// Decision + per-example attack loss + d loss / d scores, shared by the x-vector tail and the AudioNet
+// head.  Serial code for ONE thread of the block (the number of classes is small).
+//   decision: argmax, rejected (-1) unless max > threshold     model/iv_plda.py:182-194, audionet_csine.py:246-257
+//   losses:   SEC4SR_CrossEntropy / SEC4SR_MarginLoss           attack/utils.py:7-102
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/speakerguard_hip.h"
+
+namespace sg {
+
+constexpr int kLossMaxS = 1024;
+
+// sc[S]: scores (LDS or registers); dsc[S]: must be zero on entry, receives d loss / d scores.
+__device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, int S, float threshold, int64_t yy,
+                                                  bool has_y, const sg_loss_spec& ls, int64_t* dec_out) {
+    int ja = 0;
+    float mx = sc[0];
+    for (int s = 1; s < S; ++s)
+        if (sc[s] > mx) { mx = sc[s]; ja = s; }
+    *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
+    float loss = 0.f;
+    if (has_y) {
+        if (ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI) {
+            if (yy >= 0) {
+                // softmax - onehot exactly as log_softmax + nll compute it in fp32 (the reference's
+                // F.cross_entropy): d/ds_y = fl(exp(s_y - lse)) - 1.  The cancellation is part of
+                // the reference's behaviour: for a confidently classified utterance (sum of the
+                // other probabilities < 6e-8, i.e. a margin > 16.6 -- the normal case for PLDA
+                // scores) exp() rounds to 1 and d/ds_y is EXACTLY 0, so the reference ascends along
+                // sum_j p_j grad(s_j) only; an "exact" -(sum of other p_j) would follow a different
+                // direction (measured: 71 % of the samples differ after 5 steps).  The only liberty
+                // taken: the non-max terms are summed first and 1 is added last, so `se` carries a
+                // single rounding instead of up to S-1.
+                float so = 0.f;
+                for (int s = 0; s < S; ++s)
+                    if (s != ja) so += expf(sc[s] - mx);
+                const float lse = logf(1.f + so);  // log-sum-exp RELATIVE to the max: torch's
+                // log_softmax is (x - max) - log(sum exp(x - max)); adding the max back first would
+                // round the 4e-5 of a confident utterance to ulp(max) ~ 8e-6 (a 9 % error on d/ds_y)
+                loss = lse - (sc[yy] - mx);
+                for (int s = 0; s < S; ++s) dsc[s] = expf((sc[s] - mx) - lse);
+                dsc[yy] -= 1.f;
+            }
+        } else if (ls.task == SG_TASK_SV) {
+            const bool enr = yy == 0;
+            if (enr == (ls.targeted != 0)) { loss = ls.threshold + ls.confidence - sc[0]; dsc[0] = -1.f; }
+            else { loss = sc[0] + ls.confidence - ls.threshold; dsc[0] = 1.f; }
+        } else if (yy >= 0) {
+            const float real = sc[yy];
+            int jo = -1;
+            float other = -10000.f;  // attack/utils.py:72
+            for (int s = 0; s < S; ++s)
+                if (s != yy && sc[s] > other) { other = sc[s]; jo = s; }
+            if (ls.targeted) {
+                if (ls.task == SG_TASK_CSI) {
+                    loss = other + ls.confidence - real;
+                    if (jo >= 0) dsc[jo] += 1.f;
+                } else {
+                    loss = fmaxf(other, ls.threshold) + ls.confidence - real;
+                    if (jo >= 0 && other >= ls.threshold) dsc[jo] += 1.f;
+                }
+                dsc[yy] -= 1.f;
+            } else if (ls.task == SG_TASK_CSI) {
+                loss = real + ls.confidence - other;
+                dsc[yy] += 1.f;
+                if (jo >= 0) dsc[jo] -= 1.f;
+            } else {
+                const float f_rej = mx + ls.confidence - ls.threshold;
+                const float f_mis = fmaxf(real, ls.threshold) + ls.confidence - other;
+                loss = fminf(f_rej, f_mis);
+                const float wr = f_rej < f_mis ? 1.f : (f_rej == f_mis ? 0.5f : 0.f);
+                dsc[ja] += wr;
+                if (real >= ls.threshold) dsc[yy] += 1.f - wr;
+                if (jo >= 0) dsc[jo] -= 1.f - wr;
+            }
+        } else if (ls.task == SG_TASK_OSI) {
+            if (ls.targeted) { loss = mx + ls.confidence - ls.threshold; dsc[ja] = 1.f; }
+            else { loss = ls.threshold + ls.confidence - mx; dsc[ja] = -1.f; }
+        }
+        if (ls.loss == SG_LOSS_MARGIN || ls.task != SG_TASK_CSI) {
+            if (ls.clip_max) {
+                const float k = loss > 0.f ? 1.f : (loss == 0.f ? 0.5f : 0.f);
+                for (int s = 0; s < S; ++s) dsc[s] *= k;
+                loss = fmaxf(loss, 0.f);
+            }
+        }
+    }
+    return loss;
+}
+
+}  // namespace sg

@@ -217,7 +217,7 @@ struct PassDims {
 int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz, hipStream_t s) {
     Workspace& w = ctx->ws;
     if (flag == SG_FLAG_WAV) {
-        if (!d.keep_scale) SG_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, s));
+        if (!d.keep_scale) SG_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 0, s));
         SG_HIP(launch_mfcc_fwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
         SG_HIP(launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else if (flag == SG_FLAG_RAW) {
@@ -533,7 +533,7 @@ int sg_input_scale(sg_ctx* ctx, const float* x_dev, int64_t n, float* scale_dev,
     if (!ctx || !x_dev || !scale_dev || n < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
     int rc = build_tables(ctx);
     if (rc) return rc;
-    SG_HIP(launch_input_scale(x_dev, n, ctx->range_scratch, scale_dev, (hipStream_t)stream));
+    SG_HIP(launch_input_scale(x_dev, n, ctx->range_scratch, scale_dev, 0, (hipStream_t)stream));
     return SG_OK;
 }
 

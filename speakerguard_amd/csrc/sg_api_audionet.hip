@@ -1,0 +1,447 @@
+// C-ABI entry points of the AudioNet CSI-NE path (include/speakerguard_hip.h, "sg_an_*"):
+// model load (BatchNorm folding), workspace, forward / backward / PGD kernel sequences.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "sg_internal.h"
+
+using namespace sg;
+
+namespace {
+
+int an_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define AN_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return an_fail(ctx, SG_ERR_HIP, "%s failed: %s (%s:%d)", #expr,         \
+                                             hipGetErrorString(e_), __FILE__, __LINE__);              \
+    } while (0)
+
+template <typename T>
+int an_alloc(sg_ctx* ctx, std::vector<void*>& pool, T** out, size_t count) {
+    void* p = nullptr;
+    AN_HIP(hipMalloc(&p, count * sizeof(T) + 256));
+    pool.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return SG_OK;
+}
+template <typename T>
+int an_upload(sg_ctx* ctx, std::vector<void*>& pool, T** out, const std::vector<T>& host) {
+    int rc = an_alloc(ctx, pool, out, host.size());
+    if (rc) return rc;
+    AN_HIP(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+// ---- front-end tables: periodic hann(800), librosa-0.8.0 slaney mel basis (Preprocessor.py:57-60) ----
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_hz / f_sp + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+int an_build_tables(sg_ctx* ctx) {
+    if (ctx->an_tables_ready) return SG_OK;
+    const double PI = 3.14159265358979323846;
+    std::vector<float> window(kAnWin), melw((size_t)kAnMel * kAnBins, 0.f), w0(kAnBins, 0.f), w1(kAnBins, 0.f);
+    std::vector<int> lo(kAnMel), hi(kAnMel), m0(kAnBins, -1);
+    std::vector<double2> tw(kAnFft / 2);
+    std::vector<uint16_t> br(kAnFft);
+    {   // torch.hann_window(800) (periodic): arange * (2 pi / 800) -> cos -> * -0.5 + 0.5, float32
+        const float step = (float)(PI * 2.0 / (double)kAnWin);
+        for (int n = 0; n < kAnWin; ++n) window[n] = cosf((float)n * step) * -0.5f + 0.5f;
+    }
+    {   // librosa.filters.mel(16000, 1024, 32, fmin=0, fmax=8000): float64 arithmetic, cast to float32
+        std::vector<double> mel_f(kAnMel + 2);
+        const double mmin = hz_to_mel(0.0), mmax = hz_to_mel(8000.0);
+        for (int i = 0; i < kAnMel + 2; ++i) mel_f[i] = mel_to_hz(mmin + (mmax - mmin) * i / (kAnMel + 1));
+        for (int m = 0; m < kAnMel; ++m) {
+            const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+            lo[m] = kAnBins;
+            hi[m] = 0;
+            for (int k = 0; k < kAnBins; ++k) {
+                const double fr = 8000.0 * k / (kAnBins - 1);
+                const double lower = (fr - mel_f[m]) / (mel_f[m + 1] - mel_f[m]);
+                const double upper = (mel_f[m + 2] - fr) / (mel_f[m + 2] - mel_f[m + 1]);
+                const double w = std::fmax(0.0, std::fmin(lower, upper)) * enorm;
+                melw[(size_t)m * kAnBins + k] = (float)w;
+                if (w > 0.0) {
+                    if (k < lo[m]) lo[m] = k;
+                    hi[m] = k + 1;
+                }
+            }
+            if (lo[m] > hi[m]) lo[m] = hi[m] = 0;
+        }
+        for (int k = 0; k < kAnBins; ++k) {
+            int first = -1, cnt = 0;
+            for (int m = 0; m < kAnMel; ++m)
+                if (melw[(size_t)m * kAnBins + k] > 0.f) {
+                    if (first < 0) first = m;
+                    ++cnt;
+                }
+            if (cnt > 2 || (cnt == 2 && melw[(size_t)(first + 1) * kAnBins + k] <= 0.f))
+                return an_fail(ctx, SG_ERR_STATE, "mel filterbank is not a two-overlap triangular bank");
+            m0[k] = first;
+            if (first >= 0) {
+                w0[k] = melw[(size_t)first * kAnBins + k];
+                w1[k] = first + 1 < kAnMel ? melw[(size_t)(first + 1) * kAnBins + k] : 0.f;
+            }
+        }
+    }
+    for (int k = 0; k < kAnFft / 2; ++k) tw[k] = make_double2(std::cos(2.0 * PI * k / kAnFft), -std::sin(2.0 * PI * k / kAnFft));
+    for (int i = 0; i < kAnFft; ++i) {
+        int r = 0;
+        for (int bit = 0; bit < 10; ++bit)
+            if (i & (1 << bit)) r |= 1 << (9 - bit);
+        br[i] = (uint16_t)r;
+    }
+    AnTables& t = ctx->an_tab;
+    std::vector<void*>& pool = ctx->model_allocs;
+    int rc = 0;
+    rc |= an_upload(ctx, pool, &t.window, window);
+    rc |= an_upload(ctx, pool, &t.mel_w, melw);
+    rc |= an_upload(ctx, pool, &t.mel_lo, lo);
+    rc |= an_upload(ctx, pool, &t.mel_hi, hi);
+    rc |= an_upload(ctx, pool, &t.bin_m0, m0);
+    rc |= an_upload(ctx, pool, &t.bin_w0, w0);
+    rc |= an_upload(ctx, pool, &t.bin_w1, w1);
+    rc |= an_upload(ctx, pool, &t.twiddle, tw);
+    rc |= an_upload(ctx, pool, &t.bitrev, br);
+    if (!ctx->range_scratch) rc |= an_alloc(ctx, pool, &ctx->range_scratch, 512);
+    if (rc) return SG_ERR_HIP;
+    ctx->an_tables_ready = true;
+    return SG_OK;
+}
+
+// frames entering / leaving every conv; false if the utterance is too short for conv8 (kernel 3, no pad)
+bool an_layer_frames(int F, int* Tin, int* Tout) {
+    int t = F;
+    for (int l = 0; l < kAnConv; ++l) {
+        Tin[l] = t;
+        Tout[l] = t + 2 * kAnPad[l] - 2;
+        if (Tout[l] < 1) return false;
+        t = kAnPool[l] ? Tout[l] / 2 : Tout[l];
+        if (t < 1) return false;
+    }
+    return Tin[kAnConv - 1] >= 3;
+}
+
+int an_ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
+    AnWorkspace& w = ctx->an_ws;
+    if (B <= w.B && F <= w.F && T <= w.T && w.scale) {
+        an_layer_frames(F, w.Tin, w.Tout);
+        return SG_OK;
+    }
+    (void)hipDeviceSynchronize();
+    for (void* p : w.allocs) (void)hipFree(p);
+    const int cb = B > w.B ? B : w.B, cf = F > w.F ? F : w.F, ct = T > w.T ? T : w.T;
+    w = AnWorkspace();
+    w.B = cb; w.F = cf; w.T = ct;
+    int Tin[kAnConv], Tout[kAnConv];
+    an_layer_frames(cf, Tin, Tout);
+    const size_t b = (size_t)cb;
+    int rc = 0;
+    rc |= an_alloc(ctx, w.allocs, &w.scale, 4);
+    rc |= an_alloc(ctx, w.allocs, &w.feats, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.pre, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.dpre, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.dfeats, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.dframes, b * cf * kAnWin);
+    for (int l = 0; l < kAnConv; ++l) {
+        const size_t n = b * (size_t)(Tout[l] > 0 ? Tout[l] : 1) * kAnCout[l];
+        rc |= an_alloc(ctx, w.allocs, &w.act[l], n);
+        rc |= an_alloc(ctx, w.allocs, &w.dact[l], n);
+        if (kAnPool[l]) {
+            rc |= an_alloc(ctx, w.allocs, &w.pool[l], n / 2 + kAnCout[l]);
+            rc |= an_alloc(ctx, w.allocs, &w.dpool[l], n / 2 + kAnCout[l]);
+        }
+    }
+    if (rc) {
+        for (void* p : w.allocs) (void)hipFree(p);
+        w = AnWorkspace();
+        return SG_ERR_HIP;
+    }
+    an_layer_frames(F, w.Tin, w.Tout);
+    return SG_OK;
+}
+
+struct AnDims {
+    int B, T, F;
+    bool keep_scale = false;
+};
+
+int an_check(sg_ctx* ctx, int B, int TF, int flag, AnDims* d) {
+    if (!ctx) return SG_ERR_ARG;
+    if (!ctx->an.loaded) return an_fail(ctx, SG_ERR_STATE, "no AudioNet model loaded (call sg_an_load)");
+    AN_HIP(hipSetDevice(ctx->device));
+    if (B < 1) return an_fail(ctx, SG_ERR_ARG, "B must be >= 1");
+    if (flag != 0 && flag != 1) return an_fail(ctx, SG_ERR_ARG, "flag must be 0 (wav) or 1 (log-mel feat)");
+    d->B = B;
+    if (flag == 0) {
+        if (TF < kAnFft) return an_fail(ctx, SG_ERR_ARG, "waveform shorter than one 1024-sample STFT frame");
+        d->T = TF;
+        d->F = an_num_frames(TF);
+    } else {
+        d->T = 0;
+        d->F = TF;
+    }
+    int Tin[kAnConv], Tout[kAnConv];
+    if (!an_layer_frames(d->F, Tin, Tout))
+        return an_fail(ctx, SG_ERR_ARG, "%d frames are too few for the AudioNet stack (need >= 3 frames at conv8)", d->F);
+    int rc = an_build_tables(ctx);
+    if (rc) return rc;
+    rc = an_ensure_workspace(ctx, d->B, d->T, d->F);
+    if (rc) return an_fail(ctx, rc, "workspace allocation failed: %s", ctx->err.c_str());
+    return SG_OK;
+}
+
+const float* an_layer_input(const AnWorkspace& w, int l) {
+    if (l == 0) return w.pre;
+    return kAnPool[l - 1] ? w.pool[l - 1] : w.act[l - 1];
+}
+
+int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipStream_t s) {
+    AnWorkspace& w = ctx->an_ws;
+    const AnModel& m = ctx->an;
+    const float* feats = x;
+    if (flag == 0) {
+        if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
+        AN_HIP(launch_an_logmel_fwd(ctx->an_tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
+        feats = w.feats;
+    }
+    AN_HIP(launch_an_prefilter(feats, w.pre, d.B, d.F, m.w25, m.pre_bias, 0, s));
+    for (int l = 0; l < kAnConv; ++l) {
+        ConvGemmArgs a{};
+        a.A = an_layer_input(w, l);
+        a.W = m.wf[l];
+        a.C = w.act[l];
+        a.bias = m.bias[l];
+        a.Ta = w.Tin[l];
+        a.Tc = w.Tout[l];
+        a.M = d.B * a.Tc;
+        a.N = kAnCout[l];
+        a.Kc = kAnCin[l];
+        a.lda = kAnCin[l];
+        a.ldw = kAnCout[l];
+        a.ldc = kAnCout[l];
+        a.taps = 3;
+        a.tap_step = 1;
+        a.tap_base = -kAnPad[l];
+        a.total_chunks = 3 * (a.Kc / 32);
+        a.chunks_per_split = a.total_chunks;
+        AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, EPI_BIAS_RELU, 1, s));
+        if (kAnPool[l]) AN_HIP(launch_an_pool_fwd(w.act[l], w.pool[l], d.B, w.Tout[l], kAnCout[l], s));
+    }
+    return SG_OK;
+}
+
+// d loss / d conv8 pre-activation (ws.dact[6]) -> input level
+int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, float* grad_out, float* x_update,
+                    const float* lower, const float* upper, float step, int grad_sign, hipStream_t s) {
+    AnWorkspace& w = ctx->an_ws;
+    const AnModel& m = ctx->an;
+    for (int l = kAnConv - 1; l >= 0; --l) {
+        // data gradient of conv l: reads dact[l] (B, Tout, Cout), writes the gradient of its input
+        const bool in_pooled = l > 0 && kAnPool[l - 1];
+        ConvGemmArgs a{};
+        a.A = w.dact[l];
+        a.W = m.wb[l];
+        a.C = l == 0 ? w.dpre : (in_pooled ? w.dpool[l - 1] : w.dact[l - 1]);
+        a.mask = (l == 0 || in_pooled) ? nullptr : w.act[l - 1];
+        a.Ta = w.Tout[l];
+        a.Tc = w.Tin[l];
+        a.M = d.B * a.Tc;
+        a.N = kAnCin[l];
+        a.Kc = kAnCout[l];
+        a.lda = kAnCout[l];
+        a.ldw = kAnCin[l];
+        a.ldc = kAnCin[l];
+        a.taps = 3;
+        a.tap_step = -1;
+        a.tap_base = kAnPad[l];  // d in[t] = sum_j W_j^T d out[t + pad - j]
+        a.total_chunks = 3 * (a.Kc / 32);
+        a.chunks_per_split = a.total_chunks;
+        AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, a.mask ? EPI_RELU_MASK : EPI_NONE, 1, s));
+        if (in_pooled)
+            AN_HIP(launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], d.B, w.Tout[l - 1], kAnCout[l - 1], s));
+    }
+    float* dfeats = flag == 1 ? grad_out : w.dfeats;
+    AN_HIP(launch_an_prefilter(w.dpre, dfeats, d.B, d.F, m.w25, 0.f, 1, s));
+    if (flag == 0) {
+        AN_HIP(launch_an_logmel_bwd(ctx->an_tab, x, d.B, d.T, d.F, w.scale, w.dfeats, w.dframes, s));
+        AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step,
+                                        grad_sign, s));
+    }
+    return SG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sg_an_num_frames(int32_t T) { return an_num_frames(T); }
+
+int sg_an_load(sg_ctx* ctx, const sg_an_weights* w) {
+    if (!ctx || !w) return SG_ERR_ARG;
+    if (w->num_class < 1 || w->num_class > 1024) return an_fail(ctx, SG_ERR_ARG, "num_class must be 1..1024");
+    if (!w->conv1_weight || !w->conv1_bias || !w->fc_weight || !w->fc_bias) return an_fail(ctx, SG_ERR_ARG, "missing tensor");
+    for (int i = 0; i < 4; ++i)
+        if (!w->bn1[i]) return an_fail(ctx, SG_ERR_ARG, "missing conv1 BatchNorm tensor");
+    for (int l = 0; l < kAnConv; ++l)
+        if (!w->conv_weight[l] || !w->conv_bias[l] || !w->bn_weight[l] || !w->bn_bias[l] || !w->bn_mean[l] || !w->bn_var[l])
+            return an_fail(ctx, SG_ERR_ARG, "missing tensor for conv%d", l + 2);
+    AN_HIP(hipSetDevice(ctx->device));
+    int rc = an_build_tables(ctx);
+    if (rc) return rc;
+    const double eps = w->bn_eps > 0.f ? w->bn_eps : 1e-5;
+    AnModel& m = ctx->an;
+    m = AnModel();
+    std::vector<void*>& pool = ctx->model_allocs;
+    // BatchNorm (eval, affine) directly follows every convolution and precedes the ReLU
+    // (audionet_csine.py:68-115): y = g (conv + b - mean) / sqrt(var + eps) + beta folds into W, b.
+    {
+        const double g = w->bn1[0][0], beta = w->bn1[1][0], mean = w->bn1[2][0], var = w->bn1[3][0];
+        const double sc = g / std::sqrt(var + eps);
+        std::vector<float> w25(25);
+        for (int i = 0; i < 25; ++i) w25[i] = (float)(w->conv1_weight[i] * sc);  // [mel offset][time offset]
+        m.pre_bias = (float)((w->conv1_bias[0] - mean) * sc + beta);
+        rc |= an_upload(ctx, pool, &m.w25, w25);
+    }
+    for (int l = 0; l < kAnConv; ++l) {
+        const int cin = kAnCin[l], cout = kAnCout[l];
+        std::vector<float> wf((size_t)3 * cin * cout), wb((size_t)3 * cout * cin), bias(cout);
+        for (int co = 0; co < cout; ++co) {
+            const double sc = w->bn_weight[l][co] / std::sqrt((double)w->bn_var[l][co] + eps);
+            bias[co] = (float)((w->conv_bias[l][co] - w->bn_mean[l][co]) * sc + w->bn_bias[l][co]);
+            for (int ci = 0; ci < cin; ++ci)
+                for (int j = 0; j < 3; ++j) {
+                    const float v = (float)(w->conv_weight[l][((size_t)co * cin + ci) * 3 + j] * sc);
+                    wf[((size_t)j * cin + ci) * cout + co] = v;
+                    wb[((size_t)j * cout + co) * cin + ci] = v;
+                }
+        }
+        rc |= an_upload(ctx, pool, &m.wf[l], wf);
+        rc |= an_upload(ctx, pool, &m.wb[l], wb);
+        rc |= an_upload(ctx, pool, &m.bias[l], bias);
+    }
+    rc |= an_upload(ctx, pool, &m.fc_w, std::vector<float>(w->fc_weight, w->fc_weight + (size_t)w->num_class * 32));
+    rc |= an_upload(ctx, pool, &m.fc_b, std::vector<float>(w->fc_bias, w->fc_bias + w->num_class));
+    if (rc) return an_fail(ctx, SG_ERR_HIP, "model upload failed: %s", ctx->err.c_str());
+    m.S = w->num_class;
+    m.loaded = true;
+    return SG_OK;
+}
+
+int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* feats_dev, void* stream) {
+    if (!ctx || !x_dev || !feats_dev || B < 1 || T < kAnFft) return an_fail(ctx, SG_ERR_ARG, "bad argument");
+    int rc = an_build_tables(ctx);
+    if (rc) return rc;
+    float* scale = nullptr;
+    if (!ctx->an_ws.scale) {
+        rc = an_ensure_workspace(ctx, 1, kAnFft, an_num_frames(kAnFft) + 40);
+        if (rc) return rc;
+    }
+    scale = ctx->an_ws.scale;
+    hipStream_t s = (hipStream_t)stream;
+    AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, scale, 1, s));
+    AN_HIP(launch_an_logmel_fwd(ctx->an_tab, x_dev, B, T, an_num_frames(T), scale, feats_dev, s));
+    return SG_OK;
+}
+
+int sg_an_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag, int64_t* decisions_dev,
+                  float* scores_dev, float* emb_dev, void* stream) {
+    AnDims d;
+    int rc = an_check(ctx, B, T_or_F, flag, &d);
+    if (rc) return rc;
+    if (!x_dev) return an_fail(ctx, SG_ERR_ARG, "x is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
+    AnWorkspace& w = ctx->an_ws;
+    sg_loss_spec none{};
+    AN_HIP(launch_an_tail(w.act[kAnConv - 1], B, w.Tout[kAnConv - 1], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, nullptr,
+                          none, 0, emb_dev, scores_dev, decisions_dev, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+    return SG_OK;
+}
+
+int sg_an_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t capacity_floats, int32_t* rows_per_utt,
+                           int32_t* channels, void* stream) {
+    if (!ctx || layer < 1 || layer > kAnConv + 1 || !ctx->an_ws.scale) return an_fail(ctx, SG_ERR_ARG, "bad layer or no pass run");
+    const AnWorkspace& w = ctx->an_ws;
+    const float* src;
+    int rows, ch;
+    if (layer == 1) { src = w.pre; rows = w.F >= 0 ? w.Tin[0] : 0; ch = kAnMel; }
+    else {
+        const int l = layer - 2;
+        src = kAnPool[l] ? w.pool[l] : w.act[l];
+        rows = kAnPool[l] ? w.Tout[l] / 2 : w.Tout[l];
+        ch = kAnCout[l];
+    }
+    if (rows_per_utt) *rows_per_utt = rows;
+    if (channels) *channels = ch;
+    if (out_dev) {
+        if (capacity_floats <= 0) return an_fail(ctx, SG_ERR_ARG, "capacity must be positive");
+        AN_HIP(hipMemcpyAsync(out_dev, src, (size_t)capacity_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return SG_OK;
+}
+
+int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32_t B, int32_t T_or_F, int32_t flag,
+                    const sg_loss_spec* loss, int64_t* decisions_dev, float* scores_dev, float* loss_dev, float* grad_dev,
+                    void* stream) {
+    AnDims d;
+    int rc = an_check(ctx, B, T_or_F, flag, &d);
+    if (rc) return rc;
+    if (!x_dev || !y_dev || !loss) return an_fail(ctx, SG_ERR_ARG, "x, y and loss are required");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
+    AnWorkspace& w = ctx->an_ws;
+    const int L = kAnConv - 1;
+    AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, *loss,
+                          grad_dev != nullptr, nullptr, scores_dev, decisions_dev, loss_dev, w.dact[L], nullptr, nullptr,
+                          nullptr, s));
+    if (grad_dev) return an_backward_net(ctx, x_dev, d, flag, grad_dev, nullptr, nullptr, nullptr, 0.f, 0, s);
+    return SG_OK;
+}
+
+int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev, const float* upper_dev,
+                  int32_t B, int32_t T, const sg_pgd_params* p, uint8_t* success_dev, int64_t* decisions_dev,
+                  float* scores_dev, float* loss_dev, float* loss_trace_dev, int64_t* decision_trace_dev, void* stream) {
+    AnDims d;
+    int rc = an_check(ctx, B, T, 0, &d);
+    if (rc) return rc;
+    if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p) return an_fail(ctx, SG_ERR_ARG, "NULL argument");
+    if (p->max_iter < 0) return an_fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    AnWorkspace& w = ctx->an_ws;
+    const int L = kAnConv - 1;
+    for (int it = 0; it <= p->max_iter; ++it) {
+        const bool last = it == p->max_iter;
+        d.keep_scale = it > 0;  // iterates stay in [-1, 1]
+        if ((rc = an_forward_net(ctx, x_adv_dev, d, 0, s))) return rc;
+        AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
+                              nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
+                              w.dact[L], loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
+                              decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr,
+                              last ? success_dev : nullptr, s));
+        if (!last) {
+            rc = an_backward_net(ctx, x_adv_dev, d, 0, nullptr, x_adv_dev, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
+            if (rc) return rc;
+        }
+    }
+    return SG_OK;
+}
+
+}  // extern "C"

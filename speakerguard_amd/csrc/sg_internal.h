@@ -37,6 +37,56 @@ constexpr int kL1BwdSplitK = 5;        // tdnn1 data gradient: one K-slab per ta
 
 inline int num_frames(int T) { return (T + kShift / 2) / kShift; }
 
+// ---------------------------------------------------------------- AudioNet CSI-NE (model/audionet_csine.py)
+constexpr int kAnFft = 1024, kAnHop = 160, kAnWin = 800, kAnMel = 32, kAnBins = 513;  // Preprocessor.py:13-23
+constexpr int kAnConv = 7;                                                              // conv2 .. conv8
+constexpr int kAnCin[kAnConv] = {32, 64, 128, 128, 128, 128, 64};
+constexpr int kAnCout[kAnConv] = {64, 128, 128, 128, 128, 64, 32};
+constexpr int kAnPad[kAnConv] = {1, 1, 1, 1, 1, 1, 0};
+constexpr bool kAnPool[kAnConv] = {true, false, false, true, false, true, false};
+// torch.stft(center=True) on the pre-emphasised signal of T-1 samples: 1 + (T-1)/hop frames
+inline int an_num_frames(int T) { return T < kAnWin ? 0 : 1 + (T - 1) / kAnHop; }
+
+struct AnTables {            // device pointers
+    float* window;           // [800] periodic hann
+    float* mel_w;            // [32][513] slaney mel filterbank
+    int* mel_lo;             // [32]
+    int* mel_hi;             // [32]
+    int* bin_m0;             // [513]
+    float* bin_w0;           // [513]
+    float* bin_w1;           // [513]
+    double2* twiddle;        // [512] exp(-2 pi i k / 1024)
+    uint16_t* bitrev;        // [1024]
+};
+
+struct AnModel {
+    bool loaded = false;
+    int S = 0;
+    float* w25 = nullptr;       // folded 5x5 pre-filter [mel offset][time offset]
+    float pre_bias = 0.f;
+    float* wf[kAnConv] = {};    // forward  [3*Cin][Cout]   (BatchNorm folded)
+    float* wb[kAnConv] = {};    // backward [3*Cout][Cin]
+    float* bias[kAnConv] = {};
+    float* fc_w = nullptr;      // [S][32]
+    float* fc_b = nullptr;      // [S]
+};
+
+struct AnWorkspace {
+    int B = 0, T = 0, F = 0;
+    int Tin[kAnConv] = {}, Tout[kAnConv] = {};  // frames entering / leaving each conv (before pooling)
+    float* scale = nullptr;
+    float* feats = nullptr;    // (B, F, 32) log-mel
+    float* pre = nullptr;      // (B, F, 32) pre-filter output
+    float* act[kAnConv] = {};  // ReLU outputs (B, Tout, Cout)
+    float* pool[kAnConv] = {}; // pooled outputs where the layer has a MaxPool
+    float* dact[kAnConv] = {}; // gradients wrt pre-activations
+    float* dpool[kAnConv] = {};
+    float* dpre = nullptr;     // (B, F, 32)
+    float* dfeats = nullptr;   // (B, F, 32)
+    float* dframes = nullptr;  // (B, F, 800)
+    std::vector<void*> allocs;
+};
+
 struct MfccTables {          // device pointers
     float* window;           // [400] povey
     float* mel_w;            // [30][256] dense triangular weights
@@ -110,6 +160,10 @@ struct sg_ctx {
     unsigned* sk_flags = nullptr;
     sg::XvModel xv;
     sg::Workspace ws;
+    sg::AnTables an_tab{};
+    bool an_tables_ready = false;
+    sg::AnModel an;
+    sg::AnWorkspace an_ws;
     std::vector<void*> model_allocs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -129,7 +183,8 @@ struct ConvGemmArgs {
     int Ta, Tc;         // rows per utterance in A / C
     int Kc;             // K per tap, multiple of 32
     int lda, ldw, ldc;
-    int taps, tap_step; // A row offset of tap j = j * tap_step
+    int taps, tap_step; // A row offset of tap j = tap_base + j * tap_step
+    int tap_base;
     int total_chunks, chunks_per_split;
     long long split_stride;
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
@@ -141,7 +196,8 @@ struct ConvGemmArgs {
 hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s);
 int conv_gemm_tile_rows(int M, int N);  // tile height launch_conv_gemm(tile 0) picks
 
-hipError_t launch_input_scale(const float* x, int64_t n, float* scratch512, float* scale, hipStream_t s);
+// mode 0: xv_plda ('origin': [-1,1] -> x32768), mode 1: AudioNet ('scale': int16 range -> /32768)
+hipError_t launch_input_scale(const float* x, int64_t n, float* scratch512, float* scale, int mode, hipStream_t s);
 hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, float* feats, hipStream_t s);
 hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
@@ -175,6 +231,22 @@ hipError_t launch_nes_grad(const float* loss, int n, int T, int half, int with_c
 hipError_t launch_fakebob_step(float* x, float* grad, const float* prev_grad, const float* lr, const float* lower,
                                const float* upper, int n, int T, float momentum, float one_m_momentum, int grad_sign,
                                hipStream_t s);
+
+hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
+                                hipStream_t s);
+hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
+                                const float* dfeats, float* dframes, hipStream_t s);
+hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
+                                    float* x_io, const float* lower, const float* upper, float step, int grad_sign,
+                                    hipStream_t s);
+hipError_t launch_an_prefilter(const float* in, float* out, int B, int T, const float* w25, float bias, int transpose,
+                               hipStream_t s);
+hipError_t launch_an_pool_fwd(const float* in, float* out, int B, int Tin, int C, hipStream_t s);
+hipError_t launch_an_pool_bwd(const float* act, const float* dpool, float* dact, int B, int Tin, int C, hipStream_t s);
+hipError_t launch_an_tail(const float* act8, int B, int T8, const float* fc_w, const float* fc_b, int S, float threshold,
+                          const int64_t* y, const sg_loss_spec& ls, int want_grad, float* emb, float* scores,
+                          int64_t* decisions, float* loss, float* dact8, float* loss_trace, int64_t* dec_trace,
+                          uint8_t* success, hipStream_t s);
 
 struct TailArgs {
     const float* fc1_part; int nsplit; int B;

@@ -1,0 +1,186 @@
+"""GPU parity tests of the AudioNet CSI-NE path against the oracle (oracle/audionet.py).
+
+PARITY UNPINNED for this model family: the oracle restates reference model/audionet_csine.py and
+model/_audionet/Preprocessor.py, but the reference class cannot be constructed in the build
+container (librosa 0.8.0 / old torch.stft), so no reference-generated fixture exists.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(ROOT, "gpurun_out", "parity_log.txt")
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(msg + "\n")
+    print(msg)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from speakerguard_amd import synth
+    return synth.make_audionet_state_dict(seed=0, num_class=251)
+
+
+@pytest.fixture(scope="module")
+def hip(sd, dev):
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    return audionet_csine.from_weights(sd, device=dev)
+
+
+@pytest.fixture(scope="module")
+def ora(sd):
+    from oracle.audionet import AudioNet
+    return AudioNet(sd)
+
+
+@pytest.mark.parametrize("T", [48000, 16000, 20011])
+def test_logmel_matches_oracle(hip, ora, dev, T):
+    from speakerguard_amd import synth
+    x = torch.from_numpy(synth.make_waveforms(3, T, seed=41))
+    got = hip.compute_feat(x.to(dev)).cpu()
+    want = ora.compute_feat(x)
+    assert got.shape == want.shape
+    log("audionet log-mel T=%d: max abs err %.3e dB (values %.1f..%.1f)" % (T, (got - want).abs().max().item(), want.min().item(), want.max().item()))
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-3)
+    # int16-scaled input is divided by 32768 (check_input_range, range_type='scale')
+    got16 = hip.compute_feat((x * 32768.0).to(dev)).cpu()
+    np.testing.assert_allclose(got16.numpy(), want.numpy(), rtol=0, atol=2e-3)
+
+
+def test_layers_scores_and_decisions(hip, ora, dev):
+    from speakerguard_amd import synth
+    x = torch.from_numpy(synth.make_waveforms(4, 48000, seed=42))
+    with torch.no_grad():
+        feats = ora.compute_feat(x)
+        outs = ora.layers(feats)
+        odec, oscores = ora.make_decision(x)
+    dec, scores = hip.make_decision(feats.to(dev), flag=1)  # same features -> isolates the CNN
+    for i, o in enumerate(outs, 1):
+        act = hip.read_activation(i, 4).cpu().numpy()  # (B, rows, C)
+        ref = o.numpy().transpose(0, 2, 1)
+        assert act.shape == ref.shape, (i, act.shape, ref.shape)
+        log("audionet layer %d: max abs err %.3e (max %.2f)" % (i, np.abs(act - ref).max(), np.abs(ref).max()))
+        np.testing.assert_allclose(act, ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(scores.cpu().numpy(), oscores.numpy(), rtol=1e-3, atol=2e-3)
+    assert dec.cpu().tolist() == odec.tolist()
+    dec2, scores2 = hip.make_decision(x.to(dev))
+    np.testing.assert_allclose(scores2.cpu().numpy(), oscores.numpy(), rtol=1e-3, atol=5e-3)
+    assert dec2.cpu().tolist() == odec.tolist()
+    emb = hip.embedding(x.to(dev)).cpu()
+    np.testing.assert_allclose(emb.numpy(), outs[-1].max(2)[0].numpy(), rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("loss_name", ["Entropy", "Margin"])
+def test_gradients_match_oracle_autograd(hip, ora, dev, loss_name):
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import resolve_loss
+    x = torch.from_numpy(synth.make_waveforms(3, 48000, seed=43))
+    with torch.no_grad():
+        y = ora.make_decision(x)[0]
+        feats = ora.compute_feat(x)
+    spec, _ = resolve_loss(loss_name, False, 0., "CSI", None, False)
+    ofn, _ = oatk.resolve_loss(loss_name, False, 0., "CSI", None, False)
+    # feature level
+    fin = feats.clone().requires_grad_(True)
+    _, sc = ora.make_decision(fin, flag=1)
+    lo = ofn(sc, y)
+    lo.backward(torch.ones_like(lo))
+    dec, scores, loss, grad = hip.loss_grad(feats.to(dev), y.to(dev), spec, flag=1)
+    np.testing.assert_allclose(loss.cpu().numpy(), lo.detach().numpy(), rtol=1e-3, atol=2e-3)
+    gs = fin.grad.abs().max().item()
+    e = (grad.cpu() - fin.grad).abs().max().item() / gs
+    log("audionet d loss/d logmel (%s): max err / max|grad| = %.3e" % (loss_name, e))
+    assert e < 2e-3
+    # waveform level
+    xin = x.clone().requires_grad_(True)
+    _, sc = ora.make_decision(xin)
+    lo = ofn(sc, y)
+    lo.backward(torch.ones_like(lo))
+    dec, scores, loss, grad = hip.loss_grad(x.to(dev), y.to(dev), spec)
+    want, got = xin.grad.numpy(), grad.cpu().numpy()
+    gs = np.abs(want).max()
+    e = np.abs(got - want).max() / gs
+    sm = float((np.sign(got) != np.sign(want)).mean())
+    log("audionet d loss/d wav (%s): max err / max|grad| = %.3e, sign mismatch %.3e" % (loss_name, e, sm))
+    assert e < 5e-3 and sm < 5e-3
+
+
+def test_fused_loop_equals_stepwise_and_fgsm_config(hip, ora, dev):
+    """BASELINE configs[0]: FGSM 1-step L-inf on AudioNet CSI-NE, one 3 s utterance."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FGSM import FGSM
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    x = torch.from_numpy(synth.make_waveforms(1, 48000, seed=44))
+    with torch.no_grad():
+        y = ora.make_decision(x)[0]
+    oadv, osucc = oatk.FGSM(ora, task="CSI", epsilon=0.002, batch_size=1).attack(x.clone(), y)
+    adv, succ = FGSM(hip, task="CSI", epsilon=0.002, batch_size=1, verbose=0).attack(x.to(dev), y.to(dev))
+    diff = (adv.cpu() - oadv).abs()
+    frac = float((diff > 1e-7).float().mean())
+    log("audionet FGSM: samples differing %.4f%%, success hip=%s oracle=%s" % (100 * frac, succ, osucc))
+    assert frac < 0.01 and succ == osucc
+    # fused == stepwise
+    xb = torch.from_numpy(synth.make_waveforms(3, 32000, seed=45)).to(dev)
+    yb = hip.make_decision(xb)[0]
+    lower, upper = torch.clamp(xb - 0.002, min=-1), torch.clamp(xb + 0.002, max=1)
+    spec = SEC4SR_CrossEntropy()
+    xa, success, dec, scores, loss, _, _ = hip.pgd_run(xb, yb, lower, upper, spec, 0.0004, 4, 1)
+    xs = xb.clone()
+    for _ in range(4):
+        _, _, _, g = hip.loss_grad(xs, yb, spec)
+        hip.pgd_update(xs, g, lower, upper, 0.0004, 1)
+    d2, s2, l2, _ = hip.loss_grad(xs, yb, spec, want_grad=False)
+    assert torch.equal(xa, xs) and torch.equal(dec, d2) and torch.equal(scores, s2)
+
+
+def test_pgd_matches_oracle(hip, ora, dev):
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    B, iters = 4, 5
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=46))
+    with torch.no_grad():
+        y = ora.make_decision(x)[0]
+    kw = dict(task="CSI", epsilon=0.002, step_size=0.0004, max_iter=iters, batch_size=B)
+    oadv, osucc = oatk.PGD(ora, **kw).attack(x.clone(), y)
+    adv, succ = PGD(hip, verbose=0, **kw).attack(x.to(dev), y.to(dev))
+    diff = (adv.cpu() - oadv).abs()
+    frac = float((diff > 1e-7).float().mean())
+    log("audionet PGD-%d: samples differing %.3f%%, success hip=%s oracle=%s" % (iters, 100 * frac, succ, osucc))
+    assert frac < 0.02 * iters and diff.max().item() <= 0.004 + 1e-6
+    assert succ == osucc
+    with torch.no_grad():
+        assert hip.make_decision(adv)[0].cpu().tolist() == ora.make_decision(oadv)[0].tolist()
+
+
+def test_full_batch_properties(hip, dev):
+    """B=64 (one GPU's shard of configs[3]): determinism and shard invariance."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    x = torch.from_numpy(synth.make_waveforms(64, 48000, seed=47)).to(dev)
+    y = hip.make_decision(x)[0]
+    lower, upper = torch.clamp(x - 0.002, min=-1), torch.clamp(x + 0.002, max=1)
+    spec = SEC4SR_CrossEntropy()
+    run = lambda sl: hip.pgd_run(x[sl], y[sl], lower[sl], upper[sl], spec, 0.0004, 3, 1)
+    a, b = run(slice(0, 64)), run(slice(0, 64))
+    assert torch.equal(a[0], b[0])
+    lo, hi = run(slice(0, 32)), run(slice(32, 64))
+    assert torch.equal(a[0], torch.cat((lo[0], hi[0])))
+    assert (a[0] - x).abs().max().item() <= 0.002 + 1e-7
+    log("audionet full-size PGD-3: successes %d/64" % int(a[1].sum()))
