@@ -285,12 +285,12 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][1], bv[ks & 1], acc[1][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == KS_STAGE) {
-                if (c + 1 < c_end) store_chunk(buf ^ 1);
-                if (c + 2 < c_end) load_chunk(c + 2);
+                if (c + 1 < c_end && !(p.ablate & 2)) store_chunk(buf ^ 1);
+                if (c + 2 < c_end && !(p.ablate & 1)) load_chunk(c + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
+        if (!(p.ablate & 4)) __syncthreads();
     }
 }
 
@@ -506,8 +506,12 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     const int ipw = (int)((total + workers - 1) / workers);
     // every range must span at least one full tile's worth of chunks, so a tile is shared by at most
     // two workers and never lies strictly inside one range.
-    // Short-K contractions (tdnn1/4/5 forward: <= 16 chunks) are faster one block per tile (measured).
-    if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < 40) return hipErrorNotSupported;
+    // Very short K (tdnn1 forward: 5 chunks) is faster one block per tile (measured).
+    static const int min_chunks = [] {
+        const char* e = getenv("SG_STREAMK_MINCHUNKS");
+        return e ? atoi(e) : 16;  // >= 16 chunks (K >= 512): tdnn4 / tdnn5 gain 4-12 %, tdnn1 (5 chunks) loses
+    }();
+    if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
     hipError_t e = hipMemsetAsync(flags, 0, 1024 * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
     dim3 grid(workers);

@@ -8,7 +8,7 @@
 //   c0 <- log-energy.
 //
 // One wave (64 lanes) owns one frame: the 400 samples are read coalesced from the waveform, the
-// 512-point FFT runs in LDS (radix-2 DIT, 9 stages, table twiddles), reductions use wavefront
+// 512-point FFT runs in LDS + registers (three radix-8 passes, table twiddles), reductions use wavefront
 // shuffles.  The FORWARD transform runs in fp64: a windowed speech frame has > 80 dB between its
 // strongest harmonic and the weak bins, and an fp32 FFT leaves a round-off floor of ~2e-7 of the
 // strongest bin on every bin -- a 1e-3 relative error on exactly the weak mel bands whose
@@ -18,16 +18,14 @@
 // against the oracle, whose own fp32-vs-fp64 noise is 0.03 %.
 // The backward kernel recomputes the forward of its frame (cheaper than storing 514 floats per
 // frame), then walks the stages in reverse; the spectrum gradient overwrites the spectrum in
-// place and is transformed back by a decimation-in-frequency pass with conjugate twiddles
-// (natural-order input, bit-reversed output -- no second buffer).  It writes per-frame sample
+// place and is transformed back by the same FFT with conjugate twiddles.  It writes per-frame sample
 // gradients (B,F,400); frames_to_wave_kernel does the deterministic overlap-add.
 #include "sg_internal.h"
 
 namespace sg {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kFramesPerWave = 4;
-constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
+constexpr int kMfccMaxBlocks = 512;  // 2 blocks (59 KB LDS each) per CU x 256 CUs
 
 struct FrameLds {
     double2 spec[kFft];  // FFT work buffer: spectrum, then (backward) its gradient; fp64, see header
@@ -42,6 +40,38 @@ struct FrameLds {
 // program order, so cross-lane hand-offs through LDS need no s_barrier -- only a fence that stops
 // the compiler from moving LDS accesses across it (a block-wide __syncthreads() here coupled the
 // four independent waves at ~25 points per frame).
+// Constant tables staged once per block into LDS: every per-frame table access was a dependent global
+// load (L1/L2 hit, but ~0.3 us of latency each with 2-3 waves per SIMD to hide it); the FFT twiddles
+// alone were 55 us of the 133 us forward kernel.
+struct TabLds {
+    double2 tw[256];
+    float window[kWin];
+    float dct[kMel * kCep];
+    float lifter[32];
+    int bin_m0[256];
+    float bin_w0[256];
+    float bin_w1[256];
+    int mel_lo[32];
+    int mel_hi[32];
+};
+
+__device__ __forceinline__ void stage_tables(const MfccTables& t, TabLds& tb) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        tb.tw[i] = t.twiddle[i];
+        tb.bin_m0[i] = t.bin_m0[i];
+        tb.bin_w0[i] = t.bin_w0[i];
+        tb.bin_w1[i] = t.bin_w1[i];
+    }
+    for (int i = threadIdx.x; i < kWin; i += blockDim.x) tb.window[i] = t.window[i];
+    for (int i = threadIdx.x; i < kMel * kCep; i += blockDim.x) tb.dct[i] = t.dct[i];
+    if (threadIdx.x < 32) {
+        tb.lifter[threadIdx.x] = threadIdx.x < kCep ? t.lifter[threadIdx.x] : 0.f;
+        tb.mel_lo[threadIdx.x] = threadIdx.x < kMel ? t.mel_lo[threadIdx.x] : 0;
+        tb.mel_hi[threadIdx.x] = threadIdx.x < kMel ? t.mel_hi[threadIdx.x] : 0;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -79,50 +109,89 @@ __device__ __forceinline__ float dither_draw(uint64_t seed, int64_t utt, int fra
     return sqrtf(-2.f * logf(u)) * cosf(6.283185307179586f * u) * dither;
 }
 
-// In-place radix-2 FFTs of 512 complex fp64 points held in LDS.  All four waves of the block run
-// them on its own buffer (wave-level sync per stage).
-// Forward: decimation in time, input scattered in bit-reversed order, output in natural order.
-__device__ __forceinline__ void fft512_dit(double2* buf, const double2* __restrict__ tw, int lane) {
-#pragma unroll 1
-    for (int s = 0; s < 9; ++s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = lane + 64 * i;
-            const int pos = j & (half - 1);
-            const int i0 = ((j >> s) << (s + 1)) + pos;
-            const int i1 = i0 + half;
-            const double2 w = tw[pos << (8 - s)];
-            const double2 a = buf[i0], b = buf[i1];
-            const double tr = b.x * w.x - b.y * w.y;
-            const double ti = b.x * w.y + b.y * w.x;
-            buf[i0] = make_double2(a.x + tr, a.y + ti);
-            buf[i1] = make_double2(a.x - tr, a.y - ti);
-        }
-        wave_sync();
+// 512-point complex FFT of one wave's private LDS buffer, fp64, natural order in and out.
+// 512 = 8 x 8 x 8: three passes of in-register radix-8 butterflies, one butterfly per lane and pass,
+// with an LDS exchange between passes (Cooley-Tukey, decimation in frequency):
+//   n = 64 n1 + n2,  k = k1 + 8 c + 64 d
+//   pass 1  lane n2       : DFT8 over n1, times W512^(n2 k1)          -> y[k1][n2]
+//   pass 2  lane (k1, b)  : DFT8 over a of y[k1][8a + b], times W64^(b c) -> z[k1][b][c]
+//   pass 3  lane (k1, c)  : DFT8 over b of z[k1][b][c]                 -> X[k1 + 8c + 64d]
+// 48 LDS accesses per lane instead of the 144 of a radix-2 network, and 6 wave-level fences instead
+// of 9 (measured on the MFCC forward kernel: FFT share 55 us -> see profiles/).
+// sgn = -1: forward transform; +1: unnormalised inverse (conjugate twiddles).
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by sgn * i
+__device__ __forceinline__ double2 cmuli(double2 a, double sgn) { return make_double2(-sgn * a.y, sgn * a.x); }
+
+#define SG_DFT8(a0, a1, a2, a3, a4, a5, a6, a7, sgn)                                               \
+    {                                                                                              \
+        const double h = 0.70710678118654752440;                                                   \
+        double2 b0 = cadd(a0, a4), b4 = csub(a0, a4), b1 = cadd(a1, a5), b5 = csub(a1, a5);        \
+        double2 b2 = cadd(a2, a6), b6 = csub(a2, a6), b3 = cadd(a3, a7), b7 = csub(a3, a7);        \
+        b5 = cmul(b5, make_double2(h, (sgn) * h));                                                 \
+        b6 = cmuli(b6, (sgn));                                                                     \
+        b7 = cmul(b7, make_double2(-h, (sgn) * h));                                                \
+        const double2 c0 = cadd(b0, b2), c2 = csub(b0, b2), c1 = cadd(b1, b3), c3 = cmuli(csub(b1, b3), (sgn)); \
+        const double2 c4 = cadd(b4, b6), c6 = csub(b4, b6), c5 = cadd(b5, b7), c7 = cmuli(csub(b5, b7), (sgn)); \
+        a0 = cadd(c0, c1); a1 = cadd(c4, c5); a2 = cadd(c2, c3); a3 = cadd(c6, c7);                \
+        a4 = csub(c0, c1); a5 = csub(c4, c5); a6 = csub(c2, c3); a7 = csub(c6, c7);                \
     }
+
+// W512^m, m in [0, 512), from the half-circle table tw[256] (W^(m+256) = -W^m); sgn = +1 conjugates
+__device__ __forceinline__ double2 tw512(const double2* __restrict__ tw, int m, double sgn) {
+    const double2 w = tw[m & 255];
+    const double f = (m & 256) ? -1.0 : 1.0;
+    return make_double2(f * w.x, -sgn * f * w.y);
 }
 
-// Inverse (conjugate twiddles, unnormalised): decimation in frequency, natural-order input,
-// output element n lands at buf[bitrev(n)].
-__device__ __forceinline__ void ifft512_dif(double2* buf, const double2* __restrict__ tw, int lane) {
-#pragma unroll 1
-    for (int s = 8; s >= 0; --s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = lane + 64 * i;
-            const int pos = j & (half - 1);
-            const int i0 = ((j >> s) << (s + 1)) + pos;
-            const int i1 = i0 + half;
-            const double2 w = tw[pos << (8 - s)];  // conj(w) = (w.x, -w.y)
-            const double2 a = buf[i0], b = buf[i1];
-            const double dx = a.x - b.x, dy = a.y - b.y;
-            buf[i0] = make_double2(a.x + b.x, a.y + b.y);
-            buf[i1] = make_double2(dx * w.x + dy * w.y, dy * w.x - dx * w.y);
-        }
+__device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
+    double2 v0, v1, v2, v3, v4, v5, v6, v7;
+    // ---- pass 1
+    v0 = buf[lane]; v1 = buf[64 + lane]; v2 = buf[128 + lane]; v3 = buf[192 + lane];
+    v4 = buf[256 + lane]; v5 = buf[320 + lane]; v6 = buf[384 + lane]; v7 = buf[448 + lane];
+    SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+    buf[lane] = v0;
+    buf[64 + lane] = cmul(v1, tw512(tw, lane, sgn));
+    buf[128 + lane] = cmul(v2, tw512(tw, 2 * lane, sgn));
+    buf[192 + lane] = cmul(v3, tw512(tw, 3 * lane, sgn));
+    buf[256 + lane] = cmul(v4, tw512(tw, 4 * lane, sgn));
+    buf[320 + lane] = cmul(v5, tw512(tw, 5 * lane, sgn));
+    buf[384 + lane] = cmul(v6, tw512(tw, 6 * lane, sgn));
+    buf[448 + lane] = cmul(v7, tw512(tw, 7 * lane, sgn));
+    wave_sync();
+    // ---- pass 2: lane = (k1, b)
+    {
+        const int k1 = lane >> 3, b = lane & 7;
+        const double2* r = buf + k1 * 64 + b;
+        v0 = r[0]; v1 = r[8]; v2 = r[16]; v3 = r[24]; v4 = r[32]; v5 = r[40]; v6 = r[48]; v7 = r[56];
         wave_sync();
+        SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+        double2* w = buf + k1 * 64 + 8 * b;  // z[k1][b][c]
+        w[0] = v0;
+        w[1] = cmul(v1, tw512(tw, 8 * b, sgn));
+        w[2] = cmul(v2, tw512(tw, 16 * b, sgn));
+        w[3] = cmul(v3, tw512(tw, 24 * b, sgn));
+        w[4] = cmul(v4, tw512(tw, 32 * b, sgn));
+        w[5] = cmul(v5, tw512(tw, 40 * b, sgn));
+        w[6] = cmul(v6, tw512(tw, 48 * b, sgn));
+        w[7] = cmul(v7, tw512(tw, 56 * b, sgn));
     }
+    wave_sync();
+    // ---- pass 3: lane = (k1, c)
+    {
+        const int k1 = lane >> 3, c = lane & 7;
+        const double2* r = buf + k1 * 64 + c;
+        v0 = r[0]; v1 = r[8]; v2 = r[16]; v3 = r[24]; v4 = r[32]; v5 = r[40]; v6 = r[48]; v7 = r[56];
+        wave_sync();
+        SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+        double2* w = buf + k1 + 8 * c;
+        w[0] = v0; w[64] = v1; w[128] = v2; w[192] = v3; w[256] = v4; w[320] = v5; w[384] = v6; w[448] = v7;
+    }
+    wave_sync();
 }
 
 struct FrameState {
@@ -131,7 +200,7 @@ struct FrameState {
 };
 
 // Forward of one frame up to the cepstra; leaves spectrum in L.spec, mel in L.mel, samples in L.samp.
-__device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, const float* __restrict__ x, int T,
+__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, FrameLds& L, const float* __restrict__ x, int T,
                                               int F, int b, int f, bool active, float scale, const sg_dither& dz,
                                               int lane, FrameState& st, float& cep_out) {
     const int base = f * kShift - (kWin / 2 - kShift / 2);
@@ -163,19 +232,19 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, 
     }
     st.energy = wave_sum(e);
     wave_sync();
-    // pre-emphasis (replicate pad on the left), povey window, bit-reversed scatter into the FFT buffer
+    // pre-emphasis (replicate pad on the left), povey window, zero-padded into the FFT buffer
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n = lane + 64 * i;
         float w = 0.f;
         if (n < kWin) {
             const float prev = L.samp[n > 0 ? n - 1 : 0];
-            w = (st.s[i < 7 ? i : 6] - 0.97f * prev) * t.window[n];
+            w = (st.s[i < 7 ? i : 6] - 0.97f * prev) * tb.window[n];
         }
-        L.spec[t.bitrev[n]] = make_double2((double)w, 0.0);
+        L.spec[n] = make_double2((double)w, 0.0);
     }
     wave_sync();
-    fft512_dit(L.spec, t.twiddle, lane);
+    if (!(t.ablate & 1)) fft512_r8(L.spec, tb.tw, lane, -1.0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
@@ -183,20 +252,30 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, FrameLds& L, 
         L.power[k] = (float)(c.x * c.x + c.y * c.y);
     }
     wave_sync();
-    if (lane < kMel) {
+    // 30 triangular mel filters, two lanes per filter (each sums half of the filter's bins); the weight
+    // of bin k in filter m is bin_w0[k] if m is the lower of the two filters covering k, else bin_w1[k]
+    if (!(t.ablate & 2)) {
+        const int m = lane >> 1, h = lane & 1;
         float acc = 0.f;
-        const int lo = t.mel_lo[lane], hi = t.mel_hi[lane];
-        for (int k = lo; k < hi; ++k) acc += L.power[k] * t.mel_w[lane * 256 + k];
-        L.mel[lane] = acc;
-        L.lmel[lane] = logf(fmaxf(acc, kEps));
+        if (m < kMel) {
+            const int lo = tb.mel_lo[m], hi = tb.mel_hi[m];
+            const int mid = lo + (hi - lo + 1) / 2;
+            for (int k = h ? mid : lo; k < (h ? hi : mid); ++k)
+                acc += L.power[k] * (tb.bin_m0[k] == m ? tb.bin_w0[k] : tb.bin_w1[k]);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        if (m < kMel && h == 0) {
+            L.mel[m] = acc;
+            L.lmel[m] = logf(fmaxf(acc, kEps));
+        }
     }
     wave_sync();
     cep_out = 0.f;
-    if (lane < kCep) {
+    if (lane < kCep && !(t.ablate & 2)) {
         float v = 0.f;
 #pragma unroll 6
-        for (int m = 0; m < kMel; ++m) v += L.lmel[m] * t.dct[m * kCep + lane];
-        v *= t.lifter[lane];
+        for (int m = 0; m < kMel; ++m) v += L.lmel[m] * tb.dct[m * kCep + lane];
+        v *= tb.lifter[lane];
         if (lane == 0) v = logf(fmaxf(st.energy, kEps));
         cep_out = v;
     }
@@ -206,16 +285,19 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
                                                        const float* __restrict__ scale_p, sg_dither dz,
                                                        float* __restrict__ feats) {
     __shared__ FrameLds lds[kWavesPerBlock];
+    __shared__ TabLds tb;
+    stage_tables(t, tb);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int b = blockIdx.y;
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLds& L = lds[wid];
-    for (int it = 0; it < kFramesPerWave; ++it) {
-        const int f = blockIdx.x * kFramesPerBlock + it * kWavesPerBlock + wid;
-        const bool active = f < F;
+    // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
+    const int total = B * F;
+    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += gridDim.x * kWavesPerBlock) {
+        const int b = gf / F, f = gf - b * F;
+        const bool active = true;
         FrameState st;
         float cep;
-        frame_forward(t, L, x, T, F, b, active ? f : 0, active, scale, dz, lane, st, cep);
+        frame_forward(t, tb, L, x, T, F, b, f, active, scale, dz, lane, st, cep);
         if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
@@ -228,29 +310,32 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
                                                        const float* __restrict__ dfeats, int ld,
                                                        float* __restrict__ dframes) {
     __shared__ FrameLds lds[kWavesPerBlock];
+    __shared__ TabLds tb;
+    stage_tables(t, tb);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int b = blockIdx.y;
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLds& L = lds[wid];
-    for (int it = 0; it < kFramesPerWave; ++it) {
-        const int f = blockIdx.x * kFramesPerBlock + it * kWavesPerBlock + wid;
-        const bool active = f < F;
+    // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
+    const int total = B * F;
+    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += gridDim.x * kWavesPerBlock) {
+        const int b = gf / F, f = gf - b * F;
+        const bool active = true;
         const int fa = active ? f : 0;
         FrameState st;
         float cep;
-        frame_forward(t, L, x, T, F, b, fa, active, scale, dz, lane, st, cep);
+        frame_forward(t, tb, L, x, T, F, b, fa, active, scale, dz, lane, st, cep);
         // ---- cepstra -> log-mel
         float dc = 0.f;
         if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];
         const float denergy = __shfl(dc, 0, 64);
-        if (lane < 32) L.tmp[lane] = (lane == 0 || lane >= kCep) ? 0.f : dc * t.lifter[lane];
+        if (lane < 32) L.tmp[lane] = (lane == 0 || lane >= kCep) ? 0.f : dc * tb.lifter[lane];
         wave_sync();
         if (lane < 32) {
             float dm = 0.f;
             if (lane < kMel) {
                 float dl = 0.f;
 #pragma unroll 6
-                for (int c = 0; c < kCep; ++c) dl += L.tmp[c] * t.dct[lane * kCep + c];
+                for (int c = 0; c < kCep; ++c) dl += L.tmp[c] * tb.dct[lane * kCep + c];
                 const float mel = L.mel[lane];
                 dm = mel > kEps ? dl / mel : 0.f;
             }
@@ -263,9 +348,9 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             const int k = lane + 64 * i;
             double2 g = make_double2(0.0, 0.0);
             if (k < 256) {
-                const int m0 = t.bin_m0[k];
+                const int m0 = tb.bin_m0[k];
                 if (m0 >= 0) {
-                    const double dp = 2.0 * (double)(L.lmel[m0] * t.bin_w0[k] + L.lmel[m0 + 1] * t.bin_w1[k]);
+                    const double dp = 2.0 * (double)(L.lmel[m0] * tb.bin_w0[k] + L.lmel[m0 + 1] * tb.bin_w1[k]);
                     const double2 c = L.spec[k];
                     g = make_double2(c.x * dp, c.y * dp);
                 }
@@ -273,12 +358,12 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             L.spec[k] = g;
         }
         wave_sync();
-        ifft512_dif(L.spec, t.twiddle, lane);
+        if (!(t.ablate & 1)) fft512_r8(L.spec, tb.tw, lane, 1.0);
         // ---- window, pre-emphasis, energy, DC removal
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int n = lane + 64 * i;
-            if (n < kWin) L.samp[n] = (float)L.spec[t.bitrev[n]].x * t.window[n];
+            if (n < kWin) L.samp[n] = (float)L.spec[n].x * tb.window[n];
         }
         wave_sync();
         float ds[7];
@@ -345,7 +430,8 @@ __global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __rest
 hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, float* feats, hipStream_t s) {
     sg_dither d = dz ? *dz : sg_dither{0.f, 0, 0, nullptr};
-    dim3 grid((F + kFramesPerBlock - 1) / kFramesPerBlock, B);
+    const int want = (B * F + kWavesPerBlock - 1) / kWavesPerBlock;
+    dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
     hipLaunchKernelGGL(mfcc_fwd_kernel, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, feats);
     return hipGetLastError();
 }
@@ -353,7 +439,8 @@ hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, in
 hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, const float* dfeats, float* dframes, hipStream_t s) {
     sg_dither d = dz ? *dz : sg_dither{0.f, 0, 0, nullptr};
-    dim3 grid((F + kFramesPerBlock - 1) / kFramesPerBlock, B);
+    const int want = (B * F + kWavesPerBlock - 1) / kWavesPerBlock;
+    dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
     hipLaunchKernelGGL(mfcc_bwd_kernel, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
     return hipGetLastError();
 }

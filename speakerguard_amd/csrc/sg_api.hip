@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sg_internal.h"
@@ -132,6 +133,10 @@ int build_tables(sg_ctx* ctx) {
         br[i] = (uint16_t)r;
     }
     MfccTables& t = ctx->tab;
+    {
+        const char* e = getenv("SG_MFCC_ABLATE");
+        t.ablate = e ? atoi(e) : 0;
+    }
     int rc = 0;
     rc |= dev_upload(ctx, ctx->model_allocs, &t.window, window);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_w, melw);

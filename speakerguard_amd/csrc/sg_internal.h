@@ -99,6 +99,7 @@ struct MfccTables {          // device pointers
     float* lifter;           // [30]
     double2* twiddle;        // [256] exp(-2 pi i k / 512), fp64 (forward FFT runs in fp64)
     uint16_t* bitrev;        // [512]
+    int ablate;              // timing experiments (SG_MFCC_ABLATE): 1 skip FFTs, 2 skip mel/DCT loops
 };
 
 struct XvModel {
