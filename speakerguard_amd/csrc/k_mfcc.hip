@@ -28,7 +28,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMfccMaxBlocks = 512;  // 2 blocks (59 KB LDS each) per CU x 256 CUs
 
 struct FrameLds {
-    double2 spec[kFft];  // FFT work buffer: spectrum, then (backward) its gradient; fp64, see header
+    double2 spec[kFft + kFft / 8];  // FFT work buffer (element i at SP(i)): spectrum, then its gradient; fp64
     float samp[kFft];    // DC-removed samples, later windowed-gradient
     float power[256];
     float mel[32];
@@ -41,8 +41,7 @@ struct FrameLds {
 // the compiler from moving LDS accesses across it (a block-wide __syncthreads() here coupled the
 // four independent waves at ~25 points per frame).
 // Constant tables staged once per block into LDS: every per-frame table access was a dependent global
-// load (L1/L2 hit, but ~0.3 us of latency each with 2-3 waves per SIMD to hide it); the FFT twiddles
-// alone were 55 us of the 133 us forward kernel.
+// load (L1/L2 hit, but ~0.3 us of latency each with only 2 waves per SIMD to hide it).
 struct TabLds {
     double2 tw[256];
     float window[kWin];
@@ -119,6 +118,12 @@ __device__ __forceinline__ float dither_draw(uint64_t seed, int64_t utt, int fra
 // 48 LDS accesses per lane instead of the 144 of a radix-2 network, and 6 wave-level fences instead
 // of 9 (measured on the MFCC forward kernel: FFT share 55 us -> see profiles/).
 // sgn = -1: forward transform; +1: unnormalised inverse (conjugate twiddles).
+// The work buffer keeps element i at SP(i) = i + i/8 (one 16-byte pad per 8 elements). ds_write_b128
+// is served in groups of 8 consecutive lanes over 32 banks (128 B): unpadded, the pass-2 and pass-3
+// scatters put all 8 lanes of a group on one bank slot (stride 128 B) -- 8x the LDS cycles, which made
+// the FFT ~1500 LDS cycles per frame and the whole kernel LDS-issue bound. With the pad every access
+// pattern below is conflict-free within its lane group.
+#define SP(i) ((i) + ((i) >> 3))
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -151,26 +156,26 @@ __device__ __forceinline__ double2 tw512(const double2* __restrict__ tw, int m, 
 __device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
     double2 v0, v1, v2, v3, v4, v5, v6, v7;
     // ---- pass 1
-    v0 = buf[lane]; v1 = buf[64 + lane]; v2 = buf[128 + lane]; v3 = buf[192 + lane];
-    v4 = buf[256 + lane]; v5 = buf[320 + lane]; v6 = buf[384 + lane]; v7 = buf[448 + lane];
+    double2* p1 = buf + SP(lane);  // SP(lane + 64 j) = SP(lane) + 72 j
+    v0 = p1[0]; v1 = p1[72]; v2 = p1[144]; v3 = p1[216]; v4 = p1[288]; v5 = p1[360]; v6 = p1[432]; v7 = p1[504];
     SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
-    buf[lane] = v0;
-    buf[64 + lane] = cmul(v1, tw512(tw, lane, sgn));
-    buf[128 + lane] = cmul(v2, tw512(tw, 2 * lane, sgn));
-    buf[192 + lane] = cmul(v3, tw512(tw, 3 * lane, sgn));
-    buf[256 + lane] = cmul(v4, tw512(tw, 4 * lane, sgn));
-    buf[320 + lane] = cmul(v5, tw512(tw, 5 * lane, sgn));
-    buf[384 + lane] = cmul(v6, tw512(tw, 6 * lane, sgn));
-    buf[448 + lane] = cmul(v7, tw512(tw, 7 * lane, sgn));
+    p1[0] = v0;
+    p1[72] = cmul(v1, tw512(tw, lane, sgn));
+    p1[144] = cmul(v2, tw512(tw, 2 * lane, sgn));
+    p1[216] = cmul(v3, tw512(tw, 3 * lane, sgn));
+    p1[288] = cmul(v4, tw512(tw, 4 * lane, sgn));
+    p1[360] = cmul(v5, tw512(tw, 5 * lane, sgn));
+    p1[432] = cmul(v6, tw512(tw, 6 * lane, sgn));
+    p1[504] = cmul(v7, tw512(tw, 7 * lane, sgn));
     wave_sync();
     // ---- pass 2: lane = (k1, b)
     {
         const int k1 = lane >> 3, b = lane & 7;
-        const double2* r = buf + k1 * 64 + b;
-        v0 = r[0]; v1 = r[8]; v2 = r[16]; v3 = r[24]; v4 = r[32]; v5 = r[40]; v6 = r[48]; v7 = r[56];
+        const double2* r = buf + k1 * 72 + b;  // SP(64 k1 + 8 a + b) = 72 k1 + 9 a + b
+        v0 = r[0]; v1 = r[9]; v2 = r[18]; v3 = r[27]; v4 = r[36]; v5 = r[45]; v6 = r[54]; v7 = r[63];
         wave_sync();
         SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
-        double2* w = buf + k1 * 64 + 8 * b;  // z[k1][b][c]
+        double2* w = buf + k1 * 72 + 9 * b;  // z[k1][b][c] at SP(64 k1 + 8 b + c)
         w[0] = v0;
         w[1] = cmul(v1, tw512(tw, 8 * b, sgn));
         w[2] = cmul(v2, tw512(tw, 16 * b, sgn));
@@ -184,12 +189,12 @@ __device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restric
     // ---- pass 3: lane = (k1, c)
     {
         const int k1 = lane >> 3, c = lane & 7;
-        const double2* r = buf + k1 * 64 + c;
-        v0 = r[0]; v1 = r[8]; v2 = r[16]; v3 = r[24]; v4 = r[32]; v5 = r[40]; v6 = r[48]; v7 = r[56];
+        const double2* r = buf + k1 * 72 + c;
+        v0 = r[0]; v1 = r[9]; v2 = r[18]; v3 = r[27]; v4 = r[36]; v5 = r[45]; v6 = r[54]; v7 = r[63];
         wave_sync();
         SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
-        double2* w = buf + k1 + 8 * c;
-        w[0] = v0; w[64] = v1; w[128] = v2; w[192] = v3; w[256] = v4; w[320] = v5; w[384] = v6; w[448] = v7;
+        double2* w = buf + k1 + 9 * c;  // SP(k1 + 8 c + 64 d) = k1 + 9 c + 72 d
+        w[0] = v0; w[72] = v1; w[144] = v2; w[216] = v3; w[288] = v4; w[360] = v5; w[432] = v6; w[504] = v7;
     }
     wave_sync();
 }
@@ -199,20 +204,33 @@ struct FrameState {
     float energy;    // sum of squares (before log)
 };
 
+// Raw samples of global frame gf (reflect-padded, snip_edges=False), sample n = lane + 64 i -> raw[i].
+// Issued one frame ahead of use so the ~1 us global latency overlaps the previous frame's FFT.
+__device__ __forceinline__ void load_frame(const float* __restrict__ x, int T, int F, int gf, int total, int lane,
+                                           float (&raw)[7]) {
+    const int g = gf < total ? gf : total - 1;
+    const int b = g / F, f = g - b * F;
+    const int base = f * kShift - (kWin / 2 - kShift / 2);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int n = lane + 64 * i;
+        const int p = base + (n < kWin ? n : kWin - 1);
+        const int idx = p < 0 ? -p - 1 : (p >= T ? 2 * T - 1 - p : p);
+        raw[i] = x[(size_t)b * T + idx];
+    }
+}
+
 // Forward of one frame up to the cepstra; leaves spectrum in L.spec, mel in L.mel, samples in L.samp.
-__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, FrameLds& L, const float* __restrict__ x, int T,
+__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, FrameLds& L, const float (&raw)[7],
                                               int F, int b, int f, bool active, float scale, const sg_dither& dz,
                                               int lane, FrameState& st, float& cep_out) {
-    const int base = f * kShift - (kWin / 2 - kShift / 2);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int n = lane + 64 * i;
         float v = 0.f;
         if (active && n < kWin) {
-            const int p = base + n;
-            const int idx = p < 0 ? -p - 1 : (p >= T ? 2 * T - 1 - p : p);
-            v = x[(size_t)b * T + idx] * scale;
+            v = raw[i] * scale;
             if (dz.noise_dev) v += dz.noise_dev[((size_t)b * F + f) * kWin + n];
             else if (dz.dither != 0.f) v += dither_draw(dz.seed, dz.index_base + b, f, n, dz.dither);
         }
@@ -241,14 +259,14 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
             const float prev = L.samp[n > 0 ? n - 1 : 0];
             w = (st.s[i < 7 ? i : 6] - 0.97f * prev) * tb.window[n];
         }
-        L.spec[n] = make_double2((double)w, 0.0);
+        L.spec[SP(n)] = make_double2((double)w, 0.0);
     }
     wave_sync();
     if (!(t.ablate & 1)) fft512_r8(L.spec, tb.tw, lane, -1.0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
-        const double2 c = L.spec[k];
+        const double2 c = L.spec[SP(k)];
         L.power[k] = (float)(c.x * c.x + c.y * c.y);
     }
     wave_sync();
@@ -291,13 +309,18 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLds& L = lds[wid];
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
-    const int total = B * F;
-    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += gridDim.x * kWavesPerBlock) {
+    const int total = B * F, stride = gridDim.x * kWavesPerBlock;
+    float raw[7], nxt[7];
+    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt);
+    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
         const bool active = true;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
+        load_frame(x, T, F, gf + stride, total, lane, nxt);
         FrameState st;
         float cep;
-        frame_forward(t, tb, L, x, T, F, b, f, active, scale, dz, lane, st, cep);
+        frame_forward(t, tb, L, raw, F, b, f, active, scale, dz, lane, st, cep);
         if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
@@ -316,14 +339,19 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLds& L = lds[wid];
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
-    const int total = B * F;
-    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += gridDim.x * kWavesPerBlock) {
+    const int total = B * F, stride = gridDim.x * kWavesPerBlock;
+    float raw[7], nxt[7];
+    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt);
+    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
         const bool active = true;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
+        load_frame(x, T, F, gf + stride, total, lane, nxt);
         const int fa = active ? f : 0;
         FrameState st;
         float cep;
-        frame_forward(t, tb, L, x, T, F, b, fa, active, scale, dz, lane, st, cep);
+        frame_forward(t, tb, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
         // ---- cepstra -> log-mel
         float dc = 0.f;
         if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];
@@ -351,11 +379,11 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
                 const int m0 = tb.bin_m0[k];
                 if (m0 >= 0) {
                     const double dp = 2.0 * (double)(L.lmel[m0] * tb.bin_w0[k] + L.lmel[m0 + 1] * tb.bin_w1[k]);
-                    const double2 c = L.spec[k];
+                    const double2 c = L.spec[SP(k)];
                     g = make_double2(c.x * dp, c.y * dp);
                 }
             }
-            L.spec[k] = g;
+            L.spec[SP(k)] = g;
         }
         wave_sync();
         if (!(t.ablate & 1)) fft512_r8(L.spec, tb.tw, lane, 1.0);
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int n = lane + 64 * i;
-            if (n < kWin) L.samp[n] = (float)L.spec[n].x * tb.window[n];
+            if (n < kWin) L.samp[n] = (float)L.spec[SP(n)].x * tb.window[n];
         }
         wave_sync();
         float ds[7];
