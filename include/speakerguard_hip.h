@@ -254,6 +254,22 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
 int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters,
                      float* ms_per_launch, double* flops, int32_t* tile_rows, void* stream);
 
+/* ---- the convolution primitive on caller buffers ------------------------------------------------
+ * Dilated 1-D convolution / its data gradient on channel-last rows, the contraction behind
+ * torch.nn.functional.conv1d in model/_xv_plda/xvecTDNN.py:16-33,49-53 and behind autograd's conv
+ * input-gradient (adaptive_attack/EOT.py:35), exposed so the MFMA kernels can be checked in isolation:
+ *
+ *   C[b*Tc + t][n] = epi( sum_{j < taps} sum_{c < Kc} A[b*Ta + t + tap_base + j*tap_step][c] * W[j*Kc + c][n] )
+ *
+ * rows outside [0, Ta) of an utterance contribute zero.  A: (B*Ta, Kc) floats, W: (taps*Kc, N), C: (B*Tc, N);
+ * Kc % 32 == 0, N % 128 == 0.  epi: 0 none, 1 relu(acc + bias[n]), 2 acc where mask[row][n] > 0 else 0
+ * (mask shaped like C).  kernel: 0 = what the TDNN layers get (stream-K 128x128 quad-fed kernel when the
+ * shape qualifies, else one 64x128 block per tile), 1 = force one block per tile, 2 = stream-K with the
+ * b32-fed 8-wave kernel.  All choices give bit-identical results. */
+int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c_dev, const float* bias_dev,
+                   const float* mask_dev, int32_t B, int32_t Ta, int32_t Tc, int32_t Kc, int32_t N, int32_t taps,
+                   int32_t tap_step, int32_t tap_base, int32_t epi, int32_t kernel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,8 +145,12 @@ __device__ __forceinline__ void gemm_segment(const ConvGemmArgs& p, float* smem,
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         __builtin_amdgcn_sched_barrier(0);
-        const float* a_s = As + buf * BK * BM + lhi * BM + a_rd;
-        const float* b_s = Bs + buf * BK * BN + lhi * BN + b_rd;
+        // k order shared by every kernel in this file (so results do not depend on which one runs):
+        // MFMA step ks = 4 kg + s consumes k = 8 kg + 4 lhi + s -- see gemm_segment8q, whose 16-byte
+        // operand reads dictate it.  KROW(ks) is the k-row of lane half 0.
+#define KROW(ks) (8 * ((ks) >> 2) + ((ks) & 3))
+        const float* a_s = As + buf * BK * BM + lhi * 4 * BM + a_rd;
+        const float* b_s = Bs + buf * BK * BN + lhi * 4 * BN + b_rd;
         // register double-buffered operand fetch: the ds_reads of k-step ks+1 are issued before the
         // MFMAs of ks, so their LDS latency hides under MI*NI x 64 cycles of matrix pipe
         float av[2][MI], bv[2][NI];
@@ -158,9 +162,9 @@ __device__ __forceinline__ void gemm_segment(const ConvGemmArgs& p, float* smem,
         for (int ks = 0; ks < BK / 2; ++ks) {
             if (ks + 1 < BK / 2) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) av[(ks + 1) & 1][mi] = a_s[(ks + 1) * 2 * BM + mi * 32];
+                for (int mi = 0; mi < MI; ++mi) av[(ks + 1) & 1][mi] = a_s[KROW(ks + 1) * BM + mi * 32];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bv[(ks + 1) & 1][ni] = b_s[(ks + 1) * 2 * BN + ni * 32];
+                for (int ni = 0; ni < NI; ++ni) bv[(ks + 1) & 1][ni] = b_s[KROW(ks + 1) * BN + ni * 32];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -267,8 +271,8 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         __builtin_amdgcn_sched_barrier(0);
-        const float* a_s = As + buf * BK * BM + lhi * BM + a_rd;
-        const float* b_s = Bs + buf * BK * BN + lhi * BN + b_rd;
+        const float* a_s = As + buf * BK * BM + lhi * 4 * BM + a_rd;
+        const float* b_s = Bs + buf * BK * BN + lhi * 4 * BN + b_rd;
         float av[2][2], bv[2];
         av[0][0] = a_s[0];
         av[0][1] = a_s[32];
@@ -276,9 +280,9 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             if (ks + 1 < BK / 2) {
-                av[(ks + 1) & 1][0] = a_s[(ks + 1) * 2 * BM];
-                av[(ks + 1) & 1][1] = a_s[(ks + 1) * 2 * BM + 32];
-                bv[(ks + 1) & 1] = b_s[(ks + 1) * 2 * BN];
+                av[(ks + 1) & 1][0] = a_s[KROW(ks + 1) * BM];
+                av[(ks + 1) & 1][1] = a_s[KROW(ks + 1) * BM + 32];
+                bv[(ks + 1) & 1] = b_s[KROW(ks + 1) * BN];
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][0], bv[ks & 1], acc[0][0], 0, 0, 0);
@@ -289,6 +293,152 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
                 if (c + 2 < c_end && !(p.ablate & 1)) load_chunk(c + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (!(p.ablate & 4)) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 8-wave 128 x 128 tile, quad-fed: every MFMA operand fetch is one ds_read_b128 that serves FOUR
+// k-steps (12 LDS instructions per 32 MFMAs instead of 32), and staging is a plain 16-byte copy.
+//
+// Why: on gfx950 the f32 MFMA shares its issue/datapath with the VALU -- tools/native/mfma_mix.hip
+// measures ~4.7 matrix-pipe cycles lost per VALU instruction and ~7 per ds_read_b32 issued by ANY
+// wave of the SIMD, while a b128-fed loop runs at 154 of 157 TFLOP/s.  The b32-fed loop above plus
+// its register transposes / zero-selects tops out near 120.
+//
+// How: the two k-values an MFMA step consumes may be ANY two of the chunk as long as A and W agree.
+// Step s of k-group kg takes k = 8 kg + 4 lhi + s (lhi = lane / 32), so a lane's A operands of steps
+// s = 0..3 are 4 consecutive floats of its row (activations stay row-major in LDS, no transpose) and
+// its W operands are 4 consecutive k of its column, contiguous because the weights are pre-packed
+// k4-major at load time (Wq[k/4][n][k%4]).
+// LDS image: A[128 rows][8 slots of 16 B], slot c of row r stored at c ^ ((r >> 1) & 7): conflict-free
+// for the 16-lane groups ds_read_b128 is served in and for the 8-lane groups of ds_write_b128;
+// W[8 k4-groups][128 n][4].  Out-of-range tap rows are zero-filled by the buffer-load bounds check
+// instead of being zeroed in registers.
+__device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+                                               int c_end, f32x16 (&acc)[2][1]) {
+    constexpr int BM = 128, BN = 128;
+    float* As = smem;                 // [2][BM][32]
+    float* Bs = smem + 2 * BK * BM;   // [2][8][BN][4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const bool role_a = wid < 4;
+    const int ts = tid & 255;
+
+    // Staging loads are raw buffer loads: address = descriptor base + per-lane byte offset (VGPR) + a
+    // wave-uniform byte offset (SGPR).  The K position inside a tap goes into the SGPR, so a chunk's four
+    // loads cost no VALU at all; a lane whose tap row falls outside its utterance (or whose row is past M)
+    // carries an out-of-range VGPR offset and the hardware returns zeros.  Per-lane offsets are rebuilt
+    // only when the chunk stream moves to the next tap.
+    constexpr unsigned kOob = 0x80000000u;
+    const int kchunks = p.Kc / BK;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        role_a ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000)
+               : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
+    unsigned row_off[4];  // A role: byte offset of (row, tap 0, k = 4 c4); W role: byte offset in the chunk image
+    int a_t[4];
+    int st_off;  // LDS float offset of this thread's first staged float4 (the others: + i * 1024)
+    if (role_a) {
+        const int c4 = ts & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + (ts >> 3) + 32 * i;
+            const int b = r / p.Tc;
+            const int t = r - b * p.Tc;
+            row_off[i] = (unsigned)(((b * p.Ta + t) * p.lda + c4 * 4) * 4);
+            a_t[i] = r < p.M ? t : -(1 << 28);
+        }
+        st_off = (ts >> 3) * 32 + ((c4 ^ ((ts >> 4) & 7)) << 2);  // row stride 32 floats; rows + 32 i keep the swizzle
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            row_off[i] = (unsigned)((((ts >> 7) + 2 * i) * p.ldw + n0 + (ts & 127)) * 16);
+            a_t[i] = 0;
+        }
+        st_off = 2 * BK * BM + ts * 4;  // group (ts >> 7) + 2 i -> + i * 1024 floats
+    }
+    // load stream state (chunks are requested in increasing order)
+    int ld_j = c_begin / kchunks;
+    int ld_kc = (c_begin - ld_j * kchunks) * BK;
+    unsigned voff[4];
+    auto set_tap = [&](int j) {
+        const int off = p.tap_base + j * p.tap_step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool okv = (unsigned)(a_t[i] + off) < (unsigned)p.Ta;
+            voff[i] = !role_a ? row_off[i] : okv ? row_off[i] + (unsigned)(off * p.lda * 4) : kOob;
+        }
+    };
+    set_tap(ld_j);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 r0, r1, r2, r3;
+    auto load_chunk = [&]() {
+        // W role: all taps are one contiguous k range -> everything in the SGPR offset
+        const int soff = role_a ? ld_kc * 4 : (ld_j * p.Kc + ld_kc) * p.ldw * 4;
+        r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[0], soff, 0);
+        r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[1], soff, 0);
+        r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2], soff, 0);
+        r3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[3], soff, 0);
+        ld_kc += BK;
+        if (ld_kc == p.Kc) {
+            ld_kc = 0;
+            ++ld_j;
+            if (role_a) set_tap(ld_j);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* d = smem + st_off + buf * BK * BM;  // both operand stages are BK*BM = BK*BN floats
+        *reinterpret_cast<i32x4*>(d + 0 * 1024) = r0;
+        *reinterpret_cast<i32x4*>(d + 1 * 1024) = r1;
+        *reinterpret_cast<i32x4*>(d + 2 * 1024) = r2;
+        *reinterpret_cast<i32x4*>(d + 3 * 1024) = r3;
+    };
+    if (c_begin < c_end) {
+        load_chunk();
+        store_chunk(0);
+        if (c_begin + 1 < c_end) load_chunk();
+    }
+    __syncthreads();
+    const int sw = (l31 >> 1) & 7;
+    const int a_row = (wm * 64 + l31) * 32;
+    const int b_col = (lhi * BN + wn * 32 + l31) * 4;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* a_s = As + buf * BK * BM + a_row;
+        const float* b_s = Bs + buf * BK * BN + b_col;
+        float4 a0 = *reinterpret_cast<const float4*>(a_s + ((lhi ^ sw) << 2));
+        float4 a1 = *reinterpret_cast<const float4*>(a_s + 32 * 32 + ((lhi ^ sw) << 2));
+        float4 b0 = *reinterpret_cast<const float4*>(b_s);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            float4 na0, na1, nb0;
+            if (kg < 3) {
+                const int slot = (((kg + 1) * 2 + lhi) ^ sw) << 2;
+                na0 = *reinterpret_cast<const float4*>(a_s + slot);
+                na1 = *reinterpret_cast<const float4*>(a_s + 32 * 32 + slot);
+                nb0 = *reinterpret_cast<const float4*>(b_s + (kg + 1) * 2 * BN * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg == 1) {
+                if (c + 1 < c_end && !(p.ablate & 2)) store_chunk(buf ^ 1);
+                if (c + 2 < c_end && !(p.ablate & 1)) load_chunk();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kg < 3) { a0 = na0; a1 = na1; b0 = nb0; }
         }
         if (!(p.ablate & 4)) __syncthreads();
     }
@@ -380,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 // The waiting side always has the higher block index, so under in-order dispatch the block it
 // waits for is resident or already finished.  Hand-off = agent-scope release/acquire on one flag
 // per worker (cdna guide G16); flags are zeroed by a memset node in front of every launch.
-template <int EPI, bool W8>
+template <int EPI, bool W8, bool QUAD>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                    int iters_per_worker, float* slabs,
                                                                    unsigned* flags) {
@@ -397,7 +547,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1) {
-        if constexpr (W8) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
+        if constexpr (W8 && QUAD) gemm_segment8q(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (W8) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
         else gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, c0, c1, acc);
     };
     auto frag = [&](int mi, int ni, int e) { return (((wid * MI + mi) * NI + ni) * 16 + e) * 64 + lane; };
@@ -516,10 +667,12 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     if (e != hipSuccess) return e;
     dim3 grid(workers);
 #define SG_SK(EPI)                                                                                              \
-    if (w8) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw, \
-                               slabs, flags);                                                                   \
-    else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false>), grid, dim3(256), 0, s, a, ntiles, tiles, ipw,   \
-                            slabs, flags);
+    if (w8 && a.Wq) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true, true>), grid, dim3(512), 0, s, a, ntiles, \
+                                       tiles, ipw, slabs, flags);                                               \
+    else if (w8) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true, false>), grid, dim3(512), 0, s, a, ntiles,   \
+                                    tiles, ipw, slabs, flags);                                                  \
+    else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false, false>), grid, dim3(256), 0, s, a, ntiles, tiles,   \
+                            ipw, slabs, flags);
     switch (epi) {
         case EPI_NONE: SG_SK(EPI_NONE) break;
         case EPI_BIAS_RELU: SG_SK(EPI_BIAS_RELU) break;
@@ -546,6 +699,19 @@ static int pick_height(int M, int ntiles) {
     return 64;
 }
 
+__global__ void pack_k4_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ wq) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)K * N) return;
+    const int k = (int)(i / N), n = (int)(i % N);
+    wq[((size_t)(k >> 2) * N + n) * 4 + (k & 3)] = w[i];
+}
+
+hipError_t launch_pack_k4(const float* w, int K, int N, float* wq, hipStream_t s) {
+    const size_t n = (size_t)K * N;
+    hipLaunchKernelGGL(pack_k4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, K, N, wq);
+    return hipGetLastError();
+}
+
 int conv_gemm_tile_rows(int M, int N) { return pick_height(M, N / 128); }
 
 hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int splits, hipStream_t s) {
@@ -559,11 +725,18 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     }();
     ConvGemmArgs a = a_in;
     a.ablate = ablate;
+    static const int use_quad = [] {
+        const char* e = getenv("SG_QUADFEED");  // 0 = b32-fed 8-wave kernel even when packed weights exist
+        return e ? atoi(e) : 1;
+    }();
+    if (!use_quad || a.force == 2 || (a.ldw % 4) || (a.Kc % 4)) a.Wq = nullptr;
+    a.a_bytes = (unsigned)((size_t)(a.M / a.Tc) * a.Ta * a.lda * sizeof(float));
+    a.w_bytes = (unsigned)((size_t)a.taps * a.Kc * a.ldw * sizeof(float));
     if (a.Kc % BK != 0 || a.M <= 0) return hipErrorInvalidValue;
     switch (tile) {
         case 0: {
             if (a.N % 128) return hipErrorInvalidValue;
-            if (splits == 1 && use_streamk) {
+            if (splits == 1 && use_streamk && a.force != 1) {
                 const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
                 if (e != hipErrorNotSupported) return e;
             }

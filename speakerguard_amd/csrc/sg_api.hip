@@ -46,6 +46,16 @@ int dev_upload(sg_ctx* ctx, std::vector<void*>& pool, T** out, const std::vector
     return SG_OK;
 }
 
+// [K][N] row-major -> k4-major [K/4][N][4] (Wq[k/4][n][k%4]): four consecutive k of one column become one
+// 16-byte LDS read in the quad-fed GEMM (k_conv_gemm.hip); K is padded up to a multiple of 4 with zeros.
+std::vector<float> pack_k4(const std::vector<float>& w, int K, int N) {
+    const int K4 = (K + 3) / 4;
+    std::vector<float> q((size_t)K4 * N * 4, 0.f);
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) q[((size_t)(k / 4) * N + n) * 4 + (k & 3)] = w[(size_t)k * N + n];
+    return q;
+}
+
 void free_pool(std::vector<void*>& pool) {
     for (void* p : pool) (void)hipFree(p);
     pool.clear();
@@ -238,6 +248,7 @@ ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
     ConvGemmArgs a{};
     a.A = l == 0 ? w.feats : w.act[l - 1];
     a.W = ctx->xv.wf[l];
+    a.Wq = ctx->xv.wfq[l];
     a.C = w.act[l];
     a.bias = ctx->xv.bias[l];
     a.mask = nullptr;
@@ -294,7 +305,8 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         ConvGemmArgs a{};
         a.A = w.dact[l];
         a.W = ctx->xv.wb[l];
-        a.C = l == 0 ? w.dfeats : w.dact[l - 1];
+        a.Wq = ctx->xv.wbq[l];
+            a.C = l == 0 ? w.dfeats : w.dact[l - 1];
         a.bias = nullptr;
         a.mask = l == 0 ? nullptr : w.act[l - 1];
         a.Ta = w.Fl[l];
@@ -457,6 +469,8 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
         }
         rc |= dev_upload(ctx, pool, &m.wf[l], wf);
         rc |= dev_upload(ctx, pool, &m.wb[l], wb);
+        rc |= dev_upload(ctx, pool, &m.wfq[l], pack_k4(wf, k * cip, cop));
+        rc |= dev_upload(ctx, pool, &m.wbq[l], pack_k4(wb, k * cop, cip));
         rc |= dev_upload(ctx, pool, &m.bias[l], bias);
         r_prev.assign(cout, 0.0);
         m_prev.assign(cout, 0.0);
@@ -705,6 +719,32 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     return SG_OK;
 }
 
+int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c_dev, const float* bias_dev,
+                   const float* mask_dev, int32_t B, int32_t Ta, int32_t Tc, int32_t Kc, int32_t N, int32_t taps,
+                   int32_t tap_step, int32_t tap_base, int32_t epi, int32_t kernel, void* stream) {
+    if (!ctx) return SG_ERR_ARG;
+    if (!a_dev || !w_dev || !c_dev || B <= 0 || Ta <= 0 || Tc <= 0 || taps <= 0 || Kc <= 0 || Kc % 32 || N <= 0 || N % 128)
+        return fail(ctx, SG_ERR_ARG, "sg_conv1d_rows: need Kc %% 32 == 0 and N %% 128 == 0 (got Kc=%d N=%d)", Kc, N);
+    if (epi < 0 || epi > 2 || (epi == 1 && !bias_dev) || (epi == 2 && !mask_dev) || kernel < 0 || kernel > 2)
+        return fail(ctx, SG_ERR_ARG, "sg_conv1d_rows: bad epi/kernel");
+    if (build_tables(ctx) != SG_OK) return SG_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    float* wq = nullptr;
+    SG_HIP(hipMalloc(reinterpret_cast<void**>(&wq), (size_t)taps * Kc * N * sizeof(float)));
+    hipError_t e = launch_pack_k4(w_dev, taps * Kc, N, wq, s);
+    ConvGemmArgs a{};
+    a.A = a_dev; a.W = w_dev; a.Wq = wq; a.C = c_dev; a.bias = bias_dev; a.mask = mask_dev;
+    a.M = B * Tc; a.N = N; a.Ta = Ta; a.Tc = Tc; a.Kc = Kc; a.lda = Kc; a.ldw = N; a.ldc = N;
+    a.taps = taps; a.tap_step = tap_step; a.tap_base = tap_base;
+    a.total_chunks = taps * (Kc / 32); a.chunks_per_split = a.total_chunks;
+    a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.force = kernel;
+    if (e == hipSuccess) e = launch_conv_gemm(a, 0, epi, 1, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(wq);
+    if (e != hipSuccess) return fail(ctx, SG_ERR_HIP, "sg_conv1d_rows: %s", hipGetErrorString(e));
+    return SG_OK;
+}
+
 int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters, float* ms_per_launch,
                      double* flops, int32_t* tile_rows, void* stream) {
     if (!ctx || !ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no model loaded");
@@ -720,7 +760,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
     int tile = 0, epi = EPI_BIAS_RELU, splits = 1;
     if (layer < 0) {  // data-gradient contraction of the same layer (reads d(out), writes d(in))
         a = ConvGemmArgs{};
-        a.A = w.dact[l]; a.W = ctx->xv.wb[l]; a.C = l == 0 ? w.dfeats : w.dact[l - 1];
+        a.A = w.dact[l]; a.W = ctx->xv.wb[l]; a.Wq = ctx->xv.wbq[l]; a.C = l == 0 ? w.dfeats : w.dact[l - 1];
         a.mask = l == 0 ? nullptr : w.act[l - 1];
         a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
         a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];

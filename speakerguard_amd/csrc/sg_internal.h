@@ -110,6 +110,8 @@ struct XvModel {
     // folded TDNN weights, GEMM layouts
     float* wf[kLayers] = {};    // forward  [taps*CinPad][CoutPad]
     float* wb[kLayers] = {};    // backward [taps*CoutPad][CinPad]
+    float* wfq[kLayers] = {};   // wf packed k4-major [taps*CinPad/4][CoutPad][4] (quad-fed GEMM)
+    float* wbq[kLayers] = {};   // wb packed k4-major
     float* bias[kLayers] = {};  // [CoutPad] folded
     float* fc1_w = nullptr;     // [kStats][512] folded (K-major)
     float* fc1_wt = nullptr;    // [512][kStats] folded (for the backward GEMM)
@@ -177,6 +179,8 @@ enum Epilogue { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_RELU_MASK = 2 };
 struct ConvGemmArgs {
     const float* A;     // activations [B*Ta][lda]
     const float* W;     // weights [taps*Kc][ldw]
+    const float* Wq;    // same weights packed k4-major [taps*Kc/4][ldw][4] (null: b32-fed kernels only)
+    unsigned a_bytes, w_bytes;  // extents of A and W for the buffer descriptors (filled by launch_conv_gemm)
     float* C;           // output [B*Tc][ldc] (+ z*split_stride for split-K partials)
     const float* bias;  // [N]            (EPI_BIAS_RELU)
     const float* mask;  // [B*Tc][ldc]    (EPI_RELU_MASK: keep where mask > 0)
@@ -188,6 +192,7 @@ struct ConvGemmArgs {
     int tap_base;
     int total_chunks, chunks_per_split;
     long long split_stride;
+    int force;          // 0 auto, 1 one block per tile, 2 stream-K with the b32-fed 8-wave kernel (parity tests)
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags
@@ -195,7 +200,9 @@ struct ConvGemmArgs {
 
 // tile: 0 = 128x128 (2x2 waves), 1 = 128x32 (4x1 waves), 2 = 64x128 (2x2 waves)
 hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s);
-int conv_gemm_tile_rows(int M, int N);  // tile height launch_conv_gemm(tile 0) picks
+int conv_gemm_tile_rows(int M, int N);
+// [K][N] row-major -> k4-major [K/4][N][4] on the device (K % 4 == 0)
+hipError_t launch_pack_k4(const float* w, int K, int N, float* wq, hipStream_t s);  // tile height launch_conv_gemm(tile 0) picks
 
 // mode 0: xv_plda ('origin': [-1,1] -> x32768), mode 1: AudioNet ('scale': int16 range -> /32768)
 hipError_t launch_input_scale(const float* x, int64_t n, float* scratch512, float* scale, int mode, hipStream_t s);

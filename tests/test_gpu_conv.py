@@ -1,0 +1,102 @@
+"""The implicit-GEMM convolution kernels in isolation (C-ABI sg_conv1d_rows) against the numpy oracle.
+
+Every launch strategy (one block per tile, stream-K with the b32-fed 8-wave kernel, stream-K with the
+quad-fed kernel the TDNN layers use) must give BIT-IDENTICAL results -- that is what makes a batch shard
+reproduce the unsharded batch exactly -- and all must agree with the float64 oracle to fp32 accumulation error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.conv_rows import conv1d_rows, conv1d_torch_layout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from speakerguard_amd import _native as N
+    return N.Context()
+
+
+def _run(ctx, a, w, B, Ta, Tc, taps, step, base, epi, kernel, bias=None, mask=None):
+    from speakerguard_amd import _native as N
+    dev = torch.device("cuda:0")
+    Kc, n = a.shape[1], w.shape[1]
+    ta, tw = torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev)
+    tb = torch.from_numpy(bias).to(dev) if bias is not None else None
+    tm = torch.from_numpy(mask).to(dev) if mask is not None else None
+    out = torch.full((B * Tc, n), float("nan"), device=dev)
+    ctx.call("sg_conv1d_rows", N._ptr(ta), N._ptr(tw), N._ptr(out), N._ptr(tb) if tb is not None else None,
+             N._ptr(tm) if tm is not None else None, B, Ta, Tc, Kc, n, taps, step, base, epi, kernel,
+             N.current_stream_ptr(dev))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _case(seed, B, Ta, Tc, Kc, n, taps):
+    rng = np.random.RandomState(seed)
+    a = rng.standard_normal((B * Ta, Kc)).astype(np.float32)
+    w = (rng.standard_normal((taps * Kc, n)) / np.sqrt(taps * Kc)).astype(np.float32)
+    return a, w
+
+
+# (B, Ta, Tc, Kc, N, taps, step, base): the two big ones qualify for stream-K (>= 512 tiles of 128x128)
+SHAPES = [
+    pytest.param((64, 270, 266, 192, 512, 3, 2, 0), id="fwd_streamk_dil2"),
+    pytest.param((64, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_edges"),
+    pytest.param((3, 50, 46, 64, 128, 5, 1, 0), id="fwd_small_ragged_tile"),
+    pytest.param((2, 40, 46, 96, 256, 3, -3, 0), id="dgrad_small"),
+    pytest.param((5, 33, 33, 32, 128, 3, 1, -1), id="same_padding_tap_base"),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
+    B, Ta, Tc, Kc, n, taps, step, base = shape
+    a, w = _case(7, B, Ta, Tc, Kc, n, taps)
+    want = conv1d_rows(a, w, B, Ta, Tc, taps, step, base)
+    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2)]
+    scale = np.abs(want).max()
+    for k, o in enumerate(outs):
+        assert np.isfinite(o).all(), "kernel %d left rows unwritten" % k
+        err = np.abs(o - want).max() / scale
+        assert err < 2e-5, "kernel %d: rel err %.3e" % (k, err)  # fp32 accumulation over K <= 576
+    assert np.array_equal(outs[0], outs[1]), "quad-fed stream-K differs from the tile launch"
+    assert np.array_equal(outs[2], outs[1]), "b32-fed stream-K differs from the tile launch"
+
+
+def test_conv_rows_epilogues(ctx):
+    B, Ta, Tc, Kc, n, taps, step = 64, 270, 266, 192, 512, 3, 2
+    a, w = _case(11, B, Ta, Tc, Kc, n, taps)
+    rng = np.random.RandomState(3)
+    bias = rng.standard_normal(n).astype(np.float32)
+    mask = (rng.standard_normal((B * Tc, n)) > 0).astype(np.float32) * rng.rand(B * Tc, n).astype(np.float32)
+    for epi, kw in ((1, dict(bias=bias)), (2, dict(mask=mask))):
+        want = conv1d_rows(a, w, B, Ta, Tc, taps, step, 0, **kw)
+        o0 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 0, **kw)
+        o1 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 1, **kw)
+        assert np.abs(o0 - want).max() / np.abs(want).max() < 2e-5
+        assert np.array_equal(o0, o1)
+
+
+def test_conv_rows_is_torch_conv1d(ctx):
+    """The row formulation equals torch.nn.functional.conv1d (CPU, float64) on the reference's layout."""
+    rng = np.random.RandomState(5)
+    x = rng.standard_normal((4, 64, 60)).astype(np.float32)
+    wt = (rng.standard_normal((128, 64, 3)) / 14).astype(np.float32)
+    ref = torch.nn.functional.conv1d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), dilation=3).numpy()
+    assert np.abs(conv1d_torch_layout(x, wt, 3) - ref).max() < 1e-12
+    a = np.ascontiguousarray(x.transpose(0, 2, 1)).reshape(4 * 60, 64)
+    w = np.ascontiguousarray(wt.transpose(2, 1, 0)).reshape(3 * 64, 128)
+    got = _run(ctx, a, w, 4, 60, 54, 3, 3, 0, 0, 0).reshape(4, 54, 128).transpose(0, 2, 1)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_conv_rows_rejects_bad_shapes(ctx):
+    from speakerguard_amd import _native as N
+    dev = torch.device("cuda:0")
+    t = torch.zeros(64, 64, device=dev)
+    with pytest.raises(N.NativeError):
+        ctx.call("sg_conv1d_rows", N._ptr(t), N._ptr(t), N._ptr(t), None, None, 1, 64, 64, 48, 128, 1, 1, 0, 0, 0,
+                 N.current_stream_ptr(dev))
