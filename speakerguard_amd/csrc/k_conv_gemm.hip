@@ -18,6 +18,7 @@
 // ds_write_b128), W chunk [32][BN]; MFMA operands are conflict-free ds_read_b32 (lanes 0-31 read
 // 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages + one register stage; the
 // staging of chunk c+1 / c+2 is issued in the middle of chunk c's MFMA stream (one barrier/chunk).
+#include <atomic>
 #include <cstdlib>
 
 #include "sg_internal.h"
@@ -451,9 +452,45 @@ __device__ __forceinline__ void tile_store(const ConvGemmArgs& p, float* C, int 
                                            f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
+    if (m0 + BM <= p.M) {
+        // Interior tile (all but the last row of tiles): no row checks, and every address is a wave-uniform
+        // 64-bit base (one per fragment row, SALU) plus ONE per-lane 32-bit offset, which the compiler folds
+        // into the saddr form of global_load/store -- no per-element VALU address arithmetic.  (The general
+        // path below costs ~10 instructions per element, ~350 per thread and tile.)
+        const unsigned lane_off = (unsigned)(4 * lhi * p.ldc + l31) * 4u;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int colu = n0 + wn * (BN / WN) + ni * 32;       // uniform
+                const int rowu = m0 + wm * (BM / WM) + mi * 32;       // uniform
+                const size_t base = (size_t)rowu * p.ldc + colu;
+                float bias = 0.f;
+                if (EPI == EPI_BIAS_RELU) bias = p.bias[colu + l31];
+                f32x16 mk;
+                if (EPI == EPI_RELU_MASK) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const char* mb = reinterpret_cast<const char*>(p.mask + base + (size_t)((e & 3) + 8 * (e >> 2)) * p.ldc);
+                        mk[e] = *reinterpret_cast<const float*>(mb + lane_off);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[mi][ni][e];
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                    if (EPI == EPI_RELU_MASK) v = mk[e] > 0.f ? v : 0.f;
+                    char* cb = reinterpret_cast<char*>(C + base + (size_t)((e & 3) + 8 * (e >> 2)) * p.ldc);
+                    *reinterpret_cast<float*>(cb + lane_off) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -529,11 +566,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 // so the result is bit-identical to the data-parallel launch) and runs the epilogue.
 // The waiting side always has the higher block index, so under in-order dispatch the block it
 // waits for is resident or already finished.  Hand-off = agent-scope release/acquire on one flag
-// per worker (cdna guide G16); flags are zeroed by a memset node in front of every launch.
+// per worker (cdna guide G16).  A flag holds the EPOCH of the launch that parked the slab (a process-wide
+// launch counter passed as a kernel argument), so nothing has to be cleared between launches.
 template <int EPI, bool W8, bool QUAD>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                    int iters_per_worker, float* slabs,
-                                                                   unsigned* flags) {
+                                                                   unsigned* flags, unsigned epoch) {
     constexpr int BM = W8 ? 128 : 64, BN = 128, WM = 2, WN = W8 ? 4 : 2;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 1x2 (4 waves) or 2x1 (8 waves)
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
@@ -579,7 +617,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // 2. whole tiles
@@ -600,7 +638,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_
         tile_origin(first_tile, m0, n0);
         if (threadIdx.x == 0) {
             unsigned spins = 0;
-            while (__hip_atomic_load(flags + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            while (__hip_atomic_load(flags + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1u << 26)) break;  // bounded: a lost hand-off shows up as a parity failure
             }
@@ -663,16 +701,17 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 16;  // >= 16 chunks (K >= 512): tdnn4 / tdnn5 gain 4-12 %, tdnn1 (5 chunks) loses
     }();
     if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
-    hipError_t e = hipMemsetAsync(flags, 0, 1024 * sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
+    static std::atomic<unsigned> launch_counter{0};
+    unsigned epoch = ++launch_counter;
+    if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
     dim3 grid(workers);
 #define SG_SK(EPI)                                                                                              \
     if (w8 && a.Wq) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true, true>), grid, dim3(512), 0, s, a, ntiles, \
-                                       tiles, ipw, slabs, flags);                                               \
+                                       tiles, ipw, slabs, flags, epoch);                                               \
     else if (w8) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true, false>), grid, dim3(512), 0, s, a, ntiles,   \
-                                    tiles, ipw, slabs, flags);                                                  \
+                                    tiles, ipw, slabs, flags, epoch);                                                  \
     else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false, false>), grid, dim3(256), 0, s, a, ntiles, tiles,   \
-                            ipw, slabs, flags);
+                            ipw, slabs, flags, epoch);
     switch (epi) {
         case EPI_NONE: SG_SK(EPI_NONE) break;
         case EPI_BIAS_RELU: SG_SK(EPI_BIAS_RELU) break;

@@ -163,6 +163,7 @@ int build_tables(sg_ctx* ctx) {
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->cw2_scratch, 1024 * 32);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_slabs, (size_t)512 * 128 * 128);  // >= 768 * 64 * 128
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_flags, 1024);
+    if (!rc && hipMemset(ctx->sk_flags, 0, 1024 * sizeof(unsigned)) != hipSuccess) rc = SG_ERR_HIP;
     if (rc) return SG_ERR_HIP;
     ctx->tables_ready = true;
     return SG_OK;
