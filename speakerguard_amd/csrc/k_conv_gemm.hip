@@ -564,8 +564,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 // them first thing and parks the accumulators in its slab; the worker that owns the LAST chunks
 // handles them last, starting from the parked accumulators (same fmaf chain as an unsplit tile,
 // so the result is bit-identical to the data-parallel launch) and runs the epilogue.
-// The waiting side always has the higher block index, so under in-order dispatch the block it
-// waits for is resident or already finished.  Hand-off = agent-scope release/acquire on one flag
+// All workers are co-resident (grid = resident slots), and a worker parks its head piece before anything
+// else, so a waiter never waits on work that depends on it (spins are bounded regardless).  Hand-off = agent-scope release/acquire on one flag
 // per worker (cdna guide G16).  A flag holds the EPOCH of the launch that parked the slab (a process-wide
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
 template <int EPI, bool W8, bool QUAD>
@@ -577,7 +577,15 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int C = p.total_chunks;
     const long total = (long)tiles * C;
-    const int w = blockIdx.x;
+    // Worker id and tile order are chosen for the per-XCD L2s (4 MB each; block b runs on XCD b % 8):
+    // XCD x takes the CONTIGUOUS workers [x*G, (x+1)*G), and tiles are numbered n-tile-major, so an XCD
+    // works on one or two n-tiles only and its W panels (K x 128 floats, 1.8 MB for tdnn3) stay L2-resident
+    // while the A rows stream through.  With w = blockIdx.x and m-tile-major order every XCD touched every
+    // W panel at unrelated k positions (stream-K ranges drift by ipw - C chunks per worker): 42 % TCC hit
+    // rate, 1.1 GB of fabric reads per tdnn3 launch against 45 MB of operands.
+    const int per_xcd = gridDim.x >> 3;
+    const int w = p.sk_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const int mtiles = tiles / ntiles;
     const long it_begin = (long)w * iters_per_worker;
     const long it_end = min(total, it_begin + iters_per_worker);
     if (it_begin >= it_end) return;
@@ -596,8 +604,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_
     const bool head_piece = last_c1 < C;                   // my range stops inside last_tile
     const bool tail_piece = first_c0 > 0;                  // my range starts inside first_tile
     auto tile_origin = [&](int tile, int& m0, int& n0) {
-        m0 = (tile / ntiles) * BM;
-        n0 = (tile % ntiles) * BN;
+        if (p.sk_xcd) {
+            m0 = (tile % mtiles) * BM;
+            n0 = (tile / mtiles) * BN;
+        } else {
+            m0 = (tile / ntiles) * BM;
+            n0 = (tile % ntiles) * BN;
+        }
     };
 
     // 1. the head piece of my last tile (chunks [0, last_c1)): park it for worker w+1
@@ -764,6 +777,11 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     }();
     ConvGemmArgs a = a_in;
     a.ablate = ablate;
+    static const int sk_xcd = [] {
+        const char* e = getenv("SG_STREAMK_XCD");  // 0 = worker id = block id, m-tile-major tiles
+        return e ? atoi(e) : 1;
+    }();
+    a.sk_xcd = sk_xcd;
     static const int use_quad = [] {
         const char* e = getenv("SG_QUADFEED");  // 0 = b32-fed 8-wave kernel even when packed weights exist
         return e ? atoi(e) : 1;
