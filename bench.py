@@ -116,13 +116,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel: TDNN layer 3 forward contraction (conv_gemm_kernel<128,128,...>),
+    # roofline of the dominant kernel: TDNN layer 3 forward contraction (stream-K, 128x128 quad-fed tiles),
     # HIP events on the launch stream inside the library
-    ms, flops, rows = model.time_layer(3, B_PER_GPU, T_SAMPLES, iters=20)
+    ms, flops, _ = model.time_layer(3, B_PER_GPU, T_SAMPLES, iters=20)
     achieved = flops / (ms * 1e-3) / 1e12
+    # memory-side bytes of that launch come from the committed rocprofv3 --pmc passes (cannot be collected
+    # from inside this process); null if the summary is missing
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tdnn3.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+        traffic_src = "profiles/r01_pmc_tdnn3.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; fabric bytes incl. Infinity-Cache hits)"
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "conv_gemm_kernel<%d,128,..,BIAS_RELU> tdnn3 forward (B=64: M=17280 N=512 K=3584)" % rows,
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "conv_gemm_streamk_kernel<BIAS_RELU,W8,QUAD> tdnn3 forward (B=64: M=17280 N=512 K=3584)",
                 "ms_per_launch": ms, "flop_per_launch": flops}
 
     steps_per_s = world * args.steps / dt
