@@ -379,3 +379,55 @@ class FAKEBOB:
             adver.append(a)
             success += s
         return torch.cat(adver, 0), success
+
+    # FAKEBOB.estimate_threshold_run :210-278 / estimate_threshold :280-295
+    def estimate_threshold_run(self, x, step=0.1):
+        with torch.no_grad():
+            n = x.shape[0]
+            d, s = self.model.make_decision(x)
+            if int(d[0]) != -1:
+                return None
+            y = torch.full((n,), -1, dtype=torch.long)
+            init_score = float(np.max(s[0].numpy()))
+            delta = np.abs(init_score * step)
+            threshold = init_score + delta
+            adver_x = x.clone()
+            grad = torch.zeros_like(x)
+            upper = torch.clamp(x + self.epsilon, max=1)
+            lower = torch.clamp(x - self.epsilon, min=-1)
+            while True:
+                self.loss, self.grad_sign = resolve_loss("Margin", False, 0.0, self.task, threshold, False)
+                last_ls = [[]] * n  # aliased on purpose, see attack_batch
+                lr = [self.max_lr] * n
+                while True:
+                    decision, score = self.model.make_decision(adver_x)
+                    top = float(np.max(score[0].numpy()))
+                    if int(decision[0]) != -1:
+                        return top
+                    elif top >= threshold:
+                        break
+                    prev_grad = grad.clone()
+                    loss, grad, _, _, _ = self.get_grad(adver_x, y)
+                    grad = self.momentum * prev_grad + (1.0 - self.momentum) * grad
+                    for jj, l_ in enumerate(loss):
+                        last_ls[jj].append(l_)
+                        last_ls[jj] = last_ls[jj][-self.plateau_length:]
+                        if last_ls[jj][-1] > last_ls[jj][0] and len(last_ls[jj]) == self.plateau_length:
+                            if lr[jj] > self.min_lr:
+                                lr[jj] = max(lr[jj] / self.plateau_drop, self.min_lr)
+                            last_ls[jj] = []
+                    lr_t = torch.tensor(lr, dtype=torch.float).view(-1, 1, 1)
+                    adver_x = adver_x + self.grad_sign * lr_t * torch.sign(grad)
+                    adver_x = torch.min(torch.max(adver_x, lower), upper)
+                threshold += delta
+
+    def estimate_threshold(self, x, step=0.1):
+        if self.task == "CSI":
+            return None
+        est = []
+        for xx in x.unsqueeze(0):  # sic (FAKEBOB.py:287): a single pass with the whole batch
+            t = self.estimate_threshold_run(xx, step)
+            if t is not None:
+                est.append(t)
+        self.threshold = np.mean(est) if est else None
+        return self.threshold

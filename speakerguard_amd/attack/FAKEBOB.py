@@ -1,10 +1,14 @@
-"""FAKEBOB black-box attack (NES gradient + momentum + per-example plateau LR); mirrors reference
-attack/FAKEBOB.py:50-208.  Queries are forward-only passes of the native engine.
+"""FAKEBOB black-box attack (NES gradient + momentum + per-example plateau LR) and its threshold
+estimation for black-box SV/OSI; mirrors reference attack/FAKEBOB.py:50-295.  Queries are forward-only
+passes of the native engine.
 
 Faithfulness notes:
   * ``last_ls = [[]] * n`` (FAKEBOB.py:56) aliases one list across the batch; the in-place append at
     :95 therefore leaks earlier examples' losses into later examples' plateau history until each
     entry is rebound.  That changes the LR schedule and is reproduced on purpose.
+  * ``estimate_threshold`` (:280-295) iterates ``for xx in x.unsqueeze(0)``, i.e. exactly once with the
+    WHOLE (N,1,T) batch, and ``estimate_threshold_run`` reads only example 0's decision / top score
+    (:214-216, :246-249) while updating all N examples -- reproduced as is.
   * At the convergence check (:106-116) the reference assigns the UNFILTERED ``loss_np`` to
     ``prev_loss`` after examples were dropped, which mis-aligns (or crashes) for batch_size > 1;
     the reference default is batch_size=1 where both behaviours coincide.  Here the surviving
@@ -149,3 +153,66 @@ class FAKEBOB(Attack):
             adver.append(a)
             success += s
         return torch.cat(adver, 0), success
+
+    # ------------------------------------------------------------------ threshold estimation (:210-295)
+    def estimate_threshold_run(self, x, step=0.1):
+        """Push a REJECTED voice up a ladder of candidate thresholds until the model accepts it; the top
+        score at that moment is the estimate (:210-278).  None if example 0 is already accepted."""
+        n_audios = x.shape[0]
+        d, s = self.model.make_decision(x)
+        if int(d[0]) != -1:
+            return None  # already accepted, cannot be used to estimate the threshold (:217-218)
+        y = torch.full((n_audios,), -1, dtype=torch.long, device=x.device)
+        init_score = float(np.max(s[0].cpu().numpy()))
+        delta = np.abs(init_score * step)
+        threshold = init_score + delta
+        adver_x = x.clone().contiguous()
+        grad = torch.zeros_like(x)
+        upper = torch.clamp(x + self.epsilon, max=1).contiguous()
+        lower = torch.clamp(x - self.epsilon, min=-1).contiguous()
+        base = getattr(self.model, 'base_model', self.model)
+        iter_outer = 0
+        while True:
+            self.loss, self.grad_sign = resolve_loss('Margin', False, 0., self.task, threshold, False)
+            self.EOT_wrapper = EOT(self.model, self.loss, self.EOT_size, self.EOT_batch_size, False)
+            iter_inner = 0
+            last_ls = [[]] * n_audios
+            lr = [self.max_lr] * n_audios
+            while True:
+                decision, score = self.model.make_decision(adver_x)
+                top = float(np.max(score[0].cpu().numpy()))
+                if self.verbose:
+                    print(iter_outer, iter_inner, top, getattr(self.model, 'threshold', None))
+                if int(decision[0]) != -1:  # accepted: found the threshold (:251-252)
+                    return top
+                elif top >= threshold:      # candidate exceeded without acceptance: raise it (:253-254)
+                    break
+                prev_grad = grad.clone()
+                loss, grad, _, _, _ = self.get_grad(adver_x, y)
+                loss_h = [float(l) for l in loss.cpu().numpy()]
+                for jj, loss_ in enumerate(loss_h):
+                    last_ls[jj].append(loss_)
+                    last_ls[jj] = last_ls[jj][-self.plateau_length:]
+                    if last_ls[jj][-1] > last_ls[jj][0] and len(last_ls[jj]) == self.plateau_length:
+                        if lr[jj] > self.min_lr:
+                            lr[jj] = max(lr[jj] / self.plateau_drop, self.min_lr)
+                        last_ls[jj] = []
+                lr_t = torch.tensor(lr, device=adver_x.device, dtype=torch.float)
+                grad = grad.contiguous()
+                base.fakebob_step(adver_x, grad, prev_grad.contiguous(), lr_t, lower, upper, self.momentum,
+                                  self.grad_sign)  # :260 momentum mix, :269-270 sign step + clamp
+                iter_inner += 1
+            threshold += delta
+            iter_outer += 1
+
+    def estimate_threshold(self, x, step=0.1):
+        if self.task == 'CSI':
+            print("--- Warning: no need to estimate threshold for CSI, quitting ---")
+            return
+        estimated_thresholds = []
+        for xx in x.unsqueeze(0):  # sic (:287): one pass over the whole batch
+            estimated_threshold = self.estimate_threshold_run(xx, step)
+            if estimated_threshold is not None:
+                estimated_thresholds.append(estimated_threshold)
+        self.threshold = np.mean(estimated_thresholds) if len(estimated_thresholds) > 0 else None
+        return self.threshold

@@ -272,6 +272,32 @@ def gen_attacks():
                                               "toy": "tests/toy_model.py ToyModel(T=800,n_spk=4,seed=7)"}, **out)
 
 
+def gen_estimate_threshold():
+    """FAKEBOB.estimate_threshold (FAKEBOB.py:210-295) run by the reference on the toy model."""
+    import contextlib
+    import io
+    x = toy_inputs(B=4, T=800)
+    out = {}
+    cases = (("single", [0], 6.0), ("batch_quirk", [3, 0], 9.0), ("accepted", [2], 6.0), ("negative", [1], 0.5))
+    kw = dict(task="OSI", epsilon=0.05, max_lr=0.004, min_lr=1e-4, samples_per_draw=16,
+              samples_per_draw_batch_size=8, sigma=0.01, plateau_length=3, verbose=0)
+    for name, idx, thr in cases:
+        model = ToyModel(threshold=thr).eval()
+        atk = FAKEBOB(model, **kw)
+        torch.manual_seed(321)
+        np.random.seed(321)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):  # the reference prints one line per inner iteration
+            est = atk.estimate_threshold(x[idx].clone(), step=0.1)
+        out[name + "_idx"] = np.array(idx)
+        out[name + "_model_threshold"] = np.float64(thr)
+        out[name + "_estimate"] = np.float64(np.nan if est is None else est)
+        out[name + "_iters"] = np.int64(len(buf.getvalue().strip().splitlines()))
+        print(name, "estimate", est, "model threshold", thr, "inner iterations", out[name + "_iters"])
+    save("estimate_threshold.npz", x=x.numpy(), meta={"seeds": "torch.manual_seed(321); np.random.seed(321) per case",
+                                                      "kw": json.dumps(kw), "step": 0.1}, **out)
+
+
 if __name__ == "__main__":
     import contextlib
     import io
@@ -284,3 +310,4 @@ if __name__ == "__main__":
         gen_attacks()
         gen_xv(tmp)
         gen_xv_pgd(tmp)
+        gen_estimate_threshold()

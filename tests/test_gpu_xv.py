@@ -500,6 +500,36 @@ def test_fakebob_matches_oracle_with_shared_noise(hip_model, oracle_model, dev):
     assert frac < 0.05 and diff.max().item() <= 2 * 0.002 + 1e-6
 
 
+@pytest.mark.timeout(300)  # the reference loop has no iteration bound (FAKEBOB.py:236-278)
+def test_estimate_threshold_matches_oracle_with_shared_noise(xv_weights, dev):
+    """SURVEY 8(f) N2 on the native engine: a rejected voice is pushed up the threshold ladder with NES
+    queries until the (hidden) OSI threshold accepts it; same noise stream on both sides."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    from speakerguard_amd.model.xv_plda import xv_plda
+    x = torch.from_numpy(synth.make_waveforms(1, 16000, seed=41))
+    probe = XvPlda(xv_weights, threshold=None)
+    with torch.no_grad():
+        top = float(probe.make_decision(x)[1].max())
+    hidden = top + 0.25 * abs(top)  # the voice starts below the threshold: rejected
+    om = XvPlda(xv_weights, threshold=hidden)
+    hm = xv_plda.from_weights(xv_weights, threshold=hidden, device=dev, dither=0.0)
+    assert int(hm.make_decision(x.to(dev))[0][0]) == -1
+    kw = dict(task="OSI", epsilon=0.004, max_lr=0.001, min_lr=1e-6, samples_per_draw=8, samples_per_draw_batch_size=4,
+              sigma=0.001, plateau_length=3)
+    g = torch.Generator().manual_seed(9)
+    want = oatk.FAKEBOB(om, noise_fn=lambda shape: torch.randn(shape, generator=g), **kw).estimate_threshold(x.clone(), step=0.1)
+    g2 = torch.Generator().manual_seed(9)
+    atk = FAKEBOB(hm, verbose=0, noise_fn=lambda shape: torch.randn(shape, generator=g2), **kw)
+    got = atk.estimate_threshold(x.to(dev), step=0.1)
+    log("estimate_threshold: hidden %.4f, oracle %.4f, hip %.4f" % (hidden, want, got))
+    assert got is not None and atk.threshold == got
+    assert got > hidden                                  # first accepted top score
+    assert abs(got - want) <= 0.02 * abs(hidden) + 1e-3  # sign-step trajectories drift (H3); same rung of the ladder
+
+
 def test_defended_model_passthrough_and_sharded_wrapper(hip_model, dev):
     from speakerguard_amd import synth
     from speakerguard_amd.attack.PGD import PGD

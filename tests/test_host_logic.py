@@ -60,6 +60,28 @@ def test_attacks_match_reference_trajectories(tag, thr, task, capsys):
     check("fakebob_t", FAKEBOB(model, batch_size=1, targeted=True, confidence=0.05, noise_fn=rn, **fb))
 
 
+def test_estimate_threshold_matches_reference():
+    """Product FAKEBOB.estimate_threshold vs the reference's own run (tests/golden/estimate_threshold.npz)."""
+    import json
+    from conftest import load_golden
+    g = load_golden("estimate_threshold.npz")
+    x = torch.from_numpy(g["x"])
+    kw = json.loads(g["meta"]["kw"])
+    rn = lambda shape: torch.randn(shape)
+    for name in ("single", "batch_quirk", "accepted", "negative"):
+        model = AutogradEngine(ToyModel(threshold=float(g[name + "_model_threshold"])).eval())
+        atk = FAKEBOB(model, noise_fn=rn, **kw)
+        torch.manual_seed(321)
+        np.random.seed(321)
+        est = atk.estimate_threshold(x[g[name + "_idx"].tolist()].clone(), step=g["meta"]["step"])
+        want = float(g[name + "_estimate"])
+        if np.isnan(want):
+            assert est is None and atk.threshold is None
+        else:
+            assert abs(est - want) < 1e-5, (name, est, want)
+    assert FAKEBOB(model, task="CSI", verbose=0).estimate_threshold(x) is None  # FAKEBOB.py:281-283
+
+
 def test_attack_asserts_follow_reference():
     model = AutogradEngine(ToyModel().eval())
     atk = PGD(model, verbose=0)

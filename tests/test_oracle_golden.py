@@ -150,3 +150,25 @@ def test_attack_logic_on_toy_model(tag, thr, task):
         fb["threshold"] = thr
     check("fakebob", oatk.FAKEBOB(model, batch_size=1, **fb))
     check("fakebob_t", oatk.FAKEBOB(model, batch_size=1, targeted=True, confidence=0.05, **fb))
+
+
+def test_estimate_threshold_matches_reference():
+    """FAKEBOB.estimate_threshold (FAKEBOB.py:210-295), incl. the whole-batch / example-0 quirk."""
+    import json
+    g = load_golden("estimate_threshold.npz")
+    x = torch.from_numpy(g["x"])
+    kw = json.loads(g["meta"]["kw"])
+    kw.pop("verbose", None)
+    for name in ("single", "batch_quirk", "accepted", "negative"):
+        model = ToyModel(threshold=float(g[name + "_model_threshold"])).eval()
+        atk = oatk.FAKEBOB(model, **kw)
+        torch.manual_seed(321)
+        np.random.seed(321)
+        est = atk.estimate_threshold(x[g[name + "_idx"].tolist()].clone(), step=g["meta"]["step"])
+        want = float(g[name + "_estimate"])
+        if np.isnan(want):
+            assert est is None and atk.threshold is None
+        else:
+            assert abs(est - want) < 1e-5, (name, est, want)
+            # the estimate is the first accepted top score: just above the model's true threshold
+            assert est > float(g[name + "_model_threshold"])
