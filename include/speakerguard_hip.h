@@ -270,6 +270,22 @@ int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c
                    const float* mask_dev, int32_t B, int32_t Ta, int32_t Tc, int32_t Kc, int32_t N, int32_t taps,
                    int32_t tap_step, int32_t tap_base, int32_t epi, int32_t kernel, void* stream);
 
+/* ---- data formats either side of the path ----------------------------
+ * attackMain.py:154-166 save_audio + metric/metric.py:8-42, one pass over the batch:
+ *   pcm (B,T) int16: per utterance, x * 2^15 if 0.9*max <= 1 and 0.9*min >= -1, then numpy astype(int16)
+ *     (truncate toward zero, keep the low 16 bits: 1.0 -> -32768);
+ *   metrics (B,5) double: L2, L0, L1, Linf of preprocess(adver) - preprocess(benign) and SNR in dB
+ *     (+inf for a zero perturbation); preprocess divides by 2^15 unless -1 <= max <= 1 (metric.py:8-12).
+ * pcm_dev or metrics_dev may be NULL; benign_dev is only needed for the metrics. */
+int sg_wav_finalize(sg_ctx* ctx, const float* benign_dev, const float* adver_dev, int32_t B, int32_t T,
+                    int16_t* pcm_dev, double* metrics_dev, void* stream);
+
+/* set_threshold.py:22-47 set_threshold(score_target, score_untarget): scans the target scores in order and
+ * keeps the first one minimising |FRR - FAR| (both in percent).  out3_dev: threshold, FRR, FAR (doubles).
+ * Synchronises the stream. */
+int sg_eer_threshold(sg_ctx* ctx, const float* target_dev, int32_t n_target, const float* untarget_dev,
+                     int32_t n_untarget, double* out3_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

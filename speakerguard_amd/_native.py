@@ -21,7 +21,7 @@ EXPORTS = (
     "sg_xv_loss_grad", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
     "sg_cw2_step", "sg_nes_queries", "sg_nes_grad", "sg_fakebob_step",
     "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
-    "sg_an_pgd_run", "sg_conv1d_rows",
+    "sg_an_pgd_run", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
 )
 
 
@@ -107,6 +107,8 @@ def load():
         "sg_an_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
         "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32), vp]),
         "sg_conv1d_rows": (C.c_int, [vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]),
+        "sg_wav_finalize": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
+        "sg_eer_threshold": (C.c_int, [vp, vp, i32, vp, i32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -298,6 +298,62 @@ def gen_estimate_threshold():
                                                       "kw": json.dumps(kw), "step": 0.1}, **out)
 
 
+def _ref_functions(rel_path, names, env):
+    """Executes, UNMODIFIED, the named top-level functions of a reference file whose module cannot be imported
+    here (its imports need pesq / pystoi / torch_lfilter / torchaudio): the FunctionDef nodes are taken from
+    the file's AST and compiled with the file's own name; nothing else of the module runs."""
+    import ast
+    path = os.path.join(REF, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), (rel_path, names)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), env)
+    return env
+
+
+def gen_post_formats(tmpdir):
+    """save_audio int16 rounding, perturbation metrics, EER threshold -- reference functions."""
+    from numpy import linalg as LA
+    from scipy.io import wavfile
+    rs = np.random.RandomState(77)
+    T = 1200
+    benign = np.clip(0.2 * rs.randn(8, T), -0.95, 0.95).astype(np.float32)
+    adver = benign + rs.uniform(-0.002, 0.002, benign.shape).astype(np.float32)
+    adver[1] = benign[1]                     # zero perturbation -> SNR inf, L0 0
+    adver[2, :5] = [1.0, -1.0, 0.999985, 3.0517578e-05 * 0.9, -3.0517578e-05 * 1.5]   # 1.0 -> wraps to -32768
+    adver[3] = adver[3] * 1.15               # max in (1, 1.111]: still scaled by save_audio, /2^15 by preprocess
+    benign[4] = np.round(benign[4] * 32768)  # int16-scale inputs: save_audio leaves them, preprocess divides
+    adver[4] = benign[4] + np.round(rs.uniform(-60, 60, T)).astype(np.float32)
+    adver[5, 100:200] = benign[5, 100:200]   # partial L0
+    benign[6] = -np.abs(benign[6])           # max <= 0: fine for both rules
+    adver[6] = benign[6] - 0.001
+    adver[7, 7] = 1.2                        # 0.9*max > 1 -> NOT scaled: values truncate to 0 / 1
+    env = _ref_functions("attackMain.py", ["save_audio"], {"np": np, "torch": torch, "os": os, "write": wavfile.write, "bits": 16})
+    names = ["id%02d-utt%d" % (i, i) for i in range(8)]
+    env["save_audio"](torch.from_numpy(adver).unsqueeze(1), names, tmpdir)
+    pcm = np.stack([wavfile.read(os.path.join(tmpdir, n.split("-")[0], n + ".wav"))[1] for n in names])
+    menv = _ref_functions("metric/metric.py", ["preprocess", "Lp", "L2", "L0", "L1", "Linf", "SNR"],
+                          {"np": np, "LA": LA, "LOWER": -1, "UPPER": 1})
+    with np.errstate(divide="ignore"):
+        metrics = np.array([[menv[k](torch.from_numpy(benign[i:i + 1]), torch.from_numpy(adver[i:i + 1]))
+                             for k in ("L2", "L0", "L1", "Linf", "SNR")] for i in range(8)], dtype=np.float64)
+    tenv = _ref_functions("set_threshold.py", ["set_threshold"], {"np": np})
+    eer = {}
+    for name, nt, nu, rnd in (("plain", 200, 700, None), ("ties", 150, 400, 1), ("separable", 60, 90, None), ("single", 1, 5, None)):
+        st = rs.randn(nt).astype(np.float32) * 3 + (8 if name == "separable" else 2)
+        su = rs.randn(nu).astype(np.float32) * 3 - (8 if name == "separable" else 2)
+        if rnd is not None:
+            st, su = np.round(st, rnd), np.round(su, rnd)
+        thr, frr, far = tenv["set_threshold"](st.astype(np.float64), su.astype(np.float64))
+        eer[name + "_target"], eer[name + "_untarget"] = st, su
+        eer[name + "_out"] = np.array([thr, frr, far], dtype=np.float64)
+    save("post_formats.npz", benign=benign, adver=adver, pcm=pcm, metrics=metrics,
+         meta={"how": "reference functions save_audio (attackMain.py:154-166), preprocess/Lp/L2/L0/L1/Linf/SNR "
+                      "(metric/metric.py:8-42) and set_threshold (set_threshold.py:22-47) extracted from the reference "
+                      "files by AST and executed unmodified (their modules import uninstalled packages); wav files "
+                      "written by the reference code were read back with scipy.io.wavfile"}, **eer)
+
+
 if __name__ == "__main__":
     import contextlib
     import io
@@ -311,3 +367,4 @@ if __name__ == "__main__":
         gen_xv(tmp)
         gen_xv_pgd(tmp)
         gen_estimate_threshold()
+        gen_post_formats(tmp)
