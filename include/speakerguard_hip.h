@@ -124,6 +124,15 @@ int sg_xv_mfcc(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const floa
 /* model/iv_plda.py:296-377 cmvn(): sliding 300-frame centred mean subtraction. (B,F,30)->(B,F,30) */
 int sg_xv_cmvn(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, float* out_dev, void* stream);
 
+/* Backward of the two front-end stages alone (what autograd derives for xv_plda.py:107-156 and
+ * iv_plda.py:296-377): needed when something sits BETWEEN the stages, i.e. a feature-level defense
+ * (model/defended_model.py:46-65 process_sequential with a flag-1 or flag-2 defense).
+ * sg_xv_mfcc_backward: d loss/d raw MFCC (B,F,30) -> d loss/d waveform (B,T); same scale / dither as the forward.
+ * sg_xv_cmvn_backward: d loss/d CMVN features -> d loss/d raw features, (B,F,30) both. */
+int sg_xv_mfcc_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* scale_dev,
+                        const sg_dither* dither, const float* dfeats_dev, float* grad_dev, void* stream);
+int sg_xv_cmvn_backward(sg_ctx* ctx, const float* dout_dev, int32_t B, int32_t F, float* din_dev, void* stream);
+
 /* Forward pass: model.make_decision / score / embedding (iv_plda.py:155-194, xv_plda.py:87-104).
  * Any output pointer may be NULL.  decisions (B) int64, scores (B,S), emb (B,D) processed
  * embedding (xv_plda.py:159-174), tdnn_emb (B,512) raw fc1 output (xvecTDNN.py:63). */
@@ -285,6 +294,21 @@ int sg_wav_finalize(sg_ctx* ctx, const float* benign_dev, const float* adver_dev
  * Synchronises the stream. */
 int sg_eer_threshold(sg_ctx* ctx, const float* target_dev, int32_t n_target, const float* untarget_dev,
                      int32_t n_untarget, double* out3_dev, void* stream);
+
+/* ---- FeCo feature-level defense -------------------------------------------
+ * defense/feature_level.py:168-217 kmeans(): cluster the F frames of each utterance into k = int(F * ratio)
+ * groups and replace every group by the mean of its frames; feats (B,F,D), D <= 64.
+ * sg_feco_kmeans: cluster ids (B,F) under this library's determinism contract (k_feco.hip header; the reference
+ *   delegates to a randomly initialised third-party k-means, so its ids are not reproducible).
+ * sg_feco_compress: :204-216 given the ids: out (B,k,D) = cluster means, an empty cluster i takes frame i (the
+ *   reference's `force` fallback; with B == 1 the reference drops such rows -- the host compacts using counts).
+ * sg_feco_compress_backward: the gradient autograd derives for that step. */
+int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
+                   int32_t* assign_dev, void* stream);
+int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_dev, int32_t B, int32_t F, int32_t D,
+                     int32_t k, float* out_dev, int32_t* counts_dev, void* stream);
+int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev, const int32_t* counts_dev,
+                              int32_t B, int32_t F, int32_t D, int32_t k, int32_t force, float* dfeats_dev, void* stream);
 
 #ifdef __cplusplus
 }

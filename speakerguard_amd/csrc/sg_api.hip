@@ -572,6 +572,25 @@ int sg_xv_cmvn(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, float*
     return SG_OK;
 }
 
+int sg_xv_mfcc_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* scale_dev,
+                        const sg_dither* dither, const float* dfeats_dev, float* grad_dev, void* stream) {
+    if (!x_dev || !dfeats_dev || !grad_dev) return fail(ctx, SG_ERR_ARG, "bad argument");
+    PassDims d;
+    int rc = check_dims(ctx, B, T, SG_FLAG_WAV, &d);  // sizes the per-frame gradient scratch
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Workspace& w = ctx->ws;
+    SG_HIP(launch_mfcc_bwd(ctx->tab, x_dev, d.B, d.T, d.F, scale_dev, dither, dfeats_dev, w.dframes, s));
+    SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
+    return SG_OK;
+}
+
+int sg_xv_cmvn_backward(sg_ctx* ctx, const float* dout_dev, int32_t B, int32_t F, float* din_dev, void* stream) {
+    if (!ctx || !dout_dev || !din_dev || B < 1 || F < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    SG_HIP(launch_cmvn_bwd(dout_dev, kCep, 1, 0, din_dev, kCep, B, F, (hipStream_t)stream));
+    return SG_OK;
+}
+
 int sg_xv_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag, const sg_dither* dither,
                   int64_t* decisions_dev, float* scores_dev, float* emb_dev, float* tdnn_emb_dev, void* stream) {
     PassDims d;

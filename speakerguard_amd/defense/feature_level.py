@@ -1,0 +1,71 @@
+"""FeCo feature-level defense on the native engine; mirrors reference defense/feature_level.py:15-50,168-217
+(method 'kmeans', distance 'L2').
+
+``FeCo(feat, method, param, other_param)`` keeps the reference's function signature (forward only).
+``FeCoDefense`` is the same transform as an object with ``fwd`` / ``bwd`` so that ``defended_model`` can chain
+the hand-coded backward through it (adaptive attacks against a FeCo-defended model).
+
+The cluster ids come from the library's deterministic k-means (contract in csrc/k_feco.hip); the reference's
+ids come from a randomly initialised third-party k-means and are not reproducible, so parity with the reference
+exists only for the step after the ids (cluster means + empty-cluster fallback, :204-216).
+'warped_kmeans' and the cosine distance are not built.
+"""
+import torch
+
+from .. import _native as N
+from ..metric.metric import _context
+
+
+class FeCoDefense:
+
+    def __init__(self, param=0.5, method='kmeans', other_param='L2', max_iter=10):
+        if method != 'kmeans':
+            raise NotImplementedError('Currently FEATURE COMPRESSION only supports kmeans on the native engine')
+        if other_param != 'L2':
+            raise NotImplementedError("only the 'L2' distance is built (the reference notes 'cos' works poorly, :178)")
+        self.param, self.max_iter = param, max_iter
+
+    # ---- forward with saved state ------------------------------------------------------------------
+    def fwd(self, feat):
+        """feat (B,F,D) -> (compressed (B,k,D) [or (1,k',D) with empty clusters dropped when B == 1], saved)."""
+        feat = feat.to(torch.float32).contiguous()
+        if not feat.is_cuda:
+            raise N.NativeError("FeCo runs on the HIP device only")
+        B, F, D = feat.shape
+        k = int(F * self.param)  # :184
+        ctx, s = _context(feat.device), N.current_stream_ptr(feat.device)
+        ids = torch.empty(B, F, device=feat.device, dtype=torch.int32)
+        out = torch.empty(B, k, D, device=feat.device, dtype=torch.float32)
+        counts = torch.empty(B, k, device=feat.device, dtype=torch.int32)
+        ctx.call("sg_feco_kmeans", N._ptr(feat), B, F, D, k, self.max_iter, N._ptr(ids), s)
+        ctx.call("sg_feco_compress", N._ptr(feat), N._ptr(ids), B, F, D, k, N._ptr(out), N._ptr(counts), s)
+        force = B > 1  # :33 force=feat.shape[0] > 1
+        keep = None
+        if not force and bool((counts == 0).any()):
+            keep = torch.nonzero(counts[0] > 0).flatten()  # :209-212: empty clusters are skipped
+            out = out.index_select(1, keep)
+        return out, (ids, counts, (B, F, D, k), force, keep)
+
+    def bwd(self, saved, dout):
+        ids, counts, (B, F, D, k), force, keep = saved
+        dout = dout.to(torch.float32)
+        if keep is not None:
+            full = torch.zeros(B, k, D, device=dout.device, dtype=torch.float32)
+            full.index_copy_(1, keep, dout)
+            dout = full
+        dout = dout.contiguous()
+        dfeat = torch.empty(B, F, D, device=dout.device, dtype=torch.float32)
+        _context(dout.device).call("sg_feco_compress_backward", N._ptr(dout), N._ptr(ids), N._ptr(counts), B, F, D, k,
+                                   1 if force else 0, N._ptr(dfeat), N.current_stream_ptr(dout.device))
+        return dfeat
+
+    def __call__(self, feat):
+        return self.fwd(feat)[0]
+
+
+def FeCo(feat, method='kmeans', param=0.5, other_param='L2'):
+    return FEATURE_COMPRESSION(feat, method, param, other_param)
+
+
+def FEATURE_COMPRESSION(feat, method='kmeans', param=0.5, other_param='L2'):
+    return FeCoDefense(param=param, method=method, other_param=other_param)(feat)

@@ -3,8 +3,10 @@
 With ``defense=None`` (reference :127-128,156-157) every call is passed straight to the base model,
 including the native ``loss_grad`` / ``pgd_run`` entry points the attacks use.  Input- and
 feature-level defenses are applied for the forward calls exactly like ``process_sequential``
-(:46-65); differentiating THROUGH a defense is not part of this round and
-``loss_grad`` raises instead of silently ignoring the defense.
+(:46-65).  The gradient THROUGH feature-level defenses is chained by hand for
+defenses that expose ``fwd`` / ``bwd`` (``speakerguard_amd.defense.feature_level.FeCoDefense``) on an xv_plda
+base model in sequential order; any other defended configuration raises in ``loss_grad`` instead of silently
+ignoring the defense.
 """
 import warnings
 
@@ -103,10 +105,41 @@ class defended_model:
     def loss_grad(self, x, y, loss_spec, want_grad=True):
         if self.defense is None:
             return self.base_model.loss_grad(x, y, loss_spec, flag=0, want_grad=want_grad)
-        if want_grad:
-            raise NotImplementedError('gradient through defenses is not implemented in this round (SURVEY.md N1)')
-        decisions, scores = self.make_decision(x)
-        return decisions, scores, loss_spec(scores, y), None
+        if not want_grad:
+            decisions, scores = self.make_decision(x)
+            return decisions, scores, loss_spec(scores, y), None
+        return self._loss_grad_through_defenses(x, y, loss_spec)
+
+    def _loss_grad_through_defenses(self, x, y, loss_spec):
+        """wav -> MFCC -> [flag-1 defenses] -> CMVN -> [flag-2 defenses] -> TDNN ... -> loss, and back.
+
+        The order is process_sequential's (:52-63).  Each stage's backward is the native one: the model's own
+        loss_grad from the last defended level, the defenses' ``bwd``, CMVN / MFCC backward in between."""
+        bm = self.base_model
+        chainable = (self.order == sequential and hasattr(bm, 'frontend_forward') and not self.flag2defense.get(0)
+                     and all(hasattr(d, 'fwd') and hasattr(d, 'bwd') for f in (1, 2) for d in self.flag2defense.get(f, [])))
+        if not chainable:
+            raise NotImplementedError('gradient through this defense configuration is not built: needs an xv_plda base '
+                                      'model, sequential order, and feature-level defenses with fwd/bwd (FeCoDefense)')
+        feats, saved_front = bm.frontend_forward(x)
+        tape1, tape2 = [], []
+        for d in self.flag2defense[1]:
+            feats, sv = d.fwd(feats)
+            tape1.append((d, sv))
+        if self.flag2defense[2]:
+            feats = bm.comput_feat_from_feat(feats, ori_flag=1, des_flag=2)
+            for d in self.flag2defense[2]:
+                feats, sv = d.fwd(feats)
+                tape2.append((d, sv))
+            decisions, scores, loss, g = bm.loss_grad(feats, y, loss_spec, flag=2, want_grad=True)
+            for d, sv in reversed(tape2):
+                g = d.bwd(sv, g)
+            g = bm.cmvn_backward(g)
+        else:
+            decisions, scores, loss, g = bm.loss_grad(feats, y, loss_spec, flag=1, want_grad=True)
+        for d, sv in reversed(tape1):
+            g = d.bwd(sv, g)
+        return decisions, scores, loss, bm.frontend_backward(saved_front, g)
 
     def pgd_update(self, *a, **k):
         return self.base_model.pgd_update(*a, **k)

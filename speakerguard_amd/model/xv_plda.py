@@ -211,6 +211,35 @@ class xv_plda(EngineOps):
         self.ctx.call("sg_xv_mfcc", N._ptr(x), B, T, N._ptr(scale), C.byref(dz), N._ptr(feats), s)
         return feats if flag == 1 else self.comput_feat_from_feat(feats, 1, 2)
 
+    # ---- front-end stages with their backward (used when a feature-level defense sits between them) ----
+    def frontend_forward(self, x):
+        """wav (B,1,T) -> (raw MFCC (B,F,30), saved) with the state the backward needs (same scale, same dither)."""
+        x, B, T = self._prep(x, 0)
+        F = N.load().sg_xv_num_frames(T)
+        scale = torch.empty(1, device=self.device, dtype=torch.float32)
+        feats = torch.empty(B, F, 30, device=self.device, dtype=torch.float32)
+        s = self._stream()
+        self.ctx.call("sg_input_scale", N._ptr(x), x.numel(), N._ptr(scale), s)
+        dz = self._dither(None)
+        self.ctx.call("sg_xv_mfcc", N._ptr(x), B, T, N._ptr(scale), C.byref(dz), N._ptr(feats), s)
+        return feats, (x, scale, dz)
+
+    def frontend_backward(self, saved, dfeats):
+        """d loss / d raw MFCC (B,F,30) -> d loss / d wav (B,1,T)."""
+        x, scale, dz = saved
+        B, T = x.shape[0], x.shape[2]
+        dfeats = dfeats.to(self.device, torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        self.ctx.call("sg_xv_mfcc_backward", N._ptr(x), B, T, N._ptr(scale), C.byref(dz), N._ptr(dfeats), N._ptr(grad),
+                      self._stream())
+        return grad
+
+    def cmvn_backward(self, dout):
+        dout, B, F = self._prep(dout, 1)
+        din = torch.empty_like(dout)
+        self.ctx.call("sg_xv_cmvn_backward", N._ptr(dout), B, F, N._ptr(din), self._stream())
+        return din
+
     def comput_feat_from_feat(self, feats, ori_flag=1, des_flag=2):
         """raw -> CMVN (sic, name as at xv_plda.py:70)."""
         assert ori_flag == 1 and des_flag == 2

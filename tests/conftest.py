@@ -38,3 +38,14 @@ def weights_checksum(w):
     for k in ("emb_mean", "lda", "plda_mean", "plda_transform", "plda_psi", "enroll"):
         h.update(np.ascontiguousarray(w[k]).tobytes())
     return h.hexdigest()
+
+
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_log.txt")
+
+
+def log(msg):
+    """Measured parity numbers of the GPU tests (copied to profiles/ at the end of a round)."""
+    os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+    with open(PARITY_LOG, "a") as f:
+        f.write(msg + "\n")
+    print(msg)

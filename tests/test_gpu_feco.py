@@ -1,0 +1,161 @@
+"""SURVEY 8(f) N1 -- FeCo on the native engine: k-means ids bit-exact against the contract restatement
+(oracle/feco.py), cluster means and their gradient against the reference's step under torch autograd, and the
+hand-chained gradient wav -> MFCC -> FeCo -> CMVN -> TDNN -> loss against the oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import log
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip_model(xv_weights):
+    from speakerguard_amd.model.xv_plda import xv_plda
+    return xv_plda.from_weights(xv_weights, device=DEV, dither=0.0)
+
+
+@pytest.fixture(scope="module")
+def oracle_model(xv_weights):
+    from oracle.xv_plda import XvPlda
+    return XvPlda(xv_weights, threshold=None)
+
+
+def _ids(feat, ratio=0.5, max_iter=10):
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    out, (ids, counts, dims, force, keep) = FeCoDefense(ratio, max_iter=max_iter).fwd(feat.to(DEV))
+    return out, ids.cpu().numpy(), counts.cpu().numpy()
+
+
+def test_kmeans_ids_bit_exact(hip_model):
+    from oracle import feco
+    from speakerguard_amd import synth
+    rs = np.random.RandomState(4)
+    mfcc = hip_model.compute_feat(torch.from_numpy(synth.make_waveforms(3, 48000, seed=70)).to(DEV), flag=1).cpu()
+    cases = [("mfcc 3x300x30", mfcc, 0.5), ("random 2x77x13", torch.from_numpy(rs.randn(2, 77, 13).astype(np.float32)), 0.3),
+             ("logmel-like 2x300x32", torch.from_numpy((rs.randn(2, 300, 32) * 10 - 40).astype(np.float32)), 0.5),
+             ("duplicates", torch.from_numpy(np.repeat(rs.randn(1, 20, 8).astype(np.float32), 4, axis=1)), 0.5)]
+    for name, feat, ratio in cases:
+        _, ids, counts = _ids(feat, ratio)
+        k = int(feat.shape[1] * ratio)
+        for b in range(feat.shape[0]):
+            want = feco.kmeans_ids(feat[b].numpy(), k)
+            assert np.array_equal(ids[b], want), "%s utt %d: %d ids differ" % (name, b, (ids[b] != want).sum())
+            assert np.array_equal(counts[b], np.bincount(want, minlength=k))
+        log("FeCo k-means %s: ids bit-exact, empty clusters %d" % (name, int((counts == 0).sum())))
+
+
+def test_compress_forward_backward_match_reference_step():
+    """Given ids (incl. empty clusters): forward = per-cluster torch.mean / fallback, backward = its autograd."""
+    from oracle import feco
+    from speakerguard_amd import _native as N
+    from speakerguard_amd.metric.metric import _context
+    rs = np.random.RandomState(5)
+    B, F, D, k = 3, 40, 6, 12
+    feat = torch.from_numpy(rs.randn(B, F, D).astype(np.float32))
+    ids = rs.randint(0, k, size=(B, F)).astype(np.int32)
+    ids[ids == 3] = 4  # cluster 3 empty everywhere
+    ids[1][ids[1] == 7] = 8
+    g = torch.from_numpy(rs.randn(B, k, D).astype(np.float32))
+    fd, idd, gd = feat.to(DEV), torch.from_numpy(ids).to(DEV), g.to(DEV)
+    out = torch.empty(B, k, D, device=DEV)
+    counts = torch.empty(B, k, device=DEV, dtype=torch.int32)
+    dfe = torch.empty(B, F, D, device=DEV)
+    ctx, s = _context(DEV), N.current_stream_ptr(DEV)
+    ctx.call("sg_feco_compress", N._ptr(fd), N._ptr(idd), B, F, D, k, N._ptr(out), N._ptr(counts), s)
+    ctx.call("sg_feco_compress_backward", N._ptr(gd), N._ptr(idd), N._ptr(counts), B, F, D, k, 1, N._ptr(dfe), s)
+    x = feat.clone().requires_grad_(True)
+    want = torch.stack([feco.compress_from_ids(x[b], ids[b], k, force=True) for b in range(B)])
+    (want * g).sum().backward()
+    assert (out.cpu() - want.detach()).abs().max().item() < 1e-6
+    assert (dfe.cpu() - x.grad).abs().max().item() < 1e-6
+    assert int(counts[0, 3]) == 0 and torch.equal(out[0, 3].cpu(), feat[0, 3])  # fallback row = frame i
+
+
+def test_single_utterance_drops_empty_clusters():
+    from oracle import feco
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    rs = np.random.RandomState(6)
+    base = rs.randn(1, 10, 4).astype(np.float32)
+    feat = torch.from_numpy(np.repeat(base, 3, axis=1))  # 30 frames, 10 distinct -> k = 15 has empty clusters
+    d = FeCoDefense(0.5)
+    out, saved = d.fwd(feat.to(DEV))
+    ids = saved[0].cpu().numpy()[0]
+    x = feat[0].clone().requires_grad_(True)
+    want = feco.compress_from_ids(x, ids, 15, force=False)
+    assert out.shape == (1,) + tuple(want.shape) and want.shape[0] < 15
+    assert (out[0].cpu() - want.detach()).abs().max().item() < 1e-6
+    g = torch.from_numpy(rs.randn(*want.shape).astype(np.float32))
+    (want * g).sum().backward()
+    got = d.bwd(saved, g.unsqueeze(0).to(DEV))
+    assert (got[0].cpu() - x.grad).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_gradient_through_feco_matches_oracle_autograd(hip_model, oracle_model, level):
+    """d loss / d wav through MFCC -> [FeCo at flag 1 | CMVN -> FeCo at flag 2] -> ... vs the oracle's autograd.
+    The oracle is given the ids the device computed (the clustering is piecewise constant; its own ids are also
+    compared and reported)."""
+    from oracle import attacks as oatk
+    from oracle import feco
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.defended_model import defended_model
+    x = torch.from_numpy(synth.make_waveforms(3, 32000, seed=71))
+    d = FeCoDefense(0.5)
+    dm = defended_model(hip_model, defense=[(level, d)])
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    dec, scores, loss, grad = dm.loss_grad(x.to(DEV), y.to(DEV), SEC4SR_CrossEntropy())
+    # the same forward through the public (forward-only) path
+    dec2, scores2 = dm.make_decision(x.to(DEV))
+    assert torch.equal(dec, dec2) and torch.equal(scores, scores2)
+    feats_dev = hip_model.compute_feat(x.to(DEV), flag=level)
+    ids_dev = d.fwd(feats_dev)[1][0].cpu().numpy()
+    xin = x.clone().requires_grad_(True)
+    feats = oracle_model.compute_feat(xin, flag=level)
+    k = feats.shape[1] // 2
+    same = np.mean([np.mean(feco.kmeans_ids(feats[b].detach().numpy(), k) == ids_dev[b]) for b in range(3)])
+    comp = torch.stack([feco.compress_from_ids(feats[b], ids_dev[b], k, force=True) for b in range(3)])
+    _, sc = oracle_model.make_decision(comp, flag=level)
+    lo = oatk.cross_entropy_loss(sc, y)
+    lo.backward(torch.ones(3))
+    want, got = xin.grad.numpy(), grad.cpu().numpy()
+    gs = np.abs(want).max()
+    err = np.abs(got - want).max() / gs
+    log("FeCo at flag %d: oracle-feature ids equal to device ids %.4f; wav grad err/max %.3e; score err %.3e" % (
+        level, same, err, (scores.cpu() - sc.detach()).abs().max().item()))
+    assert dec.cpu().tolist() == sc.argmax(1).tolist()
+    assert (scores.cpu() - sc.detach()).abs().max().item() < 5e-3
+    # Stage by stage (tools/feco_debug.py) the FeCo and MFCC backward are exact given the oracle's upstream
+    # gradient (0 and 2.5e-6); what remains is the TDNN's own fp32 behaviour: one ReLU whose pre-activation is
+    # within round-off of 0 flips between the two implementations and changes the gradient of its receptive
+    # field (seen at flag 2: 0.1 % of the samples, 6e-3 of max).  Hence a bulk tolerance plus a bound on outliers.
+    bad = float((np.abs(got - want) > 3e-3 * gs).mean())
+    assert bad < 5e-3 and err < 2e-2, (bad, err)
+    assert same > 0.97
+
+
+def test_pgd_against_feco_defended_model(hip_model):
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.defense.feature_level import FeCo, FeCoDefense
+    from speakerguard_amd.model.defended_model import defended_model
+    x = torch.from_numpy(synth.make_waveforms(4, 32000, seed=72)).to(DEV)
+    dm = defended_model(hip_model, defense=[(1, FeCoDefense(0.5))])
+    y = dm.make_decision(x)[0]
+    adv, success = PGD(dm, epsilon=0.002, step_size=0.0004, max_iter=5, batch_size=4, verbose=0).attack(x, y)
+    assert (adv - x).abs().max().item() <= 0.002 + 1e-7 and adv.abs().max().item() <= 1.0
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    l0 = dm.loss_grad(x, y, SEC4SR_CrossEntropy(), want_grad=False)[2]
+    l1 = dm.loss_grad(adv, y, SEC4SR_CrossEntropy(), want_grad=False)[2]
+    log("PGD-5 vs FeCo-defended xv_plda: CE loss %s -> %s, success %s" % (l0.cpu().numpy().round(3), l1.cpu().numpy().round(3), success))
+    assert (l1 >= l0 - 1e-4).all()  # untargeted CE ascent
+    # the reference-signature function gives the same forward
+    f = hip_model.compute_feat(x, flag=1)
+    assert torch.equal(FeCo(f, 'kmeans', 0.5, 'L2'), FeCoDefense(0.5)(f))
+    with pytest.raises(NotImplementedError):
+        FeCo(f, 'warped_kmeans', 0.5, 'ts')

@@ -1,0 +1,40 @@
+import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import numpy as np, torch
+from speakerguard_amd import synth
+from speakerguard_amd.model.xv_plda import xv_plda
+from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+from speakerguard_amd.defense.feature_level import FeCoDefense
+from oracle.xv_plda import XvPlda
+from oracle import attacks as oatk, feco
+DEV = torch.device("cuda:0")
+w = synth.make_xv_weights()
+hm = xv_plda.from_weights(w, device=DEV, dither=0.0)
+om = XvPlda(w)
+x = torch.from_numpy(synth.make_waveforms(3, 32000, seed=71))
+with torch.no_grad():
+    y = om.make_decision(x)[0]
+d = FeCoDefense(0.5)
+# device chain, stage by stage
+feats_raw, saved = hm.frontend_forward(x.to(DEV))
+feats_c = hm.comput_feat_from_feat(feats_raw)
+comp, sv = d.fwd(feats_c)
+dec, sc, loss, g_comp = hm.loss_grad(comp, y.to(DEV), SEC4SR_CrossEntropy(), flag=2)
+g_c = d.bwd(sv, g_comp)
+g_raw = hm.cmvn_backward(g_c)
+g_x = hm.frontend_backward(saved, g_raw)
+ids = sv[0].cpu().numpy()
+# oracle chain with retained grads
+xin = x.clone().requires_grad_(True)
+o_raw = om.compute_feat(xin, flag=1); o_raw.retain_grad()
+o_c = om.comput_feat_from_feat(o_raw); o_c.retain_grad()
+o_comp = torch.stack([feco.compress_from_ids(o_c[b], ids[b], o_c.shape[1] // 2, True) for b in range(3)]); o_comp.retain_grad()
+_, osc = om.make_decision(o_comp, flag=2)
+oatk.cross_entropy_loss(osc, y).backward(torch.ones(3))
+def rep(name, a, b):
+    a, b = a.cpu().numpy(), b.detach().numpy()
+    print("%-10s max|b| %.3e  max err %.3e  rel %.3e  bad frac %.2e" % (name, np.abs(b).max(), np.abs(a-b).max(), np.abs(a-b).max()/np.abs(b).max(), (np.abs(a-b) > 3e-3*np.abs(b).max()).mean()))
+rep("comp", comp, o_comp); rep("scores", sc, osc)
+rep("g_comp", g_comp, o_comp.grad); rep("g_c", g_c, o_c.grad); rep("g_raw", g_raw, o_raw.grad); rep("g_x", g_x, xin.grad)
+# device backward fed with the ORACLE's upstream gradients
+rep("bwd feco|o", d.bwd(sv, o_comp.grad.to(DEV)), o_c.grad)
+rep("bwd mfcc|o", hm.frontend_backward(saved, o_raw.grad.to(DEV)), xin.grad)
