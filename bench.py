@@ -94,8 +94,9 @@ def main():
     def attack(k):
         out = model.pgd_run(x, y, lower, upper, spec, STEP, k, 1)
         if dist is not None:  # the attack's only exchange: success flags of every shard
-            flags = [torch.empty_like(out[1]) for _ in range(world)]
-            dist.all_gather(flags, out[1])
+            mine = out[1].to(torch.uint8)  # RCCL has no bool type
+            flags = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(flags, mine)
             return out, torch.cat(flags)
         return out, out[1]
 

@@ -7,10 +7,11 @@
 //   PLDA log-likelihood-ratio against each enrolled speaker                      plda.py:140-190
 //   decision = argmax, rejected (-1) unless max > threshold                      iv_plda.py:182-194
 //   loss (attack/utils.py:7-102) and d loss/d scores, then the chain back to d loss/d fc1-output.
-// One block of 256 threads per utterance; reductions are wavefront shuffles + a 4-entry LDS pass.
-// The matrix-vector loops are unrolled 8-16x: with one block per utterance they are bound by the
-// latency of the (L2-resident) matrix loads, and un-unrolled they issued one dependent load at a
-// time (measured 157 us for the kernel).
+// One block of 1024 threads per utterance; reductions are wavefront shuffles + a 16-entry LDS pass.
+// The four matrix-vector products are bound by the LATENCY of the (L2-resident) matrix loads, not by bandwidth
+// (1.2 MB per utterance): un-unrolled they issued one dependent load at a time (157 us for the kernel), unrolled
+// 8-16x with 256 threads 97 us; now the K range of every product is split over the four 256-thread quarters of
+// the block (4x the loads in flight), partial sums are combined in a fixed order through LDS.
 #include "loss_device.h"
 #include "sg_internal.h"
 
@@ -25,16 +26,44 @@ struct TailModelDev {
     float threshold, logdet_given, logdet_without;
 };
 
+constexpr int kTailThreads = 1024;
+constexpr int kTailParts = kTailThreads / 256;
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < kTailThreads / 64; ++i) r += red[i];
+    return r;
 }
 
-__global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* __restrict__ fc1_part, int nsplit, int B,
+// out[n] = sum_k W[k * ld + n] * v[k] for n < N (v, out, part in LDS).  Quarter q of the block takes the k range
+// [q K/4, (q+1) K/4); the four partial sums are added in quarter order.  Ends with a barrier.
+__device__ __forceinline__ void matvec_cols(const float* __restrict__ W, int ld, int K, int N, const float* v,
+                                            float* out, float* part) {
+    const int q = threadIdx.x >> 8, c = threadIdx.x & 255;
+    const int k0 = (int)((long long)K * q / kTailParts), k1 = (int)((long long)K * (q + 1) / kTailParts);
+    for (int n = c; n < N; n += 256) {
+        float acc = 0.f;
+#pragma unroll 16
+        for (int k = k0; k < k1; ++k) acc += W[(size_t)k * ld + n] * v[k];
+        part[q * kMaxD + n] = acc;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += kTailThreads) {
+        float r = part[n];
+#pragma unroll
+        for (int i = 1; i < kTailParts; ++i) r += part[i * kMaxD + n];
+        out[n] = r;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, const float* __restrict__ fc1_part, int nsplit, int B,
                                                    const int64_t* __restrict__ y, sg_loss_spec ls, int want_grad,
                                                    float* __restrict__ tdnn_emb, float* __restrict__ emb_out,
                                                    float* __restrict__ scores_out, int64_t* __restrict__ dec_out,
@@ -44,13 +73,15 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     __shared__ float e1[kEmb];
     __shared__ float e2[kMaxD], e4[kMaxD], e5[kMaxD], dv[kMaxD];
     __shared__ float sc[kMaxS], dsc[kMaxS];
-    __shared__ float red[4];
+    __shared__ float red[kTailThreads / 64];
+    __shared__ float part[kTailParts * kMaxD];
+    constexpr int NT = kTailThreads;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int D = m.D, S = m.S;
     const float sqrtD = sqrtf((float)D);
 
     // 1. fc1 output, global-mean subtraction
-    for (int i = tid; i < kEmb; i += 256) {
+    for (int i = tid; i < kEmb; i += NT) {
         float v = 0.f;
         for (int z = 0; z < nsplit; ++z) v += fc1_part[((size_t)z * B + b) * kEmb + i];
         v += m.fc1_b[i];
@@ -58,32 +89,25 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
         e1[i] = v - m.emb_mean[i];
     }
     __syncthreads();
-    // 2. LDA
+    // 2. LDA (the offset column of the (D, 513) matrix is row kEmb of the transposed copy)
+    matvec_cols(m.lda_t, D, kEmb, D, e1, e2, part);
     float n2 = 0.f;
-    for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-#pragma unroll 16
-        for (int i = 0; i < kEmb; ++i) acc += m.lda_t[(size_t)i * D + d] * e1[i];
-        acc += m.lda_t[(size_t)kEmb * D + d];
+    for (int d = tid; d < D; d += NT) {
+        const float acc = e2[d] + m.lda_t[(size_t)kEmb * D + d];
         e2[d] = acc;
         n2 += acc * acc;
     }
     // 3. length normalisation (ratio is a constant for the backward pass)
     const float ratio = sqrtD / sqrtf(block_sum(n2, red));
-    for (int d = tid; d < D; d += 256) e2[d] = e2[d] * ratio - m.plda_mean[d];
+    for (int d = tid; d < D; d += NT) e2[d] = e2[d] * ratio - m.plda_mean[d];
     __syncthreads();
     // 4. PLDA transform + normalisation factor
+    matvec_cols(m.plda_pt, D, D, D, e2, e4, part);
     float qp = 0.f;
-    for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < D; ++j) acc += m.plda_pt[(size_t)j * D + d] * e2[j];
-        e4[d] = acc;
-        qp += acc * acc / (m.plda_psi[d] + 1.f);
-    }
+    for (int d = tid; d < D; d += NT) qp += e4[d] * e4[d] / (m.plda_psi[d] + 1.f);
     const float q = block_sum(qp, red);
     const float fac = sqrtf((float)D / q);
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid; d < D; d += NT) {
         e5[d] = e4[d] * fac;
         if (emb_out) emb_out[(size_t)b * D + d] = e5[d];
     }
@@ -97,7 +121,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
         const float without = -0.5f * (m.logdet_without + l2pi + s0);
-        for (int s = wid; s < S; s += 4) {
+        for (int s = wid; s < S; s += NT / 64) {
             float s1 = 0.f;
             for (int d = lane; d < D; d += 64) {
                 const float psi = m.plda_psi[d];
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
         }
     }
     __syncthreads();
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += NT) {
         if (scores_out) scores_out[(size_t)b * S + s] = sc[s];
         dsc[s] = 0.f;
     }
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     if (!want_grad || !demb) return;
     // 9. d/d e5 of the score combination
     float dotp = 0.f;
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid; d < D; d += NT) {
         const float psi = m.plda_psi[d];
         const float r = psi / (psi + 1.f);
         const float iv1 = 1.f / (1.f + r), iv0 = 1.f / (psi + 1.f);
@@ -147,23 +171,15 @@ __global__ __launch_bounds__(256) void tail_kernel(TailModelDev m, const float* 
     }
     // 10. through the PLDA normalisation factor (differentiable, plda.py:92-97)
     const float dot = block_sum(dotp, red);
-    for (int d = tid; d < D; d += 256) dv[d] = fac * dv[d] - dot * (fac / q) * e4[d] / (m.plda_psi[d] + 1.f);
+    for (int d = tid; d < D; d += NT) dv[d] = fac * dv[d] - dot * (fac / q) * e4[d] / (m.plda_psi[d] + 1.f);
     __syncthreads();
     // 11-12. P^T, length-norm ratio
-    for (int j = tid; j < D; j += 256) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < D; ++d) acc += m.plda_p[(size_t)d * D + j] * dv[d];
-        e2[j] = acc * ratio;
-    }
+    matvec_cols(m.plda_p, D, D, D, dv, e2, part);
+    for (int j = tid; j < D; j += NT) e2[j] *= ratio;
     __syncthreads();
     // 13. LDA^T -> d loss / d fc1 output
-    for (int i = tid; i < kEmb; i += 256) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < D; ++d) acc += m.lda[(size_t)d * (kEmb + 1) + i] * e2[d];
-        demb[(size_t)b * kEmb + i] = acc;
-    }
+    matvec_cols(m.lda, kEmb + 1, D, kEmb, e2, e1, part);
+    for (int i = tid; i < kEmb; i += NT) demb[(size_t)b * kEmb + i] = e1[i];
 }
 
 hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
@@ -174,7 +190,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi; m.enroll = x.enroll;
     m.D = x.D; m.S = x.S; m.threshold = x.threshold;
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
-    hipLaunchKernelGGL(tail_kernel, dim3(a.B), dim3(256), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
+    hipLaunchKernelGGL(tail_kernel, dim3(a.B), dim3(kTailThreads), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
                        a.tdnn_emb, a.emb, a.scores, a.decisions, a.loss_out, a.demb, a.loss_trace, a.decision_trace,
                        a.success);
     return hipGetLastError();
