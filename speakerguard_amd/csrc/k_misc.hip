@@ -156,37 +156,42 @@ __device__ __forceinline__ void cmvn_window(int t, int F, int& start, int& end) 
     }
 }
 
-// grid (B), block 256.  out row stride ld_out >= 30; columns 30..ld_out-1 are zeroed (GEMM K pad).
-__global__ __launch_bounds__(256) void cmvn_fwd_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+// grid (B), block 1024.  out row stride ld_out >= 30; columns 30..ld_out-1 are zeroed (GEMM K pad).
+// One block per utterance is all the parallelism there is (64 blocks at B = 64), so the kernels are latency
+// bound: 1024 threads and 32 row-strided partial sums per column keep 4x more loads in flight than the first
+// version (256 threads, 8 partials: 23 us per launch for 2.3 MB).
+constexpr int kCmvnThreads = 1024;
+constexpr int kCmvnParts = kCmvnThreads / 32;
+__global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
                                                        int ld_out, int F) {
     const int b = blockIdx.x;
     const float* x = in + (size_t)b * F * ld_in;
     float* y = out + (size_t)b * F * ld_out;
     __shared__ double total[kCep];
-    __shared__ double part[8][32];
+    __shared__ double part[kCmvnParts][32];
     if (F <= kCmnWindow) {
-        // every window is the whole utterance: one column sum per cepstrum, 8 row-strided partial
+        // every window is the whole utterance: one column sum per cepstrum, 32 row-strided partial
         // sums per column combined in a fixed order
         {
             const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
             double acc = 0.0;
             if (d < kCep)
-                for (int t = r; t < F; t += 8) acc += (double)x[(size_t)t * ld_in + d];
+                for (int t = r; t < F; t += kCmvnParts) acc += (double)x[(size_t)t * ld_in + d];
             part[r][d] = acc;
         }
         __syncthreads();
         if (threadIdx.x < kCep) {
             double acc = 0.0;
-            for (int r = 0; r < 8; ++r) acc += part[r][threadIdx.x];
+            for (int r = 0; r < kCmvnParts; ++r) acc += part[r][threadIdx.x];
             total[threadIdx.x] = acc;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < F * ld_out; i += 256) {
+        for (int i = threadIdx.x; i < F * ld_out; i += kCmvnThreads) {
             const int t = i / ld_out, d = i - t * ld_out;
             y[i] = d < kCep ? x[(size_t)t * ld_in + d] - (float)(total[d] / (double)F) : 0.f;
         }
     } else {
-        for (int i = threadIdx.x; i < F * ld_out; i += 256) {
+        for (int i = threadIdx.x; i < F * ld_out; i += kCmvnThreads) {
             const int t = i / ld_out, d = i - t * ld_out;
             float v = 0.f;
             if (d < kCep) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void cmvn_fwd_kernel(const float* __restrict__
 
 // d_in[u] = d_out[u] - sum_{t : u in window(t)} d_out[t] / |window(t)|
 // d_out arrives as `nsplit` split-K slabs of the tdnn1 data-gradient contraction (summed in order).
-__global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout, int nsplit,
+__global__ __launch_bounds__(kCmvnThreads) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout, int nsplit,
                                                        long long slab_stride, float* __restrict__ din, int ld_din,
                                                        int F) {
     const int b = blockIdx.x;
@@ -216,10 +221,10 @@ __global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__
         return v;
     };
     __shared__ double total[kCep];
-    __shared__ double part[8][32];
+    __shared__ double part[kCmvnParts][32];
     __shared__ float stage[kCmnWindow * kCep];  // summed slabs of one utterance (<= 300 frames)
     if (F <= kCmnWindow) {
-        for (int i = threadIdx.x; i < F * kCep; i += 256) {
+        for (int i = threadIdx.x; i < F * kCep; i += kCmvnThreads) {
             const int t = i / kCep, d = i - t * kCep;
             stage[i] = gsum(t, d);
         }
@@ -228,22 +233,22 @@ __global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__
             const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
             double acc = 0.0;
             if (d < kCep)
-                for (int t = r; t < F; t += 8) acc += (double)stage[t * kCep + d];
+                for (int t = r; t < F; t += kCmvnParts) acc += (double)stage[t * kCep + d];
             part[r][d] = acc;
         }
         __syncthreads();
         if (threadIdx.x < kCep) {
             double acc = 0.0;
-            for (int r = 0; r < 8; ++r) acc += part[r][threadIdx.x];
+            for (int r = 0; r < kCmvnParts; ++r) acc += part[r][threadIdx.x];
             total[threadIdx.x] = acc / (double)F;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < F * kCep; i += 256) {
+        for (int i = threadIdx.x; i < F * kCep; i += kCmvnThreads) {
             const int t = i / kCep, d = i - t * kCep;
             y[(size_t)t * ld_din + d] = stage[i] - (float)total[d];
         }
     } else {
-        for (int i = threadIdx.x; i < F * kCep; i += 256) {
+        for (int i = threadIdx.x; i < F * kCep; i += kCmvnThreads) {
             const int u = i / kCep, d = i - u * kCep;
             double acc = 0.0;
             for (int t = 0; t < F; ++t) {
@@ -257,12 +262,12 @@ __global__ __launch_bounds__(256) void cmvn_bwd_kernel(const float* __restrict__
 }
 
 hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, hipStream_t s) {
-    hipLaunchKernelGGL(cmvn_fwd_kernel, dim3(B), dim3(256), 0, s, in, ld_in, out, ld_out, F);
+    hipLaunchKernelGGL(cmvn_fwd_kernel, dim3(B), dim3(kCmvnThreads), 0, s, in, ld_in, out, ld_out, F);
     return hipGetLastError();
 }
 hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long slab_stride, float* din, int ld_din,
                            int B, int F, hipStream_t s) {
-    hipLaunchKernelGGL(cmvn_bwd_kernel, dim3(B), dim3(256), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
+    hipLaunchKernelGGL(cmvn_bwd_kernel, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
     return hipGetLastError();
 }
 

@@ -361,6 +361,20 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
     return SG_OK;
 }
 
+int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* dfeats_dev, float* grad_dev,
+                          void* stream) {
+    if (!x_dev || !dfeats_dev || !grad_dev) return an_fail(ctx, SG_ERR_ARG, "bad argument");
+    AnDims d;
+    int rc = an_check(ctx, B, T, 0, &d);  // sizes the per-frame gradient scratch
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    AnWorkspace& w = ctx->an_ws;
+    AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, w.scale, 1, s));
+    AN_HIP(launch_an_logmel_bwd(ctx->an_tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, s));
+    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
+    return SG_OK;
+}
+
 int sg_an_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag, int64_t* decisions_dev,
                   float* scores_dev, float* emb_dev, void* stream) {
     AnDims d;

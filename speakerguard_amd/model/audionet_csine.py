@@ -101,6 +101,20 @@ class audionet_csine(EngineOps):
     def raw(self, x):
         return self.compute_feat(x, 1)
 
+    # ---- front-end with its backward (used when a feature-level defense sits behind it) -------------
+    def frontend_forward(self, x):
+        x, B, T = self._prep(x, 0)
+        return self.compute_feat(x, 1), x
+
+    def frontend_backward(self, saved, dfeats):
+        """d loss / d log-mel (B,F,32) -> d loss / d wav (B,1,T)."""
+        x = saved
+        dfeats = dfeats.to(self.device, torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        self.ctx.call("sg_an_logmel_backward", N._ptr(x), x.shape[0], x.shape[2], N._ptr(dfeats), N._ptr(grad),
+                      self._stream())
+        return grad
+
     def _forward(self, x, flag, want_emb=False):
         x, B, TF = self._prep(x, flag)
         dec = torch.empty(B, device=self.device, dtype=torch.int64)

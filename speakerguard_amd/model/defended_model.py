@@ -4,8 +4,8 @@ With ``defense=None`` (reference :127-128,156-157) every call is passed straight
 including the native ``loss_grad`` / ``pgd_run`` entry points the attacks use.  Input- and
 feature-level defenses are applied for the forward calls exactly like ``process_sequential``
 (:46-65).  The gradient THROUGH feature-level defenses is chained by hand for
-defenses that expose ``fwd`` / ``bwd`` (``speakerguard_amd.defense.feature_level.FeCoDefense``) on an xv_plda
-base model in sequential order; any other defended configuration raises in ``loss_grad`` instead of silently
+defenses that expose ``fwd`` / ``bwd`` (``speakerguard_amd.defense.feature_level.FeCoDefense``) on the native
+xv_plda / audionet_csine base models in sequential order; any other defended configuration raises in ``loss_grad`` instead of silently
 ignoring the defense.
 """
 import warnings
@@ -119,14 +119,14 @@ class defended_model:
         chainable = (self.order == sequential and hasattr(bm, 'frontend_forward') and not self.flag2defense.get(0)
                      and all(hasattr(d, 'fwd') and hasattr(d, 'bwd') for f in (1, 2) for d in self.flag2defense.get(f, [])))
         if not chainable:
-            raise NotImplementedError('gradient through this defense configuration is not built: needs an xv_plda base '
+            raise NotImplementedError('gradient through this defense configuration is not built: needs a native base '
                                       'model, sequential order, and feature-level defenses with fwd/bwd (FeCoDefense)')
         feats, saved_front = bm.frontend_forward(x)
         tape1, tape2 = [], []
         for d in self.flag2defense[1]:
             feats, sv = d.fwd(feats)
             tape1.append((d, sv))
-        if self.flag2defense[2]:
+        if self.flag2defense.get(2):  # xv_plda only (AudioNet has no level 2, audionet_csine.py:127-129)
             feats = bm.comput_feat_from_feat(feats, ori_flag=1, des_flag=2)
             for d in self.flag2defense[2]:
                 feats, sv = d.fwd(feats)

@@ -159,3 +159,50 @@ def test_pgd_against_feco_defended_model(hip_model):
     assert torch.equal(FeCo(f, 'kmeans', 0.5, 'L2'), FeCoDefense(0.5)(f))
     with pytest.raises(NotImplementedError):
         FeCo(f, 'warped_kmeans', 0.5, 'ts')
+
+
+# ------------------------------------------------------------------------------ BASELINE config 4 in miniature
+def test_audionet_feco_gradient_and_pgd_eot():
+    """PGD + EOT against a FeCo-defended AudioNet (BASELINE.json configs[3], small batch): the chained gradient
+    wav -> log-mel -> FeCo -> CNN vs the oracle's autograd with the device's cluster ids, then the attack itself.
+    AudioNet's oracle is unpinned, so this is agreement with this repo's restatement."""
+    from oracle import attacks as oatk
+    from oracle import feco
+    from oracle.audionet import AudioNet
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    sd = synth.make_audionet_state_dict(seed=0, num_class=251)
+    hip, ora = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
+    x = torch.from_numpy(synth.make_waveforms(3, 32000, seed=73))
+    d = FeCoDefense(0.5)
+    dm = defended_model(hip, defense=[(1, d)])
+    y = dm.make_decision(x.to(DEV))[0]
+    dec, scores, loss, grad = dm.loss_grad(x.to(DEV), y, SEC4SR_CrossEntropy())
+    ids = d.fwd(hip.compute_feat(x.to(DEV), flag=1))[1][0].cpu().numpy()
+    xin = x.clone().requires_grad_(True)
+    feats = ora.compute_feat(xin, flag=1)
+    k = feats.shape[1] // 2
+    same = np.mean([np.mean(feco.kmeans_ids(feats[b].detach().numpy(), k) == ids[b]) for b in range(3)])
+    comp = torch.stack([feco.compress_from_ids(feats[b], ids[b], k, force=True) for b in range(3)])
+    _, sc = ora.make_decision(comp, flag=1)
+    oatk.cross_entropy_loss(sc, y.cpu()).backward(torch.ones(3))
+    want, got = xin.grad.numpy(), grad.cpu().numpy()
+    gs = np.abs(want).max()
+    err = np.abs(got - want).max() / gs
+    log("FeCo-defended AudioNet: ids equal %.4f, logits err %.3e, wav grad err/max %.3e" % (
+        same, (scores.cpu() - sc.detach()).abs().max().item(), err))
+    assert dec.cpu().tolist() == sc.argmax(1).tolist()
+    bad = float((np.abs(got - want) > 3e-3 * gs).mean())
+    assert bad < 5e-3 and err < 2e-2, (bad, err)
+    atk = PGD(dm, epsilon=0.002, step_size=0.0004, max_iter=10, batch_size=3, EOT_size=2, EOT_batch_size=1, verbose=0)
+    adv, success = atk.attack(x.to(DEV), y)
+    l0 = dm.loss_grad(x.to(DEV), y, SEC4SR_CrossEntropy(), want_grad=False)[2]
+    l1 = dm.loss_grad(adv, y, SEC4SR_CrossEntropy(), want_grad=False)[2]
+    log("PGD-10 + EOT 2/1 vs FeCo-defended AudioNet: CE loss %s -> %s, success %s" % (
+        l0.cpu().numpy().round(3), l1.cpu().numpy().round(3), success))
+    assert (adv - x.to(DEV)).abs().max().item() <= 0.002 + 1e-7
+    assert (l1 >= l0 - 1e-4).all()
