@@ -477,6 +477,47 @@ def test_cw2_matches_oracle(hip_model, oracle_model, dev, capsys):
     assert (d > 2e-4).mean() < 1e-3 and d.max() <= 2 * 2e-3 * 6 + 1e-6
 
 
+def test_cw2_targeted_sv_batch32(xv_weights, dev):
+    """BASELINE.json configs[2]: CW2 (L2, Adam inner optimiser) targeted on the SV task, batch 32.  Imposter
+    utterances are pushed to be accepted as the single enrolled speaker.  1 s audio vs the oracle loop; then the
+    3 s batch on the device alone for the properties that do not need the oracle."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.CW2 import CW2
+    from speakerguard_amd.model.xv_plda import xv_plda
+    w = dict(xv_weights)
+    w["enroll"] = xv_weights["enroll"][:1].copy()  # SV: one enrolled speaker
+    x = torch.from_numpy(synth.make_waveforms(32, 16000, seed=34))
+    probe = XvPlda(w, threshold=None)
+    with torch.no_grad():
+        clean = probe.make_decision(x)[1][:, 0]
+    thr = float(clean.max()) + 2.0  # every utterance starts rejected
+    om, hm = XvPlda(w, threshold=thr), xv_plda.from_weights(w, threshold=thr, device=dev, dither=0.0)
+    y = torch.zeros(32, dtype=torch.long)
+    assert hm.make_decision(x.to(dev))[0].cpu().tolist() == [-1] * 32
+    kw = dict(task="SV", targeted=True, confidence=0.0, initial_const=1e-2, binary_search_steps=2, max_iter=5,
+              stop_early=True, stop_early_iter=5, lr=2e-3, batch_size=32)
+    oadv, osucc = oatk.CW2(om, **kw).attack(x.clone(), y)
+    adv, succ = CW2(hm, verbose=0, **kw).attack(x.to(dev), y.to(dev))
+    d = (adv.cpu() - oadv).abs().numpy()
+    log("CW2 targeted SV, batch 32 x 1 s: max |x_adv - oracle| %.3e, differing(>2e-4) %.4f%%, success %d/32 (oracle %d/32)" % (
+        d.max(), 100 * (d > 2e-4).mean(), sum(succ), sum(osucc)))
+    assert succ == osucc
+    assert (d > 2e-4).mean() < 1e-3 and d.max() <= 2 * 2e-3 * 5 + 1e-6
+    # full 3 s batch: success flags agree with the model's own decision on the returned audio
+    x3 = torch.from_numpy(synth.make_waveforms(32, 48000, seed=35)).to(dev)
+    thr3 = float(hm.make_decision(x3)[1][:, 0].max()) + 2.0
+    hm.set_enroll(threshold=thr3)
+    adv3, succ3 = CW2(hm, verbose=0, **dict(kw, max_iter=8)).attack(x3, y.to(dev))
+    dec3 = hm.make_decision(adv3)[0].cpu().tolist()
+    assert all((dd == 0) == ss for dd, ss in zip(dec3, succ3))
+    assert adv3.abs().max().item() <= 1.0 and torch.isfinite(adv3).all()
+    l2 = (adv3 - x3).flatten(1).norm(dim=1)
+    log("CW2 targeted SV, batch 32 x 3 s (device only): success %d/32, mean L2 of successes %.4f" % (
+        sum(succ3), float(l2[torch.tensor(succ3)].mean()) if any(succ3) else float("nan")))
+
+
 def test_fakebob_matches_oracle_with_shared_noise(hip_model, oracle_model, dev):
     """FAKEBOB / NES (forward-only queries): both sides draw the NES noise from the same seeded CPU
     generator so the trajectories are comparable."""
