@@ -20,6 +20,7 @@
 // staging of chunk c+1 / c+2 is issued in the middle of chunk c's MFMA stream (one barrier/chunk).
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "sg_internal.h"
 
@@ -345,13 +346,19 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
     int st_off;  // LDS float offset of this thread's first staged float4 (the others: + i * 1024)
     if (role_a) {
         const int c4 = ts & 7;
+        // one integer division per thread and segment; the other three rows are 32 apart
+        int b = (m0 + (ts >> 3)) / p.Tc;
+        int t = (m0 + (ts >> 3)) - b * p.Tc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = m0 + (ts >> 3) + 32 * i;
-            const int b = r / p.Tc;
-            const int t = r - b * p.Tc;
             row_off[i] = (unsigned)(((b * p.Ta + t) * p.lda + c4 * 4) * 4);
             a_t[i] = r < p.M ? t : -(1 << 28);
+            t += 32;
+            while (t >= p.Tc) {
+                t -= p.Tc;
+                ++b;
+            }
         }
         st_off = (ts >> 3) * 32 + ((c4 ^ ((ts >> 4) & 7)) << 2);  // row stride 32 floats; rows + 32 i keep the swizzle
     } else {
@@ -404,25 +411,33 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
         if (c_begin + 1 < c_end) load_chunk();
     }
     __syncthreads();
+    // Per-lane LDS read pointers are fixed for the whole segment (one per k-group, the XOR swizzle folded in);
+    // the stage offset is a compile-time constant of the body below, so it lands in the ds_read / ds_write
+    // immediate and a chunk issues no address VALU at all (every VALU instruction costs matrix-pipe cycles).
     const int sw = (l31 >> 1) & 7;
-    const int a_row = (wm * 64 + l31) * 32;
-    const int b_col = (lhi * BN + wn * 32 + l31) * 4;
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
+    const float* a_base = As + (wm * 64 + l31) * 32;
+    const float* a_kg0 = a_base + (((0 * 2 + lhi) ^ sw) << 2);
+    const float* a_kg1 = a_base + (((1 * 2 + lhi) ^ sw) << 2);
+    const float* a_kg2 = a_base + (((2 * 2 + lhi) ^ sw) << 2);
+    const float* a_kg3 = a_base + (((3 * 2 + lhi) ^ sw) << 2);
+    const float* b_base = Bs + (lhi * BN + wn * 32 + l31) * 4;
+    float* st_base = smem + st_off;
+    auto chunk = [&](int c, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int SOFF = BUF * BK * BM;        // this chunk's stage
+        constexpr int NOFF = (BUF ^ 1) * BK * BM;  // the stage the next chunk is written to
         __builtin_amdgcn_sched_barrier(0);
-        const float* a_s = As + buf * BK * BM + a_row;
-        const float* b_s = Bs + buf * BK * BN + b_col;
-        float4 a0 = *reinterpret_cast<const float4*>(a_s + ((lhi ^ sw) << 2));
-        float4 a1 = *reinterpret_cast<const float4*>(a_s + 32 * 32 + ((lhi ^ sw) << 2));
-        float4 b0 = *reinterpret_cast<const float4*>(b_s);
+        float4 a0 = *reinterpret_cast<const float4*>(a_kg0 + SOFF);
+        float4 a1 = *reinterpret_cast<const float4*>(a_kg0 + SOFF + 32 * 32);
+        float4 b0 = *reinterpret_cast<const float4*>(b_base + SOFF);
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             float4 na0, na1, nb0;
             if (kg < 3) {
-                const int slot = (((kg + 1) * 2 + lhi) ^ sw) << 2;
-                na0 = *reinterpret_cast<const float4*>(a_s + slot);
-                na1 = *reinterpret_cast<const float4*>(a_s + 32 * 32 + slot);
-                nb0 = *reinterpret_cast<const float4*>(b_s + (kg + 1) * 2 * BN * 4);
+                const float* an = kg == 0 ? a_kg1 : kg == 1 ? a_kg2 : a_kg3;
+                na0 = *reinterpret_cast<const float4*>(an + SOFF);
+                na1 = *reinterpret_cast<const float4*>(an + SOFF + 32 * 32);
+                nb0 = *reinterpret_cast<const float4*>(b_base + SOFF + (kg + 1) * 2 * BN * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
@@ -435,14 +450,26 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kg == 1) {
-                if (c + 1 < c_end && !(p.ablate & 2)) store_chunk(buf ^ 1);
+                if (c + 1 < c_end && !(p.ablate & 2)) {
+                    float* d = st_base + NOFF;
+                    *reinterpret_cast<i32x4*>(d + 0 * 1024) = r0;
+                    *reinterpret_cast<i32x4*>(d + 1 * 1024) = r1;
+                    *reinterpret_cast<i32x4*>(d + 2 * 1024) = r2;
+                    *reinterpret_cast<i32x4*>(d + 3 * 1024) = r3;
+                }
                 if (c + 2 < c_end && !(p.ablate & 1)) load_chunk();
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (kg < 3) { a0 = na0; a1 = na1; b0 = nb0; }
         }
         if (!(p.ablate & 4)) __syncthreads();
+    };
+    int c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
     }
+    if (c < c_end) chunk(c, std::integral_constant<int, 0>{});
 }
 
 // Walk the accumulator fragments of a tile.  C/D layout of the 32x32 MFMA: col = lane & 31,
