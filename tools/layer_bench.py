@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layers", type=str, default="1,2,3,4,5,-5,-4,-3,-2,-1")
+    ap.add_argument("--repeats", type=int, default=5, help="timing rounds per layer; the best and the median are printed")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     model = xv_plda.from_weights(synth.make_xv_weights(), device=dev, dither=0.0)
@@ -32,11 +33,14 @@ def main():
     torch.cuda.synchronize()
     tot_ms, tot_fl = 0.0, 0.0
     for l in [int(v) for v in args.layers.split(",")]:
-        ms, fl, rows = model.time_layer(l, args.batch, 48000, args.iters)
+        runs = sorted(model.time_layer(l, args.batch, 48000, args.iters) for _ in range(args.repeats))
+        ms, fl, rows = runs[0]
+        med = runs[len(runs) // 2][0]
         tf = fl / (ms * 1e-3) / 1e12
         tot_ms += ms
         tot_fl += fl
-        print("layer %+d  tile_rows %3d  %8.3f ms  %7.2f TFLOP/s  %5.1f %% of 157.3" % (l, rows, ms, tf, 100 * tf / 157.3))
+        print("layer %+d  tile_rows %3d  %8.3f ms  %7.2f TFLOP/s  %5.1f %% of 157.3   (median %.3f ms)" % (
+            l, rows, ms, tf, 100 * tf / 157.3, med))
     print("sum        %8.3f ms  %7.2f TFLOP/s" % (tot_ms, tot_fl / (tot_ms * 1e-3) / 1e12))
 
 
