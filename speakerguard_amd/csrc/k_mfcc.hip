@@ -221,6 +221,9 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ x, int T, i
 }
 
 // Forward of one frame up to the cepstra; leaves spectrum in L.spec, mel in L.mel, samples in L.samp.
+// MODE 0: full forward (writes the spectrum / mel cache when t.spec_cache is set); MODE 1: backward with a cache:
+// only the sample statistics are recomputed, spectrum and mel energies are read back (no FFT, no mel/DCT loops).
+template <int MODE>
 __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, FrameLds& L, const float (&raw)[7],
                                               int F, int b, int f, bool active, float scale, const sg_dither& dz,
                                               int lane, FrameState& st, float& cep_out) {
@@ -250,6 +253,19 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
     }
     st.energy = wave_sum(e);
     wave_sync();
+    const size_t gfi = (size_t)b * F + f;
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            const float2 c = t.spec_cache[gfi * 256 + k];
+            L.spec[SP(k)] = make_double2((double)c.x, (double)c.y);
+        }
+        if (lane < 32) L.mel[lane] = t.mel_cache[gfi * 32 + lane];
+        wave_sync();
+        cep_out = 0.f;
+        return;
+    }
     // pre-emphasis (replicate pad on the left), povey window, zero-padded into the FFT buffer
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -268,6 +284,7 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         const int k = lane + 64 * i;
         const double2 c = L.spec[SP(k)];
         L.power[k] = (float)(c.x * c.x + c.y * c.y);
+        if (t.spec_cache) t.spec_cache[gfi * 256 + k] = make_float2((float)c.x, (float)c.y);
     }
     wave_sync();
     // 30 triangular mel filters, two lanes per filter (each sums half of the filter's bins); the weight
@@ -285,6 +302,7 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         if (m < kMel && h == 0) {
             L.mel[m] = acc;
             L.lmel[m] = logf(fmaxf(acc, kEps));
+            if (t.mel_cache) t.mel_cache[gfi * 32 + m] = acc;
         }
     }
     wave_sync();
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
         load_frame(x, T, F, gf + stride, total, lane, nxt);
         FrameState st;
         float cep;
-        frame_forward(t, tb, L, raw, F, b, f, active, scale, dz, lane, st, cep);
+        frame_forward<0>(t, tb, L, raw, F, b, f, active, scale, dz, lane, st, cep);
         if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
@@ -351,7 +369,8 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
         const int fa = active ? f : 0;
         FrameState st;
         float cep;
-        frame_forward(t, tb, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
+        if (t.spec_cache) frame_forward<1>(t, tb, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
+        else frame_forward<0>(t, tb, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
         // ---- cepstra -> log-mel
         float dc = 0.f;
         if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];

@@ -205,6 +205,8 @@ int ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
     rc |= dev_alloc(ctx, w.allocs, &w.dfeats, (size_t)kL1BwdSplitK * b * cf * kFeatPad);
     rc |= dev_alloc(ctx, w.allocs, &w.dfeats_raw, b * cf * kCep);
     rc |= dev_alloc(ctx, w.allocs, &w.dframes, b * cf * kWin);
+    rc |= dev_alloc(ctx, w.allocs, &w.spec_cache, b * cf * 256);
+    rc |= dev_alloc(ctx, w.allocs, &w.mel_cache, b * cf * 32);
     rc |= dev_alloc(ctx, w.allocs, &w.stats, b * kStats);
     rc |= dev_alloc(ctx, w.allocs, &w.fc1_part, (size_t)kFc1SplitK * b * kEmb);
     rc |= dev_alloc(ctx, w.allocs, &w.demb, b * kEmb);
@@ -234,7 +236,10 @@ int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const
     Workspace& w = ctx->ws;
     if (flag == SG_FLAG_WAV) {
         if (!d.keep_scale) SG_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 0, s));
-        SG_HIP(launch_mfcc_fwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
+        MfccTables tab = ctx->tab;
+        tab.spec_cache = w.spec_cache;  // the backward of this pass starts from the stored spectrum
+        tab.mel_cache = w.mel_cache;
+        SG_HIP(launch_mfcc_fwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
         SG_HIP(launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else if (flag == SG_FLAG_RAW) {
         SG_HIP(launch_cmvn_fwd(x, kCep, w.feats, kFeatPad, d.B, d.F, s));
@@ -376,7 +381,16 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
     } else {
         SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, w.dfeats_raw, kCep,
                                d.B, d.F, s));
-        SG_HIP(launch_mfcc_bwd(ctx->tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
+        MfccTables tab = ctx->tab;
+        static const bool use_cache = [] {
+            const char* e = getenv("SG_MFCC_CACHE");  // 0 = recompute the forward in the backward kernel
+            return !e || atoi(e) != 0;
+        }();
+        if (use_cache) {
+            tab.spec_cache = w.spec_cache;
+            tab.mel_cache = w.mel_cache;
+        }
+        SG_HIP(launch_mfcc_bwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
         SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_out, x_update, lower, upper, step, grad_sign, s));
     }
     return SG_OK;

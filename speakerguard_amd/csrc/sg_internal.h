@@ -100,6 +100,10 @@ struct MfccTables {          // device pointers
     double2* twiddle;        // [256] exp(-2 pi i k / 512), fp64 (forward FFT runs in fp64)
     uint16_t* bitrev;        // [512]
     int ablate;              // timing experiments (SG_MFCC_ABLATE): 1 skip FFTs, 2 skip mel/DCT loops
+    // spectrum hand-over forward -> backward within one pass (null: the backward recomputes the forward):
+    // bins 0..255 of every frame's FFT as float2 (computed in fp64, rounded once) and the 30 mel energies
+    float2* spec_cache;      // [B*F][256]
+    float* mel_cache;        // [B*F][32]
 };
 
 struct XvModel {
@@ -137,6 +141,8 @@ struct Workspace {
     float* dfeats = nullptr;           // [kL1BwdSplitK][B][F][32] split-K slabs of the tdnn1 data gradient
     float* dfeats_raw = nullptr;       // [B][F][30]
     float* dframes = nullptr;          // [B][F][400]
+    float2* spec_cache = nullptr;      // [B][F][256] forward spectrum kept for the backward (39 MB at B = 64)
+    float* mel_cache = nullptr;        // [B][F][32]
     float* stats = nullptr;            // [B][kStats]
     float* fc1_part = nullptr;         // [kFc1SplitK][B][512]
     float* demb = nullptr;             // [B][512]
