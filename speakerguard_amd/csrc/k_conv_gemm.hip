@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 }
 
 // ------------------------------------------------------------------------------------------
-// Stream-K launch (64 x 128 tiles): `workers` persistent blocks, all co-resident (3 per CU), each
+// Stream-K launch (128 x 128 tiles, 8 waves): `workers` persistent blocks, all co-resident (2 per CU), each
 // owning an equal contiguous range of (tile, K-chunk) iterations, so every block does the same
 // number of MFMAs and the launch has no tail (the data-parallel launch of 1080 tiles on 768
 // slots idles ~16 % of the matrix pipes in its last round).  A tile whose chunks straddle two
@@ -595,12 +595,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 // else, so a waiter never waits on work that depends on it (spins are bounded regardless).  Hand-off = agent-scope release/acquire on one flag
 // per worker (cdna guide G16).  A flag holds the EPOCH of the launch that parked the slab (a process-wide
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
-template <int EPI, bool W8, bool QUAD>
-__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+template <int EPI, bool QUAD>
+__global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                    int iters_per_worker, float* slabs,
                                                                    unsigned* flags, unsigned epoch) {
-    constexpr int BM = W8 ? 128 : 64, BN = 128, WM = 2, WN = W8 ? 4 : 2;
-    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 1x2 (4 waves) or 2x1 (8 waves)
+    constexpr int BM = 128, BN = 128, WM = 2, WN = 4;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 fragments per wave
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int C = p.total_chunks;
     const long total = (long)tiles * C;
@@ -620,9 +620,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 3) void conv_gemm_streamk_
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1) {
-        if constexpr (W8 && QUAD) gemm_segment8q(p, smem, m0, n0, c0, c1, acc);
-        else if constexpr (W8) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
-        else gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, c0, c1, acc);
+        if constexpr (QUAD) gemm_segment8q(p, smem, m0, n0, c0, c1, acc);
+        else gemm_segment8(p, smem, m0, n0, c0, c1, acc);
     };
     auto frag = [&](int mi, int ni, int e) { return (((wid * MI + mi) * NI + ni) * 16 + e) * 64 + lane; };
 
@@ -719,16 +718,11 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
-constexpr int kStreamKWorkers4 = 768;  // 4-wave 64x128 blocks: 256 CUs x 3 (48 KB LDS, <= 168 VGPRs)
-constexpr int kStreamKWorkers8 = 512;  // 8-wave 128x128 blocks: 256 CUs x 2 (64 KB LDS, <= 128 VGPRs)
+constexpr int kStreamKWorkers = 512;  // 8-wave 128x128 blocks: 256 CUs x 2 (64 KB LDS, <= 128 VGPRs)
 
 // returns hipErrorNotSupported when the shape does not qualify (caller falls back to the tile launch)
 static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, unsigned* flags, hipStream_t s) {
-    static const int w8 = [] {
-        const char* e = getenv("SG_STREAMK_W8");  // tuning aid: 0 = 4-wave 64x128 blocks
-        return e ? atoi(e) : 1;
-    }();
-    const int bm = w8 ? 128 : 64, workers = w8 ? kStreamKWorkers8 : kStreamKWorkers4;
+    const int bm = 128, workers = kStreamKWorkers;
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
     const int tiles = mtiles * ntiles;
     const long total = (long)tiles * a.total_chunks;
@@ -746,12 +740,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
     dim3 grid(workers);
 #define SG_SK(EPI)                                                                                              \
-    if (w8 && a.Wq) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true, true>), grid, dim3(512), 0, s, a, ntiles, \
-                                       tiles, ipw, slabs, flags, epoch);                                               \
-    else if (w8) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true, false>), grid, dim3(512), 0, s, a, ntiles,   \
-                                    tiles, ipw, slabs, flags, epoch);                                                  \
-    else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false, false>), grid, dim3(256), 0, s, a, ntiles, tiles,   \
-                            ipw, slabs, flags, epoch);
+    if (a.Wq) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw, \
+                                 slabs, flags, epoch);                                                          \
+    else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw,   \
+                            slabs, flags, epoch);
     switch (epi) {
         case EPI_NONE: SG_SK(EPI_NONE) break;
         case EPI_BIAS_RELU: SG_SK(EPI_BIAS_RELU) break;
@@ -762,22 +754,9 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     return hipGetLastError();
 }
 
-// 128-wide tiles come in three heights.  Measured at B = 64 (tools/layer_bench.py, SG_TILE_ROWS
-// sweep, profiles/): 64 rows 97.5 TFLOP/s over the eight large contractions, 96 rows 85.4, 128 rows
-// 76.5 -- the 48 KB of LDS of the 64-row tile lets three blocks share a CU (3 waves per SIMD), which
-// hides the per-chunk staging/barrier bubble, and the finer tiles shorten the tail of the launch.
-// A "fewest rounds x rows" model preferred 96 rows and was wrong; 64 is the default.
-static int pick_height(int M, int ntiles) {
-    static const int forced = [] {
-        const char* e = getenv("SG_TILE_ROWS");  // tuning aid: force 64 / 96 / 128
-        return e ? atoi(e) : 0;
-    }();
-    if (forced == 64 || forced == 96 || forced == 128) return forced;
-    (void)M;
-    (void)ntiles;
-    return 64;
-}
-
+// One-block-per-tile launches use 64 x 128 tiles: 48 KB of LDS lets three blocks share a CU (3 waves per SIMD),
+// which hides the per-chunk staging/barrier bubble; 96- and 128-row 4-wave tiles measured 12 % and 22 % slower
+// (profiles/r01_tile_rows_sweep.txt) and were removed.
 __global__ void pack_k4_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ wq) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)K * N) return;
@@ -791,7 +770,11 @@ hipError_t launch_pack_k4(const float* w, int K, int N, float* wq, hipStream_t s
     return hipGetLastError();
 }
 
-int conv_gemm_tile_rows(int M, int N) { return pick_height(M, N / 128); }
+int conv_gemm_tile_rows(int M, int N) {
+    (void)M;
+    (void)N;
+    return 64;
+}
 
 hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int splits, hipStream_t s) {
     static const int ablate = [] {
@@ -824,10 +807,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
                 const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
                 if (e != hipErrorNotSupported) return e;
             }
-            const int h = splits == 1 ? pick_height(a.M, a.N / 128) : 128;
-            if (h == 96) return launch_tile<96, 128, 1, 4>(a, epi, splits, s);
-            if (h == 64) return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
-            return launch_tile<128, 128, 2, 2>(a, epi, splits, s);
+            return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
         }
         case 1:
             if (a.N % 32) return hipErrorInvalidValue;

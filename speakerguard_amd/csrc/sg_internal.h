@@ -205,7 +205,8 @@ struct ConvGemmArgs {
     unsigned* sk_flags; // stream-K: [768] hand-off flags
 };
 
-// tile: 0 = 128x128 (2x2 waves), 1 = 128x32 (4x1 waves), 2 = 64x128 (2x2 waves)
+// tile: 0 = auto (stream-K 128x128 8-wave blocks when the shape qualifies, else 64x128), 1 = 128x32 (4x1 waves),
+//       2 = 64x128 (2x2 waves), one block per tile
 hipError_t launch_conv_gemm(const ConvGemmArgs& a, int tile, int epi, int splits, hipStream_t s);
 int conv_gemm_tile_rows(int M, int N);
 // [K][N] row-major -> k4-major [K/4][N][4] on the device (K % 4 == 0)
