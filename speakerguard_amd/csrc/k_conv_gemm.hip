@@ -604,12 +604,14 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int C = p.total_chunks;
     const long total = (long)tiles * C;
-    // Worker id and tile order are chosen for the per-XCD L2s (4 MB each; block b runs on XCD b % 8):
-    // XCD x takes the CONTIGUOUS workers [x*G, (x+1)*G), and tiles are numbered n-tile-major, so an XCD
-    // works on one or two n-tiles only and its W panels (K x 128 floats, 1.8 MB for tdnn3) stay L2-resident
-    // while the A rows stream through.  With w = blockIdx.x and m-tile-major order every XCD touched every
-    // W panel at unrelated k positions (stream-K ranges drift by ipw - C chunks per worker): 42 % TCC hit
-    // rate, 1.1 GB of fabric reads per tdnn3 launch against 45 MB of operands.
+    // Worker id: block b runs on XCD b % 8; XCD x takes the CONTIGUOUS workers [x*G, (x+1)*G), so the tiles an
+    // XCD's L2 (4 MB) sees at any time are neighbours (shared A row panels with m-tile-major numbering, shared W
+    // panels with n-tile-major numbering) and a hand-off partner is in the same XCD.  With w = blockIdx.x every
+    // XCD touched every panel at unrelated k positions (stream-K ranges drift by ipw - C chunks per worker).
+    // Measured (sum over six big layers): w = blockIdx.x 124.0, contiguous + n-major 134.2, contiguous + m-major
+    // 135.4 TFLOP/s (tdnn4 101 -> 119); the two tile orders differ by < 1 %: the kernel is MFMA-bound, the PMC
+    // passes in profiles/r01_pmc_tdnn3.json show the fabric traffic either way is absorbed by the Infinity Cache.
+    // sk_xcd: 0 = blockIdx order, 1 = contiguous + n-tile-major, 2 = contiguous + m-tile-major (default).
     const int per_xcd = gridDim.x >> 3;
     const int w = p.sk_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
     const int mtiles = tiles / ntiles;
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
     const bool head_piece = last_c1 < C;                   // my range stops inside last_tile
     const bool tail_piece = first_c0 > 0;                  // my range starts inside first_tile
     auto tile_origin = [&](int tile, int& m0, int& n0) {
-        if (p.sk_xcd) {
+        if (p.sk_xcd == 1) {
             m0 = (tile % mtiles) * BM;
             n0 = (tile / mtiles) * BN;
         } else {
@@ -788,8 +790,8 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     ConvGemmArgs a = a_in;
     a.ablate = ablate;
     static const int sk_xcd = [] {
-        const char* e = getenv("SG_STREAMK_XCD");  // 0 = worker id = block id, m-tile-major tiles
-        return e ? atoi(e) : 1;
+        const char* e = getenv("SG_STREAMK_XCD");  // tuning aid, see the kernel
+        return e ? atoi(e) : 2;
     }();
     a.sk_xcd = sk_xcd;
     static const int use_quad = [] {
