@@ -19,7 +19,9 @@
 // 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages + one register stage; the
 // staging of chunk c+1 / c+2 is issued in the middle of chunk c's MFMA stream (one barrier/chunk).
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "sg_internal.h"
@@ -641,12 +643,24 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
         }
     };
 
+    // phase timestamps for tools/sk_trace.py (100 MHz wall clock; slot 15 = hardware id of the block's first wave)
+#define SG_STAMP(i) \
+    if (p.trace && threadIdx.x == 0) p.trace[(size_t)w * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+    if (p.trace && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.trace[(size_t)w * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+        for (int i = 1; i < 15; ++i) p.trace[(size_t)w * 16 + i] = 0;
+    }
+    SG_STAMP(0)
     // 1. the head piece of my last tile (chunks [0, last_c1)): park it for worker w+1
     if (head_piece && !(last_tile == first_tile && tail_piece)) {
         int m0, n0;
         tile_origin(last_tile, m0, n0);
         acc_zero(acc);
         segment(m0, n0, 0, last_c1);
+        SG_STAMP(1)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -660,6 +674,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        SG_STAMP(2)
     }
     // 2. whole tiles
     const int whole_begin = tail_piece ? first_tile + 1 : first_tile;
@@ -669,7 +684,9 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
         tile_origin(tile, m0, n0);
         acc_zero(acc);
         segment(m0, n0, 0, C);
+        SG_STAMP(3 + 2 * min(tile - whole_begin, 2))
         tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
+        SG_STAMP(4 + 2 * min(tile - whole_begin, 2))
     }
     // 3. the tail piece of my first tile (chunks [first_c0, C)): RESUME from the accumulators worker
     //    w-1 parked, so every output element sees exactly the fmaf chain of an unsplit tile -- the
@@ -686,6 +703,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        SG_STAMP(9)
         const float* slab = slabs + (size_t)(w - 1) * BM * BN;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -694,9 +712,13 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = slab[frag(mi, ni, e)];
         const int c1 = first_tile == last_tile ? last_c1 : C;  // (host guarantees == C, see launcher)
+        SG_STAMP(10)
         segment(m0, n0, first_c0, c1);
+        SG_STAMP(11)
         tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
+        SG_STAMP(12)
     }
+#undef SG_STAMP
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -740,7 +762,13 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     static std::atomic<unsigned> launch_counter{0};
     unsigned epoch = ++launch_counter;
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
+    static const char* trace_file = getenv("SG_SK_TRACE");  // tuning aid: dump per-worker phase timestamps
+    static unsigned long long* trace_dev = nullptr;
+    ConvGemmArgs at = a;
+    if (trace_file && !trace_dev) (void)hipMalloc(reinterpret_cast<void**>(&trace_dev), (size_t)workers * 16 * 8);
+    at.trace = trace_file ? trace_dev : nullptr;
     dim3 grid(workers);
+#define a at
 #define SG_SK(EPI)                                                                                              \
     if (a.Wq) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw, \
                                  slabs, flags, epoch);                                                          \
@@ -753,6 +781,19 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         default: return hipErrorInvalidValue;
     }
 #undef SG_SK
+#undef a
+    if (trace_file && trace_dev) {
+        std::vector<unsigned long long> h((size_t)workers * 16);
+        if (hipStreamSynchronize(s) == hipSuccess &&
+            hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(trace_file, "ab")) {
+                const int hdr[8] = {workers, at.M, at.N, at.total_chunks, ipw, tiles, epi, 0};
+                fwrite(hdr, sizeof(hdr), 1, f);
+                fwrite(h.data(), 8, h.size(), f);
+                fclose(f);
+            }
+        }
+    }
     return hipGetLastError();
 }
 

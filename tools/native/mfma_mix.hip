@@ -52,13 +52,13 @@ __global__ __launch_bounds__(256) void mix(float* out, int iters) {
 // TILE 0: 64x64 wave tile (4 reads / 16 MFMA); 1: 64x32 (3 reads / 8 MFMA).  GLDS: also stage with
 // 4 global_load_lds_dwordx4 per wave and one barrier per 32 MFMAs, like one K-chunk of the GEMM.
 template <int TILE, int GLDS, int BAR>
-__global__ __launch_bounds__(512) void mixq(float* out, const float* __restrict__ g, int iters) {
+__global__ __launch_bounds__(1024) void mixq(float* out, const float* __restrict__ g, int iters) {
     __shared__ float4 lds[2][2048];  // 2 stages x 32 KB
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) (&lds[0][0])[i] = make_float4(0.25f, -0.5f, 0.125f, 1.f);
     __syncthreads();
     f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const float* gp = g + (size_t)(blockIdx.x * 8 + wid) * 4096 + lane * 4;
+    const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & 7;
+    const float* gp = g + (size_t)((blockIdx.x * 8 + wid) & 4095) * 4096 + lane * 4;
     for (int i = 0; i < iters; ++i) {
         const float4* p = &lds[i & 1][0] + wid * 64 + lane;
         if (GLDS > 0) {
@@ -113,7 +113,7 @@ void runq(const char* name, float* d, const float* g, int blocks, int threads) {
         best = ms < best ? ms : best;
     }
     const double flop = (double)blocks * (threads / 64) * iters * (TILE == 0 ? 64 : 32) * (2.0 * 32 * 32 * 2);
-    printf("%-58s waves/SIMD %d: %7.3f ms  %6.1f TFLOP/s\n", name, blocks * (threads / 64) / 1024, best, flop / best * 1e-9);
+    printf("%-58s blocks %4d x %4d thr (waves/SIMD %d): %7.3f ms  %6.1f TFLOP/s\n", name, blocks, threads, blocks * (threads / 64) / 1024, best, flop / best * 1e-9);
 }
 
 template <int MODE, int NV>
@@ -145,8 +145,8 @@ int main() {
         run<4, 0>("W8 shape: 3 ds_read_b32 per 2 MFMA (64x32 wave tile)", d, blocks);
     }
     float* g; (void)hipMalloc(&g, (size_t)512 * 8 * 4096 * 4); (void)hipMemset(g, 0, (size_t)512 * 8 * 4096 * 4);
-    for (int threads : {256, 512}) {
-        const int blocks = 512;
+    for (int threads : {512, 1024}) {
+        const int blocks = threads == 512 ? 512 : 256;
         runq<0, 0, 1>("64x64 wave tile, barrier only", d, g, blocks, threads);
         runq<0, 8, 0>("64x64 wave tile, 8 glds, no barrier", d, g, blocks, threads);
         runq<0, 8, 1>("64x64 wave tile, 8 glds + barrier", d, g, blocks, threads);

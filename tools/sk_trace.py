@@ -1,0 +1,95 @@
+"""Reads the per-worker phase timestamps the stream-K kernel writes when SG_SK_TRACE=<file> is set
+(100 MHz wall clock, 16 slots per worker, see conv_gemm_streamk_kernel) and prints where the time goes.
+
+    SG_SK_TRACE=gpurun_out/sk.bin python tools/layer_bench.py --layers 5 --iters 2 --repeats 1
+    python tools/sk_trace.py gpurun_out/sk.bin
+"""
+import struct
+import sys
+from collections import Counter
+
+import numpy as np
+
+data = open(sys.argv[1], "rb").read()
+pos, recs = 0, []
+while pos < len(data):
+    hdr = struct.unpack("8i", data[pos:pos + 32]); pos += 32
+    n = hdr[0] * 16
+    t = np.frombuffer(data[pos:pos + 8 * n], dtype=np.uint64).reshape(hdr[0], 16).copy(); pos += 8 * n
+    recs.append((hdr, t))
+hdr, t = recs[-1]
+workers, M, N, C, ipw, tiles, epi, _ = hdr
+print("launch: workers %d  M %d N %d  chunks/tile %d  chunks/worker %d  tiles %d  epi %d" % (workers, M, N, C, ipw, tiles, epi))
+hw = t[:, 15]
+xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
+cu = ((hw >> np.uint64(8)) & np.uint64(0xF)).astype(np.int64)
+sh = ((hw >> np.uint64(12)) & np.uint64(0x1)).astype(np.int64)
+se = ((hw >> np.uint64(13)) & np.uint64(0x7)).astype(np.int64)
+place = xcc * 1000 + se * 100 + sh * 10 + cu
+cnt = Counter(place.tolist())
+print("distinct (xcc,se,sh,cu) places: %d; blocks per place histogram: %s" % (len(cnt), Counter(cnt.values())))
+by_place = {}
+for w in range(workers):
+    by_place.setdefault(int(place[w]), []).append(w)
+pairs = [v for v in by_place.values() if len(v) == 2]
+d = [abs(a - b) for a, b in pairs]
+print("worker-index distance of co-resident pairs: %s" % Counter(d).most_common(6))
+print("xcc of workers 0..15:", xcc[:16].tolist(), " workers 60..70:", xcc[60:70].tolist())
+ts = t[:, :13].astype(np.float64) * 0.01  # us
+# the 100 MHz counters of different XCDs are not aligned: normalise per XCD
+for x in range(8):
+    sel = xcc == x
+    if sel.any():
+        ts[sel] -= ts[sel, 0].min()
+def col(i):
+    v = ts[:, i].copy(); v[t[:, i] == 0] = np.nan; return v
+start = col(0)
+print("start skew inside an XCD: median %.1f p90 %.1f max %.1f us" % (np.nanmedian(start), np.nanpercentile(start, 90), np.nanmax(start)))
+end = np.nanmax(np.stack([col(i) for i in (2, 4, 6, 8, 12)]), axis=0)
+busy = end - start
+print("per-worker start->end: median %.1f p10 %.1f p90 %.1f max %.1f us;  last end inside its XCD: %.1f us" % (
+    np.nanmedian(busy), np.nanpercentile(busy, 10), np.nanpercentile(busy, 90), np.nanmax(busy), np.nanmax(end)))
+chunk_us = 128 * 128 * 32 * 2 * 2 / (157.3e12 / 256) * 1e6
+print("ideal chunk time at peak with 2 blocks per CU: %.2f us" % chunk_us)
+def rep(name, a, b, chunks=None):
+    dlt = col(b) - col(a)
+    ok = ~np.isnan(dlt)
+    if ok.sum() == 0:
+        return
+    msg = "%-28s n=%3d  median %7.2f us  p90 %7.2f" % (name, ok.sum(), np.nanmedian(dlt), np.nanpercentile(dlt[ok], 90))
+    if chunks is not None:
+        per = dlt[ok] / chunks[ok]
+        msg += "   per chunk %.2f us" % np.nanmedian(per)
+    print(msg)
+w = np.arange(workers)
+it_begin = w * ipw
+it_end = np.minimum(tiles * C, it_begin + ipw)
+first_c0 = it_begin % C
+last_c1 = (it_end - 1) % C + 1
+rep("head piece compute", 0, 1, last_c1.astype(float))
+rep("park slab + flag", 1, 2)
+rep("whole tile 0 compute", 2, 3, np.full(workers, C, float))
+rep("whole tile 0 epilogue", 3, 4)
+rep("whole tile 1 compute", 4, 5, np.full(workers, C, float))
+rep("whole tile 1 epilogue", 5, 6)
+rep("flag wait + acquire", 8, 9)
+rep("slab read", 9, 10)
+rep("tail piece compute", 10, 11, (C - first_c0).astype(float))
+rep("tail epilogue", 11, 12)
+print()
+print("busy time by XCD (median / max us):", ["%d: %.0f/%.0f" % (x, np.nanmedian(busy[xcc == x]), np.nanmax(busy[xcc == x])) for x in range(8) if (xcc == x).any()])
+occ = np.array([cnt[int(pl)] for pl in place])
+for k in sorted(set(occ.tolist())):
+    print("blocks on CUs hosting %d blocks: n=%d  busy median %.0f  max %.0f us" % (k, (occ == k).sum(), np.nanmedian(busy[occ == k]), np.nanmax(busy[occ == k])))
+order = np.argsort(busy)
+print("slowest 12 workers:", [(int(i), int(xcc[i]), int(place[i]) % 1000, int(occ[i]), round(float(busy[i]))) for i in order[-12:]])
+print("fastest 6 workers:", [(int(i), int(xcc[i]), int(place[i]) % 1000, int(occ[i]), round(float(busy[i]))) for i in order[:6]])
+hist, edges = np.histogram(busy[~np.isnan(busy)], bins=12)
+print("busy histogram:", list(zip([round(float(e)) for e in edges[:-1]], hist.tolist())))
+pa = np.array([[busy[a], busy[b]] for a, b in pairs if not (np.isnan(busy[a]) or np.isnan(busy[b]))])
+lo, hi = pa.min(1), pa.max(1)
+print("co-resident pairs: faster block median %.0f us, slower block median %.0f us; pairs with both < 430: %d, both > 430: %d, mixed: %d" % (
+    np.median(lo), np.median(hi), (hi < 430).sum(), (lo > 430).sum(), ((lo < 430) & (hi > 430)).sum()))
+first = np.array([min(a, b) for a, b in pairs])  # lower worker index of the pair
+fast_is_lower = np.mean([busy[min(a, b)] < busy[max(a, b)] for a, b in pairs])
+print("fraction of pairs where the lower worker index (first dispatched) is the faster one: %.2f" % fast_is_lower)
