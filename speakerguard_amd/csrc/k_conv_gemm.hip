@@ -150,7 +150,7 @@ __device__ __forceinline__ void gemm_segment(const ConvGemmArgs& p, float* smem,
         const int buf = (c - c_begin) & 1;
         __builtin_amdgcn_sched_barrier(0);
         // k order shared by every kernel in this file (so results do not depend on which one runs):
-        // MFMA step ks = 4 kg + s consumes k = 8 kg + 4 lhi + s -- see gemm_segment8q, whose 16-byte
+        // MFMA step ks = 4 kg + s consumes k = 8 kg + 4 lhi + s -- see gemm_segment_q, whose 16-byte
         // operand reads dictate it.  KROW(ks) is the k-row of lane half 0.
 #define KROW(ks) (8 * ((ks) >> 2) + ((ks) & 3))
         const float* a_s = As + buf * BK * BM + lhi * 4 * BM + a_rd;
@@ -303,7 +303,7 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
 }
 
 // ------------------------------------------------------------------------------------------
-// 8-wave 128 x 128 tile, quad-fed: every MFMA operand fetch is one ds_read_b128 that serves FOUR
+// Quad-fed tiles (8 or 16 waves): every MFMA operand fetch is one ds_read_b128 that serves FOUR
 // k-steps (12 LDS instructions per 32 MFMAs instead of 32), and staging is a plain 16-byte copy.
 //
 // Why: on gfx950 the f32 MFMA shares its issue/datapath with the VALU -- tools/native/mfma_mix.hip
@@ -316,22 +316,29 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
 // s = 0..3 are 4 consecutive floats of its row (activations stay row-major in LDS, no transpose) and
 // its W operands are 4 consecutive k of its column, contiguous because the weights are pre-packed
 // k4-major at load time (Wq[k/4][n][k%4]).
-// LDS image: A[128 rows][8 slots of 16 B], slot c of row r stored at c ^ ((r >> 1) & 7): conflict-free
+// LDS image: A[BM rows][8 slots of 16 B], slot c of row r stored at c ^ ((r >> 1) & 7): conflict-free
 // for the 16-lane groups ds_read_b128 is served in and for the 8-lane groups of ds_write_b128;
 // W[8 k4-groups][128 n][4].  Out-of-range tap rows are zero-filled by the buffer-load bounds check
 // instead of being zeroed in registers.
-__device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+// WMW = waves along M: 2 -> 8 waves, 128 x 128 tile, 64 KB of LDS (two blocks per CU); 4 -> 16 waves, 256 x 128
+// tile, 96 KB (one block owns the CU).  Every wave computes 64 x 32.
+template <int WMW>
+__device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
                                                int c_end, f32x16 (&acc)[2][1]) {
-    constexpr int BM = 128, BN = 128;
-    float* As = smem;                 // [2][BM][32]
-    float* Bs = smem + 2 * BK * BM;   // [2][8][BN][4]
+    constexpr int BM = 64 * WMW, BN = 128;
+    constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;   // floats per LDS stage
+    constexpr int ROLE_T = 128 * WMW;                     // threads per staging role
+    constexpr int LW = 8 / WMW;                           // W float4 per W-role thread and chunk (A role: 4)
+    constexpr int ST_STRIDE = 512 * WMW;                  // LDS floats between a thread's consecutive float4
+    float* As = smem;                   // [2][BM][32]
+    float* Bs = smem + 2 * A_STAGE;     // [2][8][BN][4]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const bool role_a = wid < 4;
-    const int ts = tid & 255;
+    const bool role_a = wid < 2 * WMW;
+    const int ts = role_a ? tid : tid - ROLE_T;  // index inside the role
 
     // Staging loads are raw buffer loads: address = descriptor base + per-lane byte offset (VGPR) + a
     // wave-uniform byte offset (SGPR).  The K position inside a tap goes into the SGPR, so a chunk's four
@@ -345,32 +352,35 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
                : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
     unsigned row_off[4];  // A role: byte offset of (row, tap 0, k = 4 c4); W role: byte offset in the chunk image
     int a_t[4];
-    int st_off;  // LDS float offset of this thread's first staged float4 (the others: + i * 1024)
+    int st_off;  // LDS float offset of this thread's first staged float4 in stage 0 (the others: + i * ST_STRIDE)
     if (role_a) {
         const int c4 = ts & 7;
-        // one integer division per thread and segment; the other three rows are 32 apart
+        // one integer division per thread and segment; the other three rows are 16 WMW apart
         int b = (m0 + (ts >> 3)) / p.Tc;
         int t = (m0 + (ts >> 3)) - b * p.Tc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = m0 + (ts >> 3) + 32 * i;
+            const int r = m0 + (ts >> 3) + 16 * WMW * i;
             row_off[i] = (unsigned)(((b * p.Ta + t) * p.lda + c4 * 4) * 4);
             a_t[i] = r < p.M ? t : -(1 << 28);
-            t += 32;
+            t += 16 * WMW;
             while (t >= p.Tc) {
                 t -= p.Tc;
                 ++b;
             }
         }
-        st_off = (ts >> 3) * 32 + ((c4 ^ ((ts >> 4) & 7)) << 2);  // row stride 32 floats; rows + 32 i keep the swizzle
+        st_off = (ts >> 3) * 32 + ((c4 ^ ((ts >> 4) & 7)) << 2);  // row stride 32 floats; rows + 16 WMW i keep the swizzle
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            row_off[i] = (unsigned)((((ts >> 7) + 2 * i) * p.ldw + n0 + (ts & 127)) * 16);
+            const int f = ts + i * ROLE_T;  // float4 index in the [8][128] chunk image (i < LW)
+            row_off[i] = i < LW ? (unsigned)(((f >> 7) * p.ldw + n0 + (f & 127)) * 16) : kOob;
             a_t[i] = 0;
         }
-        st_off = 2 * BK * BM + ts * 4;  // group (ts >> 7) + 2 i -> + i * 1024 floats
+        st_off = 2 * A_STAGE + ts * 4;
     }
+    float* st_ptr0 = smem + st_off;                                    // stage 0
+    float* st_ptr1 = st_ptr0 + (role_a ? A_STAGE : B_STAGE);           // stage 1
     // load stream state (chunks are requested in increasing order)
     int ld_j = c_begin / kchunks;
     int ld_kc = (c_begin - ld_j * kchunks) * BK;
@@ -386,13 +396,16 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
     set_tap(ld_j);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     i32x4 r0, r1, r2, r3;
+    r2 = r3 = i32x4{0, 0, 0, 0};
     auto load_chunk = [&]() {
         // W role: all taps are one contiguous k range -> everything in the SGPR offset
         const int soff = role_a ? ld_kc * 4 : (ld_j * p.Kc + ld_kc) * p.ldw * 4;
         r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[0], soff, 0);
         r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[1], soff, 0);
-        r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2], soff, 0);
-        r3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[3], soff, 0);
+        if (LW == 4 || role_a) {
+            r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2], soff, 0);
+            r3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[3], soff, 0);
+        }
         ld_kc += BK;
         if (ld_kc == p.Kc) {
             ld_kc = 0;
@@ -400,16 +413,17 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
             if (role_a) set_tap(ld_j);
         }
     };
-    auto store_chunk = [&](int buf) {
-        float* d = smem + st_off + buf * BK * BM;  // both operand stages are BK*BM = BK*BN floats
-        *reinterpret_cast<i32x4*>(d + 0 * 1024) = r0;
-        *reinterpret_cast<i32x4*>(d + 1 * 1024) = r1;
-        *reinterpret_cast<i32x4*>(d + 2 * 1024) = r2;
-        *reinterpret_cast<i32x4*>(d + 3 * 1024) = r3;
+    auto store_chunk = [&](float* d) {
+        *reinterpret_cast<i32x4*>(d + 0 * ST_STRIDE) = r0;
+        *reinterpret_cast<i32x4*>(d + 1 * ST_STRIDE) = r1;
+        if (LW == 4 || role_a) {
+            *reinterpret_cast<i32x4*>(d + 2 * ST_STRIDE) = r2;
+            *reinterpret_cast<i32x4*>(d + 3 * ST_STRIDE) = r3;
+        }
     };
     if (c_begin < c_end) {
         load_chunk();
-        store_chunk(0);
+        store_chunk(st_ptr0);
         if (c_begin + 1 < c_end) load_chunk();
     }
     __syncthreads();
@@ -423,23 +437,22 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
     const float* a_kg2 = a_base + (((2 * 2 + lhi) ^ sw) << 2);
     const float* a_kg3 = a_base + (((3 * 2 + lhi) ^ sw) << 2);
     const float* b_base = Bs + (lhi * BN + wn * 32 + l31) * 4;
-    float* st_base = smem + st_off;
     auto chunk = [&](int c, auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
-        constexpr int SOFF = BUF * BK * BM;        // this chunk's stage
-        constexpr int NOFF = (BUF ^ 1) * BK * BM;  // the stage the next chunk is written to
+        constexpr int AOFF = BUF * A_STAGE;  // this chunk's stages
+        constexpr int BOFF = BUF * B_STAGE;
         __builtin_amdgcn_sched_barrier(0);
-        float4 a0 = *reinterpret_cast<const float4*>(a_kg0 + SOFF);
-        float4 a1 = *reinterpret_cast<const float4*>(a_kg0 + SOFF + 32 * 32);
-        float4 b0 = *reinterpret_cast<const float4*>(b_base + SOFF);
+        float4 a0 = *reinterpret_cast<const float4*>(a_kg0 + AOFF);
+        float4 a1 = *reinterpret_cast<const float4*>(a_kg0 + AOFF + 32 * 32);
+        float4 b0 = *reinterpret_cast<const float4*>(b_base + BOFF);
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             float4 na0, na1, nb0;
             if (kg < 3) {
                 const float* an = kg == 0 ? a_kg1 : kg == 1 ? a_kg2 : a_kg3;
-                na0 = *reinterpret_cast<const float4*>(an + SOFF);
-                na1 = *reinterpret_cast<const float4*>(an + SOFF + 32 * 32);
-                nb0 = *reinterpret_cast<const float4*>(b_base + SOFF + (kg + 1) * 2 * BN * 4);
+                na0 = *reinterpret_cast<const float4*>(an + AOFF);
+                na1 = *reinterpret_cast<const float4*>(an + AOFF + 32 * 32);
+                nb0 = *reinterpret_cast<const float4*>(b_base + BOFF + (kg + 1) * 2 * BN * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
@@ -452,13 +465,7 @@ __device__ __forceinline__ void gemm_segment8q(const ConvGemmArgs& p, float* sme
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kg == 1) {
-                if (c + 1 < c_end && !(p.ablate & 2)) {
-                    float* d = st_base + NOFF;
-                    *reinterpret_cast<i32x4*>(d + 0 * 1024) = r0;
-                    *reinterpret_cast<i32x4*>(d + 1 * 1024) = r1;
-                    *reinterpret_cast<i32x4*>(d + 2 * 1024) = r2;
-                    *reinterpret_cast<i32x4*>(d + 3 * 1024) = r3;
-                }
+                if (c + 1 < c_end && !(p.ablate & 2)) store_chunk(BUF ? st_ptr0 : st_ptr1);  // the other stage
                 if (c + 2 < c_end && !(p.ablate & 1)) load_chunk();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -597,13 +604,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
 // else, so a waiter never waits on work that depends on it (spins are bounded regardless).  Hand-off = agent-scope release/acquire on one flag
 // per worker (cdna guide G16).  A flag holds the EPOCH of the launch that parked the slab (a process-wide
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
-template <int EPI, bool QUAD>
-__global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
-                                                                   int iters_per_worker, float* slabs,
-                                                                   unsigned* flags, unsigned epoch) {
-    constexpr int BM = 128, BN = 128, WM = 2, WN = 4;
+// KIND 0: 8 waves, b32-fed 128x128 (no packed weights); 1: 8 waves, quad-fed 128x128; 2: 16 waves, quad-fed 256x128.
+template <int EPI, int KIND>
+__global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+                                                                                      int iters_per_worker, float* slabs,
+                                                                                      unsigned* flags, unsigned epoch) {
+    constexpr int WM = KIND == 2 ? 4 : 2, WN = 4;
+    constexpr int BM = 64 * WM, BN = 128;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 fragments per wave
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BK * (BM + BN) floats
     const int C = p.total_chunks;
     const long total = (long)tiles * C;
     // Worker id: block b runs on XCD b % 8; XCD x takes the CONTIGUOUS workers [x*G, (x+1)*G), so the tiles an
@@ -624,8 +633,8 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1) {
-        if constexpr (QUAD) gemm_segment8q(p, smem, m0, n0, c0, c1, acc);
-        else gemm_segment8(p, smem, m0, n0, c0, c1, acc);
+        if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
+        else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc);
     };
     auto frag = [&](int mi, int ni, int e) { return (((wid * MI + mi) * NI + ni) * 16 + e) * 64 + lane; };
 
@@ -742,11 +751,36 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
-constexpr int kStreamKWorkers = 512;  // 8-wave 128x128 blocks: 256 CUs x 2 (64 KB LDS, <= 128 VGPRs)
+// Persistent workers = resident blocks: 512 8-wave blocks (64 KB LDS, two per CU) or 256 16-wave blocks (96 KB, one
+// per CU).  tools/sk_trace.py shows why the second exists: of two blocks sharing a CU the first-dispatched one runs
+// ~1.3x faster (the SIMD arbiter favours the older waves; s_setprio did not change it) and the other finishes the
+// kernel alone at ~60 % efficiency.  One block per CU removes the pair, and the 256-row tile stages 25 % fewer
+// bytes per MAC.
+constexpr int kStreamKWorkers8 = 512, kStreamKWorkers16 = 256;
+
+template <int EPI, int KIND>
+static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, int tiles, int ipw, float* slabs,
+                                unsigned* flags, unsigned epoch, hipStream_t s) {
+    constexpr int bm = KIND == 2 ? 256 : 128;
+    constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
+    static const bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_streamk_kernel<EPI, KIND>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, KIND>), dim3(workers), dim3(KIND == 2 ? 1024 : 512), lds, s, a, ntiles,
+                       tiles, ipw, slabs, flags, epoch);
+}
 
 // returns hipErrorNotSupported when the shape does not qualify (caller falls back to the tile launch)
 static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, unsigned* flags, hipStream_t s) {
-    const int bm = 128, workers = kStreamKWorkers;
+    static const int w16 = [] {
+        const char* e = getenv("SG_STREAMK_W16");  // 0 = two 8-wave 128x128 blocks per CU
+        return e ? atoi(e) : 1;
+    }();
+    const int kind = !a.Wq ? 0 : ((w16 && a.force != 3) ? 2 : 1);
+    const int bm = kind == 2 ? 256 : 128, workers = kind == 2 ? kStreamKWorkers16 : kStreamKWorkers8;
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
     const int tiles = mtiles * ntiles;
     const long total = (long)tiles * a.total_chunks;
@@ -769,11 +803,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     at.trace = trace_file ? trace_dev : nullptr;
     dim3 grid(workers);
 #define a at
-#define SG_SK(EPI)                                                                                              \
-    if (a.Wq) hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, true>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw, \
-                                 slabs, flags, epoch);                                                          \
-    else hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, false>), grid, dim3(512), 0, s, a, ntiles, tiles, ipw,   \
-                            slabs, flags, epoch);
+#define SG_SK(EPI)                                                                                          \
+    if (kind == 2) launch_streamk_kind<EPI, 2>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    else if (kind == 1) launch_streamk_kind<EPI, 1>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
+    else launch_streamk_kind<EPI, 0>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);
     switch (epi) {
         case EPI_NONE: SG_SK(EPI_NONE) break;
         case EPI_BIAS_RELU: SG_SK(EPI_BIAS_RELU) break;

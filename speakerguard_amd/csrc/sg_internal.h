@@ -200,7 +200,7 @@ struct ConvGemmArgs {
     long long split_stride;
     int sk_xcd;         // stream-K: XCD-contiguous workers + n-tile-major tile order (see kernel)
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
-    int force;          // 0 auto, 1 one block per tile, 2 stream-K with the b32-fed 8-wave kernel (parity tests)
+    int force;          // 0 auto, 1 one block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave (parity tests)
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags

@@ -1,7 +1,7 @@
 """The implicit-GEMM convolution kernels in isolation (C-ABI sg_conv1d_rows) against the numpy oracle.
 
-Every launch strategy (one block per tile, stream-K with the b32-fed 8-wave kernel, stream-K with the
-quad-fed kernel the TDNN layers use) must give BIT-IDENTICAL results -- that is what makes a batch shard
+Every launch strategy (one block per tile, stream-K with the b32-fed 8-wave kernel, stream-K with the 8-wave and
+the 16-wave quad-fed kernel -- the last is what the TDNN layers use) must give BIT-IDENTICAL results -- that is what makes a batch shard
 reproduce the unsharded batch exactly -- and all must agree with the float64 oracle to fp32 accumulation error.
 """
 import numpy as np
@@ -56,7 +56,7 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     B, Ta, Tc, Kc, n, taps, step, base = shape
     a, w = _case(7, B, Ta, Tc, Kc, n, taps)
     want = conv1d_rows(a, w, B, Ta, Tc, taps, step, base)
-    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2)]
+    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2, 3)]
     scale = np.abs(want).max()
     for k, o in enumerate(outs):
         assert np.isfinite(o).all(), "kernel %d left rows unwritten" % k
@@ -64,6 +64,7 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
         assert err < 2e-5, "kernel %d: rel err %.3e" % (k, err)  # fp32 accumulation over K <= 576
     assert np.array_equal(outs[0], outs[1]), "quad-fed stream-K differs from the tile launch"
     assert np.array_equal(outs[2], outs[1]), "b32-fed stream-K differs from the tile launch"
+    assert np.array_equal(outs[3], outs[1]), "8-wave quad-fed stream-K differs from the tile launch"
 
 
 def test_conv_rows_epilogues(ctx):

@@ -87,6 +87,9 @@ print("fastest 6 workers:", [(int(i), int(xcc[i]), int(place[i]) % 1000, int(occ
 hist, edges = np.histogram(busy[~np.isnan(busy)], bins=12)
 print("busy histogram:", list(zip([round(float(e)) for e in edges[:-1]], hist.tolist())))
 pa = np.array([[busy[a], busy[b]] for a, b in pairs if not (np.isnan(busy[a]) or np.isnan(busy[b]))])
+if pa.ndim != 2 or not len(pa):
+    print("no CU hosts two blocks: nothing to compare")
+    sys.exit(0)
 lo, hi = pa.min(1), pa.max(1)
 print("co-resident pairs: faster block median %.0f us, slower block median %.0f us; pairs with both < 430: %d, both > 430: %d, mixed: %d" % (
     np.median(lo), np.median(hi), (hi < 430).sum(), (lo > 430).sum(), ((lo < 430) & (hi > 430)).sum()))
