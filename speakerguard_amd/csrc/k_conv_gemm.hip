@@ -13,11 +13,16 @@
 //
 //   C[r][n] = epi( sum_j sum_c A[row(r) + j*tap_step][c] * W[j*Kc + c][n] )
 //
-// Tiling: 256 threads = 4 waves (64 lanes).  v_mfma_f32_32x32x2_f32, exact fp32, 64 cycles per
-// instruction per SIMD.  LDS: A chunk stored K-major [32][BM] (register-transposed 4x4 blocks,
-// ds_write_b128), W chunk [32][BN]; MFMA operands are conflict-free ds_read_b32 (lanes 0-31 read
-// 32 consecutive floats, lanes 32-63 the next k-row).  Two LDS stages + one register stage; the
-// staging of chunk c+1 / c+2 is issued in the middle of chunk c's MFMA stream (one barrier/chunk).
+// Kernels in this file (all share one k order, so every launch strategy gives bit-identical results):
+//   * gemm_segment<BM,BN,WM,WN> + conv_gemm_kernel: 4 waves, one block per output tile (64x128 or 128x32), operands
+//     fed by ds_read_b32 from a K-major LDS image.  Used for tdnn1 (short K), fc1, split-K launches, small batches
+//     and the AudioNet stack.
+//   * gemm_segment8: 8 waves, 128x128, role-split staging, b32-fed (stream-K fallback when no packed weights exist).
+//   * gemm_segment_q<WMW>: quad-fed 128x128 (8 waves) or 256x128 (16 waves, the default of the TDNN layers):
+//     ds_read_b128 operands, k4-packed weights, buffer-load staging with hardware zero fill.
+//   * conv_gemm_streamk_kernel: persistent blocks with equal (tile, K-chunk) ranges and a bit-exact hand-off of
+//     split tiles.
+// v_mfma_f32_32x32x2_f32 is exact fp32 (an fmaf chain), 64 cycles per instruction per SIMD.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
     // passes in profiles/r01_pmc_tdnn3.json show the fabric traffic either way is absorbed by the Infinity Cache.
     // sk_xcd: 0 = blockIdx order, 1 = contiguous + n-tile-major, 2 = contiguous + m-tile-major (default).
     const int per_xcd = gridDim.x >> 3;
-    const int w = p.sk_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const int w = (p.sk_xcd && (gridDim.x & 7) == 0) ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
     const int mtiles = tiles / ntiles;
     const long it_begin = (long)w * iters_per_worker;
     const long it_end = min(total, it_begin + iters_per_worker);
@@ -756,7 +761,6 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
 // ~1.3x faster (the SIMD arbiter favours the older waves; s_setprio did not change it) and the other finishes the
 // kernel alone at ~60 % efficiency.  One block per CU removes the pair, and the 256-row tile stages 25 % fewer
 // bytes per MAC.
-constexpr int kStreamKWorkers8 = 512, kStreamKWorkers16 = 256;
 
 template <int EPI, int KIND>
 static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, int tiles, int ipw, float* slabs,
@@ -780,7 +784,9 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 1;
     }();
     const int kind = !a.Wq ? 0 : ((w16 && a.force != 3) ? 2 : 1);
-    const int bm = kind == 2 ? 256 : 128, workers = kind == 2 ? kStreamKWorkers16 : kStreamKWorkers8;
+    // one worker per resident slot of this device (slabs / flags are sized for 256 CUs)
+    const int cus = a.num_cus > 0 && a.num_cus < 256 ? a.num_cus : 256;
+    const int bm = kind == 2 ? 256 : 128, workers = kind == 2 ? cus : 2 * cus;
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
     const int tiles = mtiles * ntiles;
     const long total = (long)tiles * a.total_chunks;

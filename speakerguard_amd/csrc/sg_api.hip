@@ -273,6 +273,7 @@ ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
     a.split_stride = 0;
     a.sk_slabs = ctx->sk_slabs;
     a.sk_flags = ctx->sk_flags;
+    a.num_cus = ctx->num_cus;
     return a;
 }
 
@@ -330,6 +331,7 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.split_stride = 0;
         a.sk_slabs = ctx->sk_slabs;
         a.sk_flags = ctx->sk_flags;
+        a.num_cus = ctx->num_cus;
         int splits = 1;
         if (l == 0) {  // 32 output columns: 148 tiles at B = 64 -- split K per tap to fill the chip
             splits = kL1BwdSplitK;
@@ -412,6 +414,9 @@ int sg_create(int device, sg_ctx** out) {
     sg_ctx* ctx = new (std::nothrow) sg_ctx();
     if (!ctx) return SG_ERR_HIP;
     ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cus = prop.multiProcessorCount;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return SG_ERR_HIP;
@@ -771,7 +776,7 @@ int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c
     a.M = B * Tc; a.N = N; a.Ta = Ta; a.Tc = Tc; a.Kc = Kc; a.lda = Kc; a.ldw = N; a.ldc = N;
     a.taps = taps; a.tap_step = tap_step; a.tap_base = tap_base;
     a.total_chunks = taps * (Kc / 32); a.chunks_per_split = a.total_chunks;
-    a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.force = kernel;
+    a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.num_cus = ctx->num_cus; a.force = kernel;
     if (e == hipSuccess) e = launch_conv_gemm(a, 0, epi, 1, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(wq);
@@ -799,7 +804,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
         a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
         a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];
         a.total_chunks = a.taps * (a.Kc / 32); a.chunks_per_split = a.total_chunks;
-        a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags;
+        a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.num_cus = ctx->num_cus;
         tile = l == 0 ? 1 : 0;
         epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;
         if (l == 0) {

@@ -160,6 +160,7 @@ struct Workspace {
 
 struct sg_ctx {
     int device = 0;
+    int num_cus = 256;               // compute units of the device: the stream-K launches are sized to it
     std::string err;
     sg::MfccTables tab{};
     bool tables_ready = false;
@@ -199,6 +200,7 @@ struct ConvGemmArgs {
     int total_chunks, chunks_per_split;
     long long split_stride;
     int sk_xcd;         // stream-K: XCD-contiguous workers + n-tile-major tile order (see kernel)
+    int num_cus;        // stream-K: persistent blocks = resident slots of THIS device (0: assume 256)
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
     int force;          // 0 auto, 1 one block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave (parity tests)
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
