@@ -76,6 +76,9 @@ def load():
         raise NativeError(
             "%s is missing: the HIP extension has not been built (run `make` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    # torch first: it ships its own libamdhip64; loaded afterwards it would be a SECOND HIP runtime beside the
+    # system one this library links to, and the two do not share devices, streams or allocations (sg_create fails)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sig = {
