@@ -221,12 +221,43 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ x, int T, i
 }
 
 // Forward of one frame up to the cepstra; leaves spectrum in L.spec, mel in L.mel, samples in L.samp.
+// Table entries a lane needs for EVERY frame, hoisted into registers once per kernel: the weights of the bins
+// its half of a mel filter sums (ascending bin order, zero-padded: adding power * 0 leaves the sum unchanged, so
+// the result is bit-identical to a loop over the exact range), and its column of the DCT matrix.  Per frame the
+// mel and DCT loops then issue one LDS read per term (the spectrum / log-mel value) instead of four / two, all
+// independent, instead of a dependent chain of table look-ups.
+constexpr int kMelLaneBins = 24;  // >= bins per half filter (21 for 30 filters, 20-7600 Hz, 512-point FFT; host-checked)
+struct LaneConst {
+    int mel_k0;                 // first bin of this lane's half filter
+    float mel_w[kMelLaneBins];  // its weights
+    float dct_col[kMel];        // dct[m][lane] * 1 (lane < kCep)
+};
+
+__device__ __forceinline__ void lane_const_init(const TabLds& tb, int lane, LaneConst& lc) {
+    const int m = lane >> 1, h = lane & 1;
+    int k0 = 0, cnt = 0;
+    if (m < kMel) {
+        const int lo = tb.mel_lo[m], hi = tb.mel_hi[m];
+        const int mid = lo + (hi - lo + 1) / 2;
+        k0 = h ? mid : lo;
+        cnt = (h ? hi : mid) - k0;
+    }
+    lc.mel_k0 = k0;
+#pragma unroll
+    for (int j = 0; j < kMelLaneBins; ++j) {
+        const int k = min(k0 + j, 255);
+        lc.mel_w[j] = j < cnt ? (tb.bin_m0[k] == m ? tb.bin_w0[k] : tb.bin_w1[k]) : 0.f;
+    }
+#pragma unroll
+    for (int mm = 0; mm < kMel; ++mm) lc.dct_col[mm] = lane < kCep ? tb.dct[mm * kCep + lane] : 0.f;
+}
+
 // MODE 0: full forward (writes the spectrum / mel cache when t.spec_cache is set); MODE 1: backward with a cache:
 // only the sample statistics are recomputed, spectrum and mel energies are read back (no FFT, no mel/DCT loops).
 template <int MODE>
-__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, FrameLds& L, const float (&raw)[7],
-                                              int F, int b, int f, bool active, float scale, const sg_dither& dz,
-                                              int lane, FrameState& st, float& cep_out) {
+__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, const LaneConst& lc, FrameLds& L,
+                                              const float (&raw)[7], int F, int b, int f, bool active, float scale,
+                                              const sg_dither& dz, int lane, FrameState& st, float& cep_out) {
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -292,12 +323,8 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
     if (!(t.ablate & 2)) {
         const int m = lane >> 1, h = lane & 1;
         float acc = 0.f;
-        if (m < kMel) {
-            const int lo = tb.mel_lo[m], hi = tb.mel_hi[m];
-            const int mid = lo + (hi - lo + 1) / 2;
-            for (int k = h ? mid : lo; k < (h ? hi : mid); ++k)
-                acc += L.power[k] * (tb.bin_m0[k] == m ? tb.bin_w0[k] : tb.bin_w1[k]);
-        }
+#pragma unroll
+        for (int j = 0; j < kMelLaneBins; ++j) acc += L.power[min(lc.mel_k0 + j, 255)] * lc.mel_w[j];
         acc += __shfl_xor(acc, 1, 64);
         if (m < kMel && h == 0) {
             L.mel[m] = acc;
@@ -309,8 +336,8 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
     cep_out = 0.f;
     if (lane < kCep && !(t.ablate & 2)) {
         float v = 0.f;
-#pragma unroll 6
-        for (int m = 0; m < kMel; ++m) v += L.lmel[m] * tb.dct[m * kCep + lane];
+#pragma unroll
+        for (int m = 0; m < kMel; ++m) v += L.lmel[m] * lc.dct_col[m];
         v *= tb.lifter[lane];
         if (lane == 0) v = logf(fmaxf(st.energy, kEps));
         cep_out = v;
@@ -326,6 +353,8 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLds& L = lds[wid];
+    LaneConst lc;
+    lane_const_init(tb, lane, lc);
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
     const int total = B * F, stride = gridDim.x * kWavesPerBlock;
     float raw[7], nxt[7];
@@ -338,7 +367,7 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
         load_frame(x, T, F, gf + stride, total, lane, nxt);
         FrameState st;
         float cep;
-        frame_forward<0>(t, tb, L, raw, F, b, f, active, scale, dz, lane, st, cep);
+        frame_forward<0>(t, tb, lc, L, raw, F, b, f, active, scale, dz, lane, st, cep);
         if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
@@ -346,6 +375,10 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
 
 // dfeats: (B,F,ld) gradient wrt the 30 cepstra; dframes: (B,F,400) gradient wrt the strided frames,
 // already multiplied by `scale` (the int16 rescale of check_input_range, model/utils.py:14).
+// CACHED: the forward kernel of the same pass left spectrum + mel energies in t.spec_cache / t.mel_cache (the attack
+// loop); otherwise the forward is recomputed here (standalone sg_xv_mfcc_backward).  Two instantiations so that the
+// cached one does not carry the forward's lane constants (it would drop to one wave per SIMD).
+template <bool CACHED>
 __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
                                                        const float* __restrict__ scale_p, sg_dither dz,
                                                        const float* __restrict__ dfeats, int ld,
@@ -356,6 +389,20 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLds& L = lds[wid];
+    LaneConst lc;
+    if (!CACHED) lane_const_init(tb, lane, lc);
+    // backward-only lane constants: row `lane` of the DCT matrix, and the mel membership of this lane's four bins
+    float dct_row[kCep];
+#pragma unroll
+    for (int c = 0; c < kCep; ++c) dct_row[c] = lane < kMel ? tb.dct[lane * kCep + c] : 0.f;
+    int bin_m0[4];
+    float bin_w0[4], bin_w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bin_m0[i] = tb.bin_m0[lane + 64 * i];
+        bin_w0[i] = tb.bin_w0[lane + 64 * i];
+        bin_w1[i] = tb.bin_w1[lane + 64 * i];
+    }
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
     const int total = B * F, stride = gridDim.x * kWavesPerBlock;
     float raw[7], nxt[7];
@@ -369,8 +416,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
         const int fa = active ? f : 0;
         FrameState st;
         float cep;
-        if (t.spec_cache) frame_forward<1>(t, tb, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
-        else frame_forward<0>(t, tb, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
+        frame_forward<CACHED ? 1 : 0>(t, tb, lc, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
         // ---- cepstra -> log-mel
         float dc = 0.f;
         if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];
@@ -381,8 +427,8 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             float dm = 0.f;
             if (lane < kMel) {
                 float dl = 0.f;
-#pragma unroll 6
-                for (int c = 0; c < kCep; ++c) dl += L.tmp[c] * tb.dct[lane * kCep + c];
+#pragma unroll
+                for (int c = 0; c < kCep; ++c) dl += L.tmp[c] * dct_row[c];
                 const float mel = L.mel[lane];
                 dm = mel > kEps ? dl / mel : 0.f;
             }
@@ -395,9 +441,9 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             const int k = lane + 64 * i;
             double2 g = make_double2(0.0, 0.0);
             if (k < 256) {
-                const int m0 = tb.bin_m0[k];
+                const int m0 = bin_m0[i & 3];
                 if (m0 >= 0) {
-                    const double dp = 2.0 * (double)(L.lmel[m0] * tb.bin_w0[k] + L.lmel[m0 + 1] * tb.bin_w1[k]);
+                    const double dp = 2.0 * (double)(L.lmel[m0] * bin_w0[i & 3] + L.lmel[m0 + 1] * bin_w1[i & 3]);
                     const double2 c = L.spec[SP(k)];
                     g = make_double2(c.x * dp, c.y * dp);
                 }
@@ -488,7 +534,8 @@ hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, in
     sg_dither d = dz ? *dz : sg_dither{0.f, 0, 0, nullptr};
     const int want = (B * F + kWavesPerBlock - 1) / kWavesPerBlock;
     dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
-    hipLaunchKernelGGL(mfcc_bwd_kernel, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
+    if (t.spec_cache) hipLaunchKernelGGL(mfcc_bwd_kernel<true>, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
+    else hipLaunchKernelGGL(mfcc_bwd_kernel<false>, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
     return hipGetLastError();
 }
 

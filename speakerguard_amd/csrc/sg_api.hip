@@ -106,6 +106,8 @@ int build_tables(sg_ctx* ctx) {
             }
         }
         if (lo[m] > hi[m]) lo[m] = hi[m] = 0;
+        // each of the two lanes of a filter keeps the weights of its half in registers (k_mfcc.hip: kMelLaneBins)
+        if ((hi[m] - lo[m] + 1) / 2 > 24) return fail(ctx, SG_ERR_STATE, "mel filter %d spans %d bins: more than the MFCC kernel holds", m, hi[m] - lo[m]);
     }
     for (int k = 0; k < 256; ++k) {
         int first = -1, cnt = 0;
