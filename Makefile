@@ -10,7 +10,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 
 all: $(LIB)
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h include/speakerguard_hip.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h $(CSRC)/fft512.h $(CSRC)/loss_device.h include/speakerguard_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

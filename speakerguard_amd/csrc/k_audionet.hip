@@ -6,69 +6,38 @@
 // Activations are channel-last (B, T, C) like everywhere else in the library.
 #include "loss_device.h"
 #include "sg_internal.h"
+#include "fft512.h"
 
 namespace sg {
 
-constexpr int kAnWavesPerBlock = 2;
+constexpr int kAnWavesPerBlock = 4;
+constexpr int kAnMaxBlocks = 512;   // 2 blocks (51 KB of LDS each) per CU x 256 CUs
+constexpr int kAnHalf = kAnFft / 2; // 512: a 1024-point REAL frame is one 512-point complex transform + a split step
+constexpr int kAnMelLaneBins = 44;  // >= bins per half filter (exactly 44 for 32 slaney filters over 513 bins; host-checked)
 
-__device__ __forceinline__ void an_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ float an_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
+// Log-mel front-end, one wave per frame, persistent over frames (same recipe as the MFCC kernels, k_mfcc.hip):
+//   * the 1024 real samples x[q] of a frame are packed as z[n] = x[2n] + i x[2n+1] and transformed by ONE 512-point
+//     complex FFT (fft512.h: in-register radix-8, padded conflict-free LDS buffer, fp64); the spectrum follows from
+//         X[k] = A_k Z[k] + B_k conj(Z[512-k]),   A_k = (1 - i W^k)/2,  B_k = (1 + i W^k)/2,  W = exp(-2 pi i/1024),
+//     for k = 0..512 -- half the butterflies and half the LDS of a 1024-point transform (the first version: radix-2,
+//     320 LDS accesses per lane per transform with twiddles and bit-reversal tables read from global memory);
+//   * the backward is the adjoint of exactly that: dZ[j] = conj(A_j) G[j] + B_{512-j} conj(G[512-j]) (+ the k = 512
+//     terms folded into j = 0), one inverse 512-point transform, d x[2n] = Re dz[n], d x[2n+1] = Im dz[n];
+//   * everything a lane needs for every frame is in registers for the whole kernel: its 16 window taps, the W^k of
+//     its 4 spectrum pairs, the weights of its half mel filter (ascending bins, zero-padded), its bins' filter
+//     membership; only the FFT twiddles live in LDS.
 struct AnFrameLds {
-    double2 spec[kAnFft];   // FFT work buffer (fp64: same dynamic-range argument as the MFCC front-end)
+    double2 spec[kAnHalf + kAnHalf / 8];  // element i at SP(i)
+    float power[kAnBins + 3];
     float mel[32];
     float dmel[34];
 };
-
-// radix-2 DIT (bit-reversed input, natural output), 1024 points, one wave, private LDS buffer
-__device__ __forceinline__ void an_fft_dit(double2* buf, const double2* __restrict__ tw, int lane) {
-#pragma unroll 1
-    for (int s = 0; s < 10; ++s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = lane + 64 * i;
-            const int pos = j & (half - 1);
-            const int i0 = ((j >> s) << (s + 1)) + pos;
-            const int i1 = i0 + half;
-            const double2 w = tw[pos << (9 - s)];
-            const double2 a = buf[i0], b = buf[i1];
-            const double tr = b.x * w.x - b.y * w.y;
-            const double ti = b.x * w.y + b.y * w.x;
-            buf[i0] = make_double2(a.x + tr, a.y + ti);
-            buf[i1] = make_double2(a.x - tr, a.y - ti);
-        }
-        an_wave_sync();
-    }
-}
-// inverse, DIF: natural input, element n of the (unnormalised) result lands at buf[bitrev(n)]
-__device__ __forceinline__ void an_ifft_dif(double2* buf, const double2* __restrict__ tw, int lane) {
-#pragma unroll 1
-    for (int s = 9; s >= 0; --s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = lane + 64 * i;
-            const int pos = j & (half - 1);
-            const int i0 = ((j >> s) << (s + 1)) + pos;
-            const int i1 = i0 + half;
-            const double2 w = tw[pos << (9 - s)];
-            const double2 a = buf[i0], b = buf[i1];
-            const double dx = a.x - b.x, dy = a.y - b.y;
-            buf[i0] = make_double2(a.x + b.x, a.y + b.y);
-            buf[i1] = make_double2(dx * w.x + dy * w.y, dy * w.x - dx * w.y);
-        }
-        an_wave_sync();
-    }
-}
 
 // pre-emphasised sample p of utterance row xr (length T), p in [0, T-2]: x[p+1] - 0.97 x[p]
 __device__ __forceinline__ float an_preemph(const float* __restrict__ xr, int p, float scale) {
@@ -76,93 +45,228 @@ __device__ __forceinline__ float an_preemph(const float* __restrict__ xr, int p,
 }
 __device__ __forceinline__ int an_reflect(int p, int L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
 
-// spectrum of frame f into L.spec, mel energies into L.mel
-__device__ __forceinline__ void an_frame_forward(const AnTables& t, AnFrameLds& L, const float* __restrict__ xr, int T,
-                                                 int f, float scale, int lane) {
+struct AnLaneConst {
+    float win[16];            // window tap of FFT input q = 2 (lane + 64 i) + {0, 1} (0 outside the 800-tap window)
+    double2 wk[4];            // W^j for this lane's pairs j = lane + 64 i
+    int mel_k0;
+    float mel_w[kAnMelLaneBins];
+};
+
+__device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLaneConst& lc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = 2 * (lane + 64 * i) + h - (kAnFft - kAnWin) / 2;
+            lc.win[2 * i + h] = (n >= 0 && n < kAnWin) ? t.window[n] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lc.wk[i] = t.twiddle[lane + 64 * i];
+    const int m = lane >> 1, h = lane & 1;
+    const int lo = t.mel_lo[m], hi = t.mel_hi[m];
+    const int mid = lo + (hi - lo + 1) / 2;
+    const int k0 = h ? mid : lo, cnt = (h ? hi : mid) - k0;
+    lc.mel_k0 = k0;
+#pragma unroll
+    for (int j = 0; j < kAnMelLaneBins; ++j) lc.mel_w[j] = j < cnt ? t.mel_w[m * kAnBins + min(k0 + j, kAnBins - 1)] : 0.f;
+}
+
+// raw samples of frame f: x[p], x[p + 1] for the 16 FFT inputs of this lane (loaded one frame ahead)
+struct AnRaw {
+    float a[16], b[16];
+};
+__device__ __forceinline__ void an_load_frame(const float* __restrict__ x, int T, int F, int gf, int total, int lane, AnRaw& r) {
+    const int g = gf < total ? gf : total - 1;
+    const int bb = g / F, f = g - bb * F;
+    const float* xr = x + (size_t)bb * T;
     const int Lp = T - 1;                         // length of the pre-emphasised signal
     const int base = f * kAnHop - kAnWin / 2;     // centre=True: frame f is centred on sample f*hop
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int q = lane + 64 * i;              // FFT input index; the 800-tap window sits at 112..911
-        const int n = q - (kAnFft - kAnWin) / 2;
-        double v = 0.0;
-        if (n >= 0 && n < kAnWin) v = (double)(an_preemph(xr, an_reflect(base + n, Lp), scale) * t.window[n]);
-        L.spec[t.bitrev[q]] = make_double2(v, 0.0);
+        const int q = 2 * (lane + 64 * (i >> 1)) + (i & 1);
+        int n = q - (kAnFft - kAnWin) / 2;
+        n = n < 0 ? 0 : (n >= kAnWin ? kAnWin - 1 : n);  // outside the window the tap is 0: any in-range sample will do
+        const int p = an_reflect(base + n, Lp);
+        r.a[i] = xr[p];
+        r.b[i] = xr[p + 1];
     }
-    an_wave_sync();
-    an_fft_dit(L.spec, t.twiddle, lane);
-    // 32 slaney-mel filters, two lanes per filter (each takes half of the filter's bin range)
-    {
-        const int m = lane >> 1, h = lane & 1;
-        const int lo = t.mel_lo[m], hi = t.mel_hi[m];
-        const int mid = lo + (hi - lo + 1) / 2;
-        float acc = 0.f;
-        for (int k = h ? mid : lo; k < (h ? hi : mid); ++k) {
-            const double2 c = L.spec[k];
-            acc += (float)(c.x * c.x + c.y * c.y) * t.mel_w[m * kAnBins + k];
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        if (h == 0) L.mel[m] = acc;
-    }
-    an_wave_sync();
 }
 
-__global__ __launch_bounds__(128) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int T, int F,
+__device__ __forceinline__ double2 an_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 an_conj(double2 a) { return make_double2(a.x, -a.y); }
+
+// X[k] and X[512 - k] from the pair (Z[k], Z[512 - k]); w = W^k.  A_k = (1 - i w)/2, B_k = (1 + i w)/2,
+// and W^(512-k) = -conj(W^k).
+__device__ __forceinline__ void an_split(double2 zk, double2 zr, double2 w, double2& xk, double2& xr) {
+    const double2 iw = make_double2(-w.y, w.x);                       // i w
+    const double2 ak = make_double2(0.5 * (1.0 - iw.x), -0.5 * iw.y);
+    const double2 bk = make_double2(0.5 * (1.0 + iw.x), 0.5 * iw.y);
+    const double2 t0 = an_cmul(ak, zk), t1 = an_cmul(bk, an_conj(zr));
+    xk = make_double2(t0.x + t1.x, t0.y + t1.y);
+    const double2 wr = make_double2(-w.x, w.y);                       // W^(512-k)
+    const double2 iwr = make_double2(-wr.y, wr.x);
+    const double2 ar = make_double2(0.5 * (1.0 - iwr.x), -0.5 * iwr.y);
+    const double2 br = make_double2(0.5 * (1.0 + iwr.x), 0.5 * iwr.y);
+    const double2 u0 = an_cmul(ar, zr), u1 = an_cmul(br, an_conj(zk));
+    xr = make_double2(u0.x + u1.x, u0.y + u1.y);
+}
+
+// packed spectrum Z of the frame into L.spec (element i at SP(i)), power of bins 0..512 into L.power, mel into L.mel
+__device__ __forceinline__ void an_frame_forward(const double2* tw512, AnFrameLds& L, const AnLaneConst& lc, const AnRaw& r,
+                                                 float scale, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v0 = (r.b[2 * i] - 0.97f * r.a[2 * i]) * scale * lc.win[2 * i];
+        const float v1 = (r.b[2 * i + 1] - 0.97f * r.a[2 * i + 1]) * scale * lc.win[2 * i + 1];
+        L.spec[SP(lane + 64 * i)] = make_double2((double)v0, (double)v1);
+    }
+    wave_sync();
+    fft512_r8(L.spec, tw512, lane, -1.0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;  // pairs (k, 512 - k), k = 0..255
+        const double2 zk = L.spec[SP(k)], zr = L.spec[SP((kAnHalf - k) & (kAnHalf - 1))];
+        double2 xk, xr;
+        an_split(zk, zr, lc.wk[i], xk, xr);
+        L.power[k] = (float)(xk.x * xk.x + xk.y * xk.y);
+        L.power[kAnHalf - k] = (float)(xr.x * xr.x + xr.y * xr.y);  // k = 0: X[512] = Re Z[0] - Im Z[0] (split with w = 1)
+    }
+    if (lane == 0) {  // the self-paired bin 256: w = W^256 = -i
+        const double2 z = L.spec[SP(256)];
+        double2 xk, xr;
+        an_split(z, z, make_double2(0.0, -1.0), xk, xr);
+        L.power[256] = (float)(xk.x * xk.x + xk.y * xk.y);
+    }
+    wave_sync();
+    // 32 slaney-mel filters, two lanes per filter (each takes half of the filter's bin range, ascending)
+    {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < kAnMelLaneBins; ++j) acc += L.power[min(lc.mel_k0 + j, kAnBins - 1)] * lc.mel_w[j];
+        acc += __shfl_xor(acc, 1, 64);
+        if ((lane & 1) == 0) L.mel[lane >> 1] = acc;
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) tw512[i] = t.twiddle[2 * i];  // W512^i = W1024^(2 i)
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p, float* __restrict__ feats) {
     __shared__ AnFrameLds lds[kAnWavesPerBlock];
+    __shared__ double2 tw512[256];
+    an_stage_tw(t, tw512);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int f = blockIdx.x * kAnWavesPerBlock + wid;
-    if (f >= F) return;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLds& L = lds[wid];
-    an_frame_forward(t, L, x + (size_t)b * T, T, f, scale, lane);
-    if (lane < kAnMel) feats[((size_t)b * F + f) * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
+    AnLaneConst lc;
+    an_lane_init(t, lane, lc);
+    const int total = B * F, stride = gridDim.x * kAnWavesPerBlock;
+    AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
+    for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
+        an_load_frame(x, T, F, gf, total, lane, cur);
+        an_frame_forward(tw512, L, lc, cur, scale, lane);
+        if (lane < kAnMel) feats[(size_t)gf * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
+        wave_sync();
+    }
 }
 
 // dfeats (B,F,32) -> dframes (B,F,800): gradient wrt the pre-emphasised, reflect-padded frame samples
-__global__ __launch_bounds__(128) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int T, int F,
+__global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p,
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
     __shared__ AnFrameLds lds[kAnWavesPerBlock];
+    __shared__ double2 tw512[256];
+    an_stage_tw(t, tw512);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int f = blockIdx.x * kAnWavesPerBlock + wid;
-    if (f >= F) return;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLds& L = lds[wid];
-    an_frame_forward(t, L, x + (size_t)b * T, T, f, scale, lane);
-    if (lane < 34) {
-        float dm = 0.f;
-        if (lane < kAnMel) {
-            const float mel = L.mel[lane];
-            // d/d mel of 10 log10(max(mel, 1e-16))
-            dm = mel > 1e-16f ? dfeats[((size_t)b * F + f) * kAnMel + lane] * (10.f / 2.302585092994046f) / mel : 0.f;
-        }
-        L.dmel[lane] = dm;
+    AnLaneConst lc;
+    an_lane_init(t, lane, lc);
+    // filter membership of every bin (which mel filter pair it feeds, with which weights): LDS, shared by the block
+    __shared__ int bin_m0[kAnBins + 3];
+    __shared__ float bin_w0[kAnBins + 3], bin_w1[kAnBins + 3];
+    for (int i = threadIdx.x; i < kAnBins; i += blockDim.x) {
+        bin_m0[i] = t.bin_m0[i];
+        bin_w0[i] = t.bin_w0[i];
+        bin_w1[i] = t.bin_w1[i];
     }
-    an_wave_sync();
+    __syncthreads();
+    const int total = B * F, stride = gridDim.x * kAnWavesPerBlock;
+    AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
+    for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
+        an_load_frame(x, T, F, gf, total, lane, cur);
+        an_frame_forward(tw512, L, lc, cur, scale, lane);
+        if (lane < 34) {
+            float dm = 0.f;
+            if (lane < kAnMel) {
+                const float mel = L.mel[lane];
+                // d/d mel of 10 log10(max(mel, 1e-16))
+                dm = mel > 1e-16f ? dfeats[(size_t)gf * kAnMel + lane] * (10.f / 2.302585092994046f) / mel : 0.f;
+            }
+            L.dmel[lane] = dm;
+        }
+        wave_sync();
+        // G[k] = 2 X[k] dP[k] for both bins of every pair, folded straight into dZ (in place: a lane owns its pair)
+        auto dpow = [&](int k) {
+            const int m0 = bin_m0[k];
+            return m0 >= 0 ? 2.0 * (double)(L.dmel[m0] * bin_w0[k] + L.dmel[m0 + 1] * bin_w1[k]) : 0.0;
+        };
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int k = lane + 64 * i;
-        double2 g = make_double2(0.0, 0.0);
-        if (k < kAnBins) {
-            const int m0 = t.bin_m0[k];
-            if (m0 >= 0) {
-                const double dp = 2.0 * (double)(L.dmel[m0] * t.bin_w0[k] + L.dmel[m0 + 1] * t.bin_w1[k]);
-                const double2 c = L.spec[k];
-                g = make_double2(c.x * dp, c.y * dp);
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            const int kr = (kAnHalf - k) & (kAnHalf - 1);
+            const double2 zk = L.spec[SP(k)], zr = L.spec[SP(kr)];
+            const double2 w = lc.wk[i];
+            double2 xk, xr;
+            an_split(zk, zr, w, xk, xr);
+            const double dpk = dpow(k), dpr = dpow(kAnHalf - k);
+            const double2 gk = make_double2(xk.x * dpk, xk.y * dpk), gr = make_double2(xr.x * dpr, xr.y * dpr);
+            const double2 iw = make_double2(-w.y, w.x);
+            const double2 ak = make_double2(0.5 * (1.0 - iw.x), -0.5 * iw.y), bk = make_double2(0.5 * (1.0 + iw.x), 0.5 * iw.y);
+            const double2 wr = make_double2(-w.x, w.y);
+            const double2 iwr = make_double2(-wr.y, wr.x);
+            const double2 ar = make_double2(0.5 * (1.0 - iwr.x), -0.5 * iwr.y), br = make_double2(0.5 * (1.0 + iwr.x), 0.5 * iwr.y);
+            // dZ[k] = conj(A_k) G[k] + B_{512-k} conj(G[512-k]);  dZ[512-k] = conj(A_{512-k}) G[512-k] + B_k conj(G[k])
+            const double2 d0 = an_cmul(an_conj(ak), gk), d1 = an_cmul(br, an_conj(gr));
+            const double2 e0 = an_cmul(an_conj(ar), gr), e1 = an_cmul(bk, an_conj(gk));
+            if (k == 0) {
+                // bins 0 and 512 both fold onto dZ[0]
+                L.spec[SP(0)] = make_double2(d0.x + d1.x + e0.x + e1.x, d0.y + d1.y + e0.y + e1.y);
+            } else {
+                L.spec[SP(k)] = make_double2(d0.x + d1.x, d0.y + d1.y);
+                L.spec[SP(kr)] = make_double2(e0.x + e1.x, e0.y + e1.y);
             }
         }
-        L.spec[k] = g;
-    }
-    an_wave_sync();
-    an_ifft_dif(L.spec, t.twiddle, lane);
-    float* out = dframes + ((size_t)b * F + f) * kAnWin;
+        wave_sync();
+        if (lane == 0) {  // self-paired bin 256
+            const double2 z = L.spec[SP(256)];
+            const double2 w = make_double2(0.0, -1.0);
+            double2 xk, xr;
+            an_split(z, z, w, xk, xr);
+            const double dp = dpow(256);
+            const double2 g = make_double2(xk.x * dp, xk.y * dp);
+            const double2 iw = make_double2(-w.y, w.x);
+            const double2 ak = make_double2(0.5 * (1.0 - iw.x), -0.5 * iw.y), bk = make_double2(0.5 * (1.0 + iw.x), 0.5 * iw.y);
+            const double2 d0 = an_cmul(an_conj(ak), g), d1 = an_cmul(bk, an_conj(g));
+            L.spec[SP(256)] = make_double2(d0.x + d1.x, d0.y + d1.y);
+        }
+        wave_sync();
+        fft512_r8(L.spec, tw512, lane, 1.0);
+        float* out = dframes + (size_t)gf * kAnWin;
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        const int n = lane + 64 * i;
-        if (n < kAnWin) out[n] = (float)L.spec[t.bitrev[n + (kAnFft - kAnWin) / 2]].x * t.window[n];
+        for (int i = 0; i < 8; ++i) {
+            const int n = lane + 64 * i;
+            const int q = 2 * n - (kAnFft - kAnWin) / 2;  // window index of FFT input 2n (even, since (1024-800)/2 = 112)
+            const double2 dz = L.spec[SP(n)];
+            if (q >= 0 && q < kAnWin)
+                *reinterpret_cast<float2*>(out + q) = make_float2((float)dz.x * lc.win[2 * i], (float)dz.y * lc.win[2 * i + 1]);
+        }
+        wave_sync();
     }
 }
 
@@ -330,14 +434,16 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
 
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 hipStream_t s) {
-    hipLaunchKernelGGL(an_logmel_fwd_kernel, dim3((F + kAnWavesPerBlock - 1) / kAnWavesPerBlock, B), dim3(128), 0, s, t, x,
-                       T, F, scale, feats);
+    const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
+    hipLaunchKernelGGL(an_logmel_fwd_kernel, dim3(want < kAnMaxBlocks ? want : kAnMaxBlocks), dim3(256), 0, s, t, x, B, T, F,
+                       scale, feats);
     return hipGetLastError();
 }
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
                                 const float* dfeats, float* dframes, hipStream_t s) {
-    hipLaunchKernelGGL(an_logmel_bwd_kernel, dim3((F + kAnWavesPerBlock - 1) / kAnWavesPerBlock, B), dim3(128), 0, s, t, x,
-                       T, F, scale, dfeats, dframes);
+    const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
+    hipLaunchKernelGGL(an_logmel_bwd_kernel, dim3(want < kAnMaxBlocks ? want : kAnMaxBlocks), dim3(256), 0, s, t, x, B, T, F,
+                       scale, dfeats, dframes);
     return hipGetLastError();
 }
 hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
