@@ -21,4 +21,10 @@ Parity status (see DESIGN.md "Oracle pinning"):
   algorithm as torchaudio.compliance.kaldi implements it.
 * AudioNet front-end and CNN (``oracle.audionet``): PARITY UNPINNED (librosa==0.8.0 and the
   old torch.stft API are not runnable here; reference model/_audionet/Preprocessor.py:57,100).
+* dilated conv contraction (``oracle.conv_rows``): PINNED against torch.nn.functional.conv1d and its autograd.
+* int16 PCM rounding, perturbation metrics, EER threshold (``oracle.post``) and FAKEBOB.estimate_threshold
+  (``oracle.attacks``): PINNED by fixtures the reference's own functions produced (tests/golden/make_golden.py).
+* FeCo (``oracle.feco``): the k-means ids restate THIS repository's determinism contract (the reference's clustering
+  is a randomly initialised third-party k-means) and the means-and-fallback step restates
+  defense/feature_level.py:204-216 -- PARITY UNPINNED.
 """
