@@ -113,6 +113,8 @@ __device__ __forceinline__ void an_split(double2 zk, double2 zr, double2 w, doub
 }
 
 // packed spectrum Z of the frame into L.spec (element i at SP(i)), power of bins 0..512 into L.power, mel into L.mel
+// WITH_MEL = false: only the packed spectrum (the cached backward takes the mel energies from the forward pass)
+template <bool WITH_MEL>
 __device__ __forceinline__ void an_frame_forward(const double2* tw512, AnFrameLds& L, const AnLaneConst& lc, const AnRaw& r,
                                                  float scale, int lane) {
 #pragma unroll
@@ -123,6 +125,7 @@ __device__ __forceinline__ void an_frame_forward(const double2* tw512, AnFrameLd
     }
     wave_sync();
     fft512_r8(L.spec, tw512, lane, -1.0);
+    if (!WITH_MEL) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;  // pairs (k, 512 - k), k = 0..255
@@ -169,13 +172,20 @@ __global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const
     AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
     for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
         an_load_frame(x, T, F, gf, total, lane, cur);
-        an_frame_forward(tw512, L, lc, cur, scale, lane);
-        if (lane < kAnMel) feats[(size_t)gf * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
+        an_frame_forward<true>(tw512, L, lc, cur, scale, lane);
+        if (lane < kAnMel) {
+            feats[(size_t)gf * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
+            if (t.mel_cache) t.mel_cache[(size_t)gf * kAnMel + lane] = L.mel[lane];
+        }
         wave_sync();
     }
 }
 
 // dfeats (B,F,32) -> dframes (B,F,800): gradient wrt the pre-emphasised, reflect-padded frame samples
+// CACHED: the forward kernel of the same pass left the mel energies in t.mel_cache (the attack loop); otherwise they
+// are recomputed (standalone sg_an_logmel_backward).  Two instantiations: the cached one does not carry the 44
+// mel-weight registers.
+template <bool CACHED>
 __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p,
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
@@ -200,11 +210,11 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
     AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
     for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
         an_load_frame(x, T, F, gf, total, lane, cur);
-        an_frame_forward(tw512, L, lc, cur, scale, lane);
+        an_frame_forward<!CACHED>(tw512, L, lc, cur, scale, lane);
         if (lane < 34) {
             float dm = 0.f;
             if (lane < kAnMel) {
-                const float mel = L.mel[lane];
+                const float mel = CACHED ? t.mel_cache[(size_t)gf * kAnMel + lane] : L.mel[lane];
                 // d/d mel of 10 log10(max(mel, 1e-16))
                 dm = mel > 1e-16f ? dfeats[(size_t)gf * kAnMel + lane] * (10.f / 2.302585092994046f) / mel : 0.f;
             }
@@ -280,7 +290,6 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
                                                                 const float* __restrict__ upper, float step, int grad_sign) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    if (t >= T) return;
     const float scale = scale_p ? *scale_p : 1.f;
     const float* df = dframes + (size_t)b * F * kAnWin;
     const int Lp = T - 1;
@@ -301,9 +310,21 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
         if (s <= Lp - 2) g += at_pos(2 * (Lp - 1) - s);  // right reflection p = 2(L-1) - s
         return g;
     };
+    // every d pre value is gathered once per block (up to 5 frame reads) and shared through LDS: d x[t] needs
+    // d pre[t-1] and d pre[t] -- the first version gathered both per thread and read the 491 MB of per-frame
+    // gradients of a batch-512 step twice
+    __shared__ float dp[257];  // dp[i] = d pre[t0 - 1 + i]
+    const int t0 = blockIdx.x * 256;
+    {
+        const int sidx = t0 + (int)threadIdx.x;  // d pre[s], stored at dp[threadIdx.x + 1]
+        dp[threadIdx.x + 1] = sidx <= Lp - 1 ? dpre(sidx) : 0.f;
+        if (threadIdx.x == 0) dp[0] = t0 >= 1 ? dpre(t0 - 1) : 0.f;
+    }
+    __syncthreads();
+    if (t >= T) return;
     float g = 0.f;
-    if (t >= 1) g += dpre(t - 1);
-    if (t <= Lp - 1) g -= 0.97f * dpre(t);
+    if (t >= 1) g += dp[threadIdx.x];
+    if (t <= Lp - 1) g -= 0.97f * dp[threadIdx.x + 1];
     g *= scale;
     const size_t o = (size_t)b * T + t;
     if (grad_out) grad_out[o] = g;
@@ -442,8 +463,9 @@ hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T,
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
                                 const float* dfeats, float* dframes, hipStream_t s) {
     const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
-    hipLaunchKernelGGL(an_logmel_bwd_kernel, dim3(want < kAnMaxBlocks ? want : kAnMaxBlocks), dim3(256), 0, s, t, x, B, T, F,
-                       scale, dfeats, dframes);
+    const dim3 grid(want < kAnMaxBlocks ? want : kAnMaxBlocks);
+    if (t.mel_cache) hipLaunchKernelGGL(an_logmel_bwd_kernel<true>, grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes);
+    else hipLaunchKernelGGL(an_logmel_bwd_kernel<false>, grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes);
     return hipGetLastError();
 }
 hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,

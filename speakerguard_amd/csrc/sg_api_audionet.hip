@@ -160,6 +160,7 @@ int an_ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
     rc |= an_alloc(ctx, w.allocs, &w.dpre, b * cf * kAnMel);
     rc |= an_alloc(ctx, w.allocs, &w.dfeats, b * cf * kAnMel);
     rc |= an_alloc(ctx, w.allocs, &w.dframes, b * cf * kAnWin);
+    rc |= an_alloc(ctx, w.allocs, &w.mel_cache, b * cf * kAnMel);
     for (int l = 0; l < kAnConv; ++l) {
         const size_t n = b * (size_t)(Tout[l] > 0 ? Tout[l] : 1) * kAnCout[l];
         rc |= an_alloc(ctx, w.allocs, &w.act[l], n);
@@ -219,7 +220,9 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
     const float* feats = x;
     if (flag == 0) {
         if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
-        AN_HIP(launch_an_logmel_fwd(ctx->an_tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
+        AnTables tab = ctx->an_tab;
+        tab.mel_cache = w.mel_cache;  // the backward of this pass starts from the stored mel energies
+        AN_HIP(launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
         feats = w.feats;
     }
     AN_HIP(launch_an_prefilter(feats, w.pre, d.B, d.F, m.w25, m.pre_bias, 0, s));
@@ -281,7 +284,9 @@ int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, floa
     float* dfeats = flag == 1 ? grad_out : w.dfeats;
     AN_HIP(launch_an_prefilter(w.dpre, dfeats, d.B, d.F, m.w25, 0.f, 1, s));
     if (flag == 0) {
-        AN_HIP(launch_an_logmel_bwd(ctx->an_tab, x, d.B, d.T, d.F, w.scale, w.dfeats, w.dframes, s));
+        AnTables tab = ctx->an_tab;
+        tab.mel_cache = w.mel_cache;
+        AN_HIP(launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, w.dfeats, w.dframes, s));
         AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step,
                                         grad_sign, s));
     }

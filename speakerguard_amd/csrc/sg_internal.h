@@ -57,6 +57,7 @@ struct AnTables {            // device pointers
     float* bin_w1;           // [513]
     double2* twiddle;        // [512] exp(-2 pi i k / 1024)
     uint16_t* bitrev;        // [1024]
+    float* mel_cache;        // [B*F][32] forward -> backward hand-over within one pass (null: the backward recomputes)
 };
 
 struct AnModel {
@@ -84,6 +85,7 @@ struct AnWorkspace {
     float* dpre = nullptr;     // (B, F, 32)
     float* dfeats = nullptr;   // (B, F, 32)
     float* dframes = nullptr;  // (B, F, 800)
+    float* mel_cache = nullptr;  // (B, F, 32) mel energies of the forward pass, kept for the backward of the same pass
     std::vector<void*> allocs;
 };
 
