@@ -767,12 +767,17 @@ static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, 
                                 unsigned* flags, unsigned epoch, hipStream_t s) {
     constexpr int bm = KIND == 2 ? 256 : 128;
     constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
-    static const bool once = [] {
+    // per device: remember for which devices the > 64 KB dynamic-LDS opt-in has been made (a process may hold one
+    // sg_ctx per GPU)
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_streamk_kernel<EPI, KIND>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return true;
-    }();
-    (void)once;
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, KIND>), dim3(workers), dim3(KIND == 2 ? 1024 : 512), lds, s, a, ntiles,
                        tiles, ipw, slabs, flags, epoch);
 }
