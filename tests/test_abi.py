@@ -54,3 +54,18 @@ def test_model_refuses_cpu_device():
     from speakerguard_amd.model.xv_plda import xv_plda
     with pytest.raises(_native.NativeError):
         xv_plda.from_weights(synth.make_xv_weights(), device="cpu")
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/speakerguard_hip.h must compile as C99 on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "speakerguard_hip.h"\nint use(void) { return sg_version(); }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                        "-c", str(src), "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
