@@ -34,7 +34,7 @@ EPS, STEP = 0.002, 0.0004
 FLOP_PER_UTT_STEP = 4.70e9
 
 
-def cpu_baseline(weights, budget_utts=16, steps=3):
+def cpu_baseline(weights, budget_utts=16, steps=3, gpu_model=None):
     """Reference-equivalent CPU path = the oracle in its structure-faithful form (per-utterance
     MFCC/TDNN loops, Python CMVN loop, autograd with parameters requiring grad), timed on this
     host's cores on a bounded sample of the same workload."""
@@ -47,7 +47,7 @@ def cpu_baseline(weights, budget_utts=16, steps=3):
     y = torch.arange(budget_utts) % 10
     atk = oatk.PGD(model, task="CSI", epsilon=EPS, step_size=STEP, max_iter=steps, batch_size=budget_utts)
     t0 = time.perf_counter()
-    atk.attack(x, y)
+    oadv, osucc = atk.attack(x, y)
     dt = time.perf_counter() - t0
     utt_steps = budget_utts * steps  # (+ one forward-only pass, charged like on the GPU side)
     # second row SURVEY.md section 8(d) asks for: the same oracle vectorised (batched, closed-form CMVN, parameters
@@ -57,7 +57,23 @@ def cpu_baseline(weights, budget_utts=16, steps=3):
     t1 = time.perf_counter()
     vatk.attack(x, y)
     dtv = time.perf_counter() - t1
+    parity = None
+    if gpu_model is not None:
+        # the checker role of the oracle: the same PGD-%d on the same utterances through the HIP path
+        from speakerguard_amd.attack.PGD import PGD
+        dev = gpu_model.device
+        adv, succ = PGD(gpu_model, task="CSI", epsilon=EPS, step_size=STEP, max_iter=steps, batch_size=budget_utts,
+                        verbose=0).attack(x.to(dev), y.to(dev))
+        diff = (adv.cpu() - oadv).abs()
+        with torch.no_grad():
+            odec = model.make_decision(oadv)[0]
+        parity = {"utterances": budget_utts, "pgd_steps": steps,
+                  "success_flags_equal": [bool(a) for a in succ] == [bool(a) for a in osucc],
+                  "decisions_on_adversarial_audio_equal": gpu_model.make_decision(adv)[0].cpu().tolist() == odec.tolist(),
+                  "perturbation_samples_differing": float((diff > 1e-7).float().mean()),
+                  "perturbation_max_abs_diff": float(diff.max())}
     return {
+        "parity_vs_oracle": parity,
         "vectorised_value": utt_steps / dtv / B_PER_GPU,
         "vectorised_sample": "same sample, batched oracle with frozen parameters: %.1f s" % dtv,
         "value": utt_steps / dt / B_PER_GPU,
@@ -166,7 +182,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(weights)
+        line["cpu_baseline"] = cpu_baseline(weights, gpu_model=model)
         line["gpu_vs_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(line))
