@@ -34,6 +34,7 @@
 namespace sg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 
@@ -399,7 +400,6 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
         }
     };
     set_tap(ld_j);
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
     i32x4 r0, r1, r2, r3;
     r2 = r3 = i32x4{0, 0, 0, 0};
     auto load_chunk = [&]() {
@@ -477,6 +477,163 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
             if (kg < 3) { a0 = na0; a1 = na1; b0 = nb0; }
         }
         if (!(p.ablate & 4)) __syncthreads();
+    };
+    int c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < c_end) chunk(c, std::integral_constant<int, 0>{});
+}
+
+// 4-wave 64 x 128 quad-fed tile for the one-block-per-tile launches (small batches, tdnn1 forward, the AudioNet
+// stack): the same operand scheme and k order as gemm_segment_q, 48 KB of LDS so three blocks share a CU.
+// Staging roles: waves 0-1 copy the A chunk (64 rows x 8 float4: 4 per thread), waves 2-3 the W chunk (8 k4-groups
+// x 128 columns: 8 per thread).
+__device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+                                                int c_end, f32x16 (&acc)[2][1]) {
+    constexpr int BM = 64, BN = 128;
+    constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;
+    constexpr int ST_STRIDE = 512;  // LDS floats between a thread's consecutive float4 (16 A rows / one W k4-group)
+    float* As = smem;                   // [2][BM][32]
+    float* Bs = smem + 2 * A_STAGE;     // [2][8][BN][4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const bool role_a = wid < 2;
+    const int ts = role_a ? tid : tid - 128;
+    constexpr unsigned kOob = 0x80000000u;
+    const int kchunks = p.Kc / BK;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        role_a ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000)
+               : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
+    unsigned row_off[8];
+    int a_t[4];
+    int st_off;
+    if (role_a) {
+        const int c4 = ts & 7;
+        int b = (m0 + (ts >> 3)) / p.Tc;
+        int t = (m0 + (ts >> 3)) - b * p.Tc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + (ts >> 3) + 16 * i;
+            row_off[i] = (unsigned)(((b * p.Ta + t) * p.lda + c4 * 4) * 4);
+            a_t[i] = r < p.M ? t : -(1 << 28);
+            t += 16;
+            while (t >= p.Tc) {
+                t -= p.Tc;
+                ++b;
+            }
+        }
+#pragma unroll
+        for (int i = 4; i < 8; ++i) row_off[i] = kOob;
+        st_off = (ts >> 3) * 32 + ((c4 ^ ((ts >> 4) & 7)) << 2);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row_off[i] = (unsigned)((i * p.ldw + n0 + ts) * 16);  // k4-group i, column ts
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_t[i] = 0;
+        st_off = 2 * A_STAGE + ts * 4;
+    }
+    float* st_ptr0 = smem + st_off;
+    float* st_ptr1 = st_ptr0 + (role_a ? A_STAGE : B_STAGE);
+    int ld_j = c_begin / kchunks;
+    int ld_kc = (c_begin - ld_j * kchunks) * BK;
+    // both roles run the same eight loads: the A role's slots 4..7 carry an out-of-range offset (the bounds check
+    // returns zeros without touching memory) -- role-dependent control flow around the staging registers made
+    // hipcc keep them in scratch
+    unsigned voff[8];
+#pragma unroll
+    for (int i = 4; i < 8; ++i) voff[i] = row_off[i];
+    auto set_tap = [&](int j) {
+        const int off = p.tap_base + j * p.tap_step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool okv = (unsigned)(a_t[i] + off) < (unsigned)p.Ta;
+            voff[i] = !role_a ? row_off[i] : okv ? row_off[i] + (unsigned)(off * p.lda * 4) : kOob;
+        }
+    };
+    set_tap(ld_j);
+    i32x4 r0, r1, r2, r3, r4, r5, r6, r7;
+    auto load_chunk = [&]() {
+        const int soff = role_a ? ld_kc * 4 : (ld_j * p.Kc + ld_kc) * p.ldw * 4;
+        r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[0], soff, 0);
+        r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[1], soff, 0);
+        r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2], soff, 0);
+        r3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[3], soff, 0);
+        r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[4], soff, 0);
+        r5 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[5], soff, 0);
+        r6 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[6], soff, 0);
+        r7 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[7], soff, 0);
+        ld_kc += BK;
+        if (ld_kc == p.Kc) {
+            ld_kc = 0;
+            ++ld_j;
+            if (role_a) set_tap(ld_j);
+        }
+    };
+    auto store_chunk = [&](float* d) {
+        *reinterpret_cast<i32x4*>(d + 0 * ST_STRIDE) = r0;
+        *reinterpret_cast<i32x4*>(d + 1 * ST_STRIDE) = r1;
+        *reinterpret_cast<i32x4*>(d + 2 * ST_STRIDE) = r2;
+        *reinterpret_cast<i32x4*>(d + 3 * ST_STRIDE) = r3;
+        if (!role_a) {
+            *reinterpret_cast<i32x4*>(d + 4 * ST_STRIDE) = r4;
+            *reinterpret_cast<i32x4*>(d + 5 * ST_STRIDE) = r5;
+            *reinterpret_cast<i32x4*>(d + 6 * ST_STRIDE) = r6;
+            *reinterpret_cast<i32x4*>(d + 7 * ST_STRIDE) = r7;
+        }
+    };
+    if (c_begin < c_end) {
+        load_chunk();
+        store_chunk(st_ptr0);
+        if (c_begin + 1 < c_end) load_chunk();
+    }
+    __syncthreads();
+    const int sw = (l31 >> 1) & 7;
+    const float* a_base = As + l31 * 32;
+    const float* a_kg0 = a_base + (((0 * 2 + lhi) ^ sw) << 2);
+    const float* a_kg1 = a_base + (((1 * 2 + lhi) ^ sw) << 2);
+    const float* a_kg2 = a_base + (((2 * 2 + lhi) ^ sw) << 2);
+    const float* a_kg3 = a_base + (((3 * 2 + lhi) ^ sw) << 2);
+    const float* b_base = Bs + (lhi * BN + wn * 32 + l31) * 4;
+    auto chunk = [&](int c, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int AOFF = BUF * A_STAGE;
+        constexpr int BOFF = BUF * B_STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        float4 a0 = *reinterpret_cast<const float4*>(a_kg0 + AOFF);
+        float4 a1 = *reinterpret_cast<const float4*>(a_kg0 + AOFF + 32 * 32);
+        float4 b0 = *reinterpret_cast<const float4*>(b_base + BOFF);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            float4 na0, na1, nb0;
+            if (kg < 3) {
+                const float* an = kg == 0 ? a_kg1 : kg == 1 ? a_kg2 : a_kg3;
+                na0 = *reinterpret_cast<const float4*>(an + AOFF);
+                na1 = *reinterpret_cast<const float4*>(an + AOFF + 32 * 32);
+                nb0 = *reinterpret_cast<const float4*>(b_base + BOFF + (kg + 1) * 2 * BN * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg == 1) {
+                if (c + 1 < c_end) store_chunk(BUF ? st_ptr0 : st_ptr1);
+                if (c + 2 < c_end) load_chunk();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kg < 3) { a0 = na0; a1 = na1; b0 = nb0; }
+        }
+        __syncthreads();
     };
     int c = c_begin;
     for (; c + 1 < c_end; c += 2) {
@@ -594,6 +751,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     acc_zero(acc);
     gemm_segment<BM, BN, WM, WN>(p, smem, m0, n0, c_begin, c_end, acc);
     tile_store<BM, BN, WM, WN, EPI>(p, p.C + (size_t)blockIdx.z * p.split_stride, m0, n0, acc);
+}
+
+// One block per tile, quad-fed 64 x 128 (needs the k4-packed weights; no split-K).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int mtiles, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (64 + 128)];
+    const int nblk = mtiles * ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8;
+        const int xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / ntiles, nt = bid % ntiles;
+    const int m0 = mt * 64, n0 = nt * 128;
+    f32x16 acc[2][1];
+    acc_zero(acc);
+    gemm_segment_q1(p, smem, m0, n0, 0, p.total_chunks, acc);
+    tile_store<64, 128, 1, 4, EPI>(p, p.C, m0, n0, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -756,6 +932,18 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
+static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
+    const int mtiles = (a.M + 63) / 64, ntiles = a.N / 128;
+    dim3 grid(mtiles * ntiles);
+    switch (epi) {
+        case EPI_NONE: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_NONE>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
+        case EPI_BIAS_RELU: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_BIAS_RELU>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
+        case EPI_RELU_MASK: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_RELU_MASK>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // Persistent workers = resident blocks: 512 8-wave blocks (64 KB LDS, two per CU) or 256 16-wave blocks (96 KB, one
 // per CU).  tools/sk_trace.py shows why the second exists: of two blocks sharing a CU the first-dispatched one runs
 // ~1.3x faster (the SIMD arbiter favours the older waves; s_setprio did not change it) and the other finishes the
@@ -890,10 +1078,11 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     switch (tile) {
         case 0: {
             if (a.N % 128) return hipErrorInvalidValue;
-            if (splits == 1 && use_streamk && a.force != 1) {
+            if (splits == 1 && use_streamk && a.force != 1 && a.force != 4) {
                 const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
                 if (e != hipErrorNotSupported) return e;
             }
+            if (a.Wq && splits == 1 && a.force != 1) return launch_tile_q(a, epi, s);
             return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
         }
         case 1:
@@ -901,6 +1090,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
             return launch_tile<128, 32, 4, 1>(a, epi, splits, s);
         case 2:
             if (a.N % 128) return hipErrorInvalidValue;
+            if (a.Wq && splits == 1 && a.force != 1) return launch_tile_q(a, epi, s);
             return launch_tile<64, 128, 2, 2>(a, epi, splits, s);
         default:
             return hipErrorInvalidValue;

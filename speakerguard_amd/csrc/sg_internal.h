@@ -204,7 +204,8 @@ struct ConvGemmArgs {
     int sk_xcd;         // stream-K: XCD-contiguous workers + n-tile-major tile order (see kernel)
     int num_cus;        // stream-K: persistent blocks = resident slots of THIS device (0: assume 256)
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
-    int force;          // 0 auto, 1 one block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave (parity tests)
+    int force;          // 0 auto, 1 one b32-fed block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave,
+                        // 4 one quad-fed block per tile (parity tests)
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags

@@ -56,7 +56,7 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     B, Ta, Tc, Kc, n, taps, step, base = shape
     a, w = _case(7, B, Ta, Tc, Kc, n, taps)
     want = conv1d_rows(a, w, B, Ta, Tc, taps, step, base)
-    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2, 3)]
+    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2, 3, 4)]
     scale = np.abs(want).max()
     for k, o in enumerate(outs):
         assert np.isfinite(o).all(), "kernel %d left rows unwritten" % k
@@ -65,6 +65,7 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     assert np.array_equal(outs[0], outs[1]), "quad-fed stream-K differs from the tile launch"
     assert np.array_equal(outs[2], outs[1]), "b32-fed stream-K differs from the tile launch"
     assert np.array_equal(outs[3], outs[1]), "8-wave quad-fed stream-K differs from the tile launch"
+    assert np.array_equal(outs[4], outs[1]), "quad-fed tile launch differs from the b32-fed tile launch"
 
 
 def test_conv_rows_epilogues(ctx):
@@ -77,8 +78,9 @@ def test_conv_rows_epilogues(ctx):
         want = conv1d_rows(a, w, B, Ta, Tc, taps, step, 0, **kw)
         o0 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 0, **kw)
         o1 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 1, **kw)
+        o4 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 4, **kw)
         assert np.abs(o0 - want).max() / np.abs(want).max() < 2e-5
-        assert np.array_equal(o0, o1)
+        assert np.array_equal(o0, o1) and np.array_equal(o4, o1)
 
 
 def test_conv_rows_is_torch_conv1d(ctx):
