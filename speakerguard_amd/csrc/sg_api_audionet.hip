@@ -245,6 +245,7 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
         a.tap_base = -kAnPad[l];
         a.total_chunks = 3 * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
+        a.Wq = m.wfq[l];
         AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, EPI_BIAS_RELU, 1, s));
         if (kAnPool[l]) AN_HIP(launch_an_pool_fwd(w.act[l], w.pool[l], d.B, w.Tout[l], kAnCout[l], s));
     }
@@ -277,6 +278,7 @@ int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, floa
         a.tap_base = kAnPad[l];  // d in[t] = sum_j W_j^T d out[t + pad - j]
         a.total_chunks = 3 * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
+        a.Wq = m.wbq[l];
         AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, a.mask ? EPI_RELU_MASK : EPI_NONE, 1, s));
         if (in_pooled)
             AN_HIP(launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], d.B, w.Tout[l - 1], kAnCout[l - 1], s));
@@ -340,6 +342,14 @@ int sg_an_load(sg_ctx* ctx, const sg_an_weights* w) {
         }
         rc |= an_upload(ctx, pool, &m.wf[l], wf);
         rc |= an_upload(ctx, pool, &m.wb[l], wb);
+        auto packed = [](const std::vector<float>& w, int K, int N) {  // [K][N] -> k4-major [K/4][N][4]
+            std::vector<float> q((size_t)K * N);
+            for (int k = 0; k < K; ++k)
+                for (int n = 0; n < N; ++n) q[((size_t)(k / 4) * N + n) * 4 + (k & 3)] = w[(size_t)k * N + n];
+            return q;
+        };
+        if (cout % 128 == 0) rc |= an_upload(ctx, pool, &m.wfq[l], packed(wf, 3 * cin, cout));
+        if (cin % 128 == 0) rc |= an_upload(ctx, pool, &m.wbq[l], packed(wb, 3 * cout, cin));
         rc |= an_upload(ctx, pool, &m.bias[l], bias);
     }
     rc |= an_upload(ctx, pool, &m.fc_w, std::vector<float>(w->fc_weight, w->fc_weight + (size_t)w->num_class * 32));

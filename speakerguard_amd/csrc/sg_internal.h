@@ -67,6 +67,8 @@ struct AnModel {
     float pre_bias = 0.f;
     float* wf[kAnConv] = {};    // forward  [3*Cin][Cout]   (BatchNorm folded)
     float* wb[kAnConv] = {};    // backward [3*Cout][Cin]
+    float* wfq[kAnConv] = {};   // k4-packed copies for the quad-fed tile kernel (layers whose N is a multiple of 128)
+    float* wbq[kAnConv] = {};
     float* bias[kAnConv] = {};
     float* fc_w = nullptr;      // [S][32]
     float* fc_b = nullptr;      // [S]
