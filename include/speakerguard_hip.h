@@ -41,8 +41,12 @@ int sg_version(void);
 int sg_create(int device, sg_ctx** out);
 void sg_destroy(sg_ctx* ctx);
 const char* sg_last_error(const sg_ctx* ctx);
-/* blocks until everything enqueued on `stream` by this ctx has finished */
+/* blocks until everything enqueued on `stream` by this ctx has finished, then reports sg_health() */
 int sg_sync(sg_ctx* ctx, void* stream);
+/* SG_ERR_HIP if a kernel of an earlier launch raised the context's health word (a stream-K hand-off wait that timed
+ * out: the contraction's output, and everything computed from it, is invalid); clears the word.  Does not
+ * synchronise -- call it after the results were awaited (sg_sync does both).  Every pass entry point checks it too. */
+int sg_health(sg_ctx* ctx);
 
 /* ---- x-vector + PLDA model ----------------------------------------------------------------
  * Replaces the tensors the reference holds after model/xv_plda.py:17-47 ran: the xvecTDNN
@@ -73,6 +77,11 @@ typedef struct sg_xv_weights {
 int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w);
 /* replace the enrolled speakers / threshold only (model.enroll_embs, model.threshold) */
 int sg_xv_set_enroll(sg_ctx* ctx, const float* enroll_host, int32_t S, float threshold);
+/* The per-call `enroll_embs=` argument of forward / score / make_decision (model/iv_plda.py:155-165,172-194): score
+ * the following passes against a caller-owned DEVICE table (S, D) instead of the model's enrolled set, which stays
+ * untouched.  NULL ends the override.  No allocation, no synchronisation; the table must stay valid until the passes
+ * enqueued while it was set have finished. */
+int sg_xv_enroll_override(sg_ctx* ctx, const float* enroll_dev, int32_t S);
 
 /* number of frames / TDNN output frames for T samples (0 if too short) */
 int32_t sg_xv_num_frames(int32_t T);

@@ -23,7 +23,7 @@ EXPORTS = (
     "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
     "sg_an_pgd_run", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
     "sg_xv_mfcc_backward", "sg_xv_cmvn_backward", "sg_feco_kmeans", "sg_feco_compress", "sg_feco_compress_backward",
-    "sg_an_logmel_backward",
+    "sg_an_logmel_backward", "sg_xv_enroll_override", "sg_health",
 )
 
 
@@ -87,8 +87,10 @@ def load():
         "sg_destroy": (None, [vp]),
         "sg_last_error": (C.c_char_p, [vp]),
         "sg_sync": (C.c_int, [vp, vp]),
+        "sg_health": (C.c_int, [vp]),
         "sg_xv_load": (C.c_int, [vp, C.POINTER(XvWeights)]),
         "sg_xv_set_enroll": (C.c_int, [vp, vp, i32, f32]),
+        "sg_xv_enroll_override": (C.c_int, [vp, vp, i32]),
         "sg_xv_num_frames": (i32, [i32]),
         "sg_input_scale": (C.c_int, [vp, vp, i64, vp, vp]),
         "sg_xv_mfcc": (C.c_int, [vp, vp, i32, i32, vp, C.POINTER(Dither), vp, vp]),

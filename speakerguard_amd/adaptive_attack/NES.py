@@ -29,8 +29,16 @@ class NES:
         model = self.EOT_wrapper.model
         base = getattr(model, 'base_model', model)
         x = x.contiguous()
-        NES._draws += 1
-        seed = (self.seed * 0x9E3779B97F4A7C15 + NES._draws) & 0xFFFFFFFFFFFFFFFF
+        index_base = 0
+        if hasattr(base, 'noise_seed'):
+            # keyed by (seed, attack call, restart, chunk base, NES call inside the chunk) + global example index in
+            # the kernel: independent of the shard layout (model/_engine_ops.py)
+            base._nes_draw += 1
+            seed = base.noise_seed(self.seed ^ 0x4E4553, base._nes_draw)
+            index_base = base._index_base
+        else:
+            NES._draws += 1
+            seed = (self.seed * 0x9E3779B97F4A7C15 + NES._draws) & 0xFFFFFFFFFFFFFFFF
         grad = torch.empty_like(x)
         EOT_num_batches = int(self.EOT_wrapper.EOT_size // self.EOT_wrapper.EOT_batch_size)
         for i in range(num_batches):
@@ -38,7 +46,7 @@ class NES:
             noise_in = None
             if self.noise_fn is not None:
                 noise_in = self.noise_fn([n_audios, half, n_channels, N]).to(x.device, torch.float32).contiguous()
-            eval_input, _ = base.nes_queries(x, half, with_clean, self.sigma, seed, i * half, noise_in)
+            eval_input, _ = base.nes_queries(x, half, with_clean, self.sigma, seed, i * half, noise_in, index_base=index_base)
             per = 2 * half + int(with_clean)
             eval_y = y.repeat_interleave(per)
             scores, loss, _, decisions = self.EOT_wrapper(eval_input, eval_y)
@@ -46,7 +54,7 @@ class NES:
             scores = (scores / EOT_num_batches).view(n_audios, -1, scores.shape[1])
             last = i == num_batches - 1
             base.nes_grad(loss, grad, n_audios, N, half, with_clean, seed, i * half, noise_in, i > 0,
-                          self.sigma if last else 0.0, num_batches)
+                          self.sigma if last else 0.0, num_batches, index_base=index_base)
             if i == 0:
                 adver_loss = loss[..., 0]
                 adver_score = scores[:, 0, :]

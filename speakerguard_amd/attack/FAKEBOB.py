@@ -147,11 +147,18 @@ class FAKEBOB(Attack):
         batch_size = min(self.batch_size, n_audios)
         n_batches = int(np.ceil(n_audios / float(batch_size)))
         adver, success = [], []
+        base = getattr(self.model, 'base_model', self.model)
+        if hasattr(base, 'begin_attack'):
+            base.begin_attack()
         for batch_id in range(n_batches):
             sl = slice(batch_id * batch_size, (batch_id + 1) * batch_size)
+            if hasattr(base, 'begin_batch'):  # NES / dither noise keyed by the chunk's global position (shard-invariant)
+                base.begin_batch(getattr(self, 'index_offset', 0) + sl.start, 0)
             a, s = self.attack_batch(x[sl], y[sl], lower[sl], upper[sl], batch_id)
             adver.append(a)
             success += s
+        if hasattr(base, 'check_health'):  # see FGSM._run_batches
+            base.check_health()
         return torch.cat(adver, 0), success
 
     # ------------------------------------------------------------------ threshold estimation (:210-295)

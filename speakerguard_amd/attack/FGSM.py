@@ -92,6 +92,19 @@ class FGSM(Attack):
                 base.pgd_update(x_batch, grad, lower, upper, self.step_size, self.grad_sign)
         return x_batch, success
 
+    index_offset = 0  # global index of x[0] when this object attacks one shard of a larger batch (shard.py)
+
+    def _begin_attack(self):
+        base = getattr(self.model, 'base_model', self.model)
+        if hasattr(base, 'begin_attack'):
+            base.begin_attack()
+
+    def _begin_batch(self, start, tag=None):
+        # noise streams (dither, NES) are keyed by the chunk's GLOBAL position, not by what ran before it
+        base = getattr(self.model, 'base_model', self.model)
+        if hasattr(base, 'begin_batch'):
+            base.begin_batch(self.index_offset + start, 0 if tag is None else int(tag) + 1)
+
     def _run_batches(self, x, y, lower, upper, tag=None):
         n_audios = x.shape[0]
         batch_size = min(self.batch_size, n_audios)
@@ -100,9 +113,15 @@ class FGSM(Attack):
         for batch_id in range(n_batches):
             sl = slice(batch_id * batch_size, (batch_id + 1) * batch_size)
             bid = batch_id if tag is None else '{}-{}'.format(tag, batch_id)
+            self._begin_batch(sl.start, tag)
             a, s = self.attack_batch(x[sl], y[sl], lower[sl], upper[sl], bid)
             adver.append(a)
             success += s
+        # the success flags are on the host, so every launch of these batches has finished: a kernel that flagged
+        # its own output as invalid (engine health word) must not go unnoticed
+        base = getattr(self.model, 'base_model', self.model)
+        if hasattr(base, 'check_health'):
+            base.check_health()
         return torch.cat(adver, 0), success
 
     def _check_inputs(self, x, y):
@@ -114,6 +133,7 @@ class FGSM(Attack):
 
     def attack(self, x, y):
         self._check_inputs(x, y)
+        self._begin_attack()
         lower = torch.tensor(-1, device=x.device, dtype=x.dtype).expand_as(x)
         upper = torch.tensor(1, device=x.device, dtype=x.dtype).expand_as(x)
         return self._run_batches(x, y, lower, upper)

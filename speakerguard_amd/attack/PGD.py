@@ -24,6 +24,7 @@ class PGD(FGSM):
 
     def attack(self, x, y):
         self._check_inputs(x, y)
+        self._begin_attack()
         upper = torch.clamp(x + self.epsilon, max=1)   # PGD.py:48-49
         lower = torch.clamp(x - self.epsilon, min=-1)
         x_ori = x.clone()

@@ -367,7 +367,7 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = m0 + (ts >> 3) + 16 * WMW * i;
-            row_off[i] = (unsigned)(((b * p.Ta + t) * p.lda + c4 * 4) * 4);
+            row_off[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
             a_t[i] = r < p.M ? t : -(1 << 28);
             t += 16 * WMW;
             while (t >= p.Tc) {
@@ -519,7 +519,7 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = m0 + (ts >> 3) + 16 * i;
-            row_off[i] = (unsigned)(((b * p.Ta + t) * p.lda + c4 * 4) * 4);
+            row_off[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
             a_t[i] = r < p.M ? t : -(1 << 28);
             t += 16;
             while (t >= p.Tc) {
@@ -862,7 +862,8 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (ablate bit 8 = fault injection for tests/test_gpu_conv.py: the flag is never published)
+            if (!(p.ablate & 8)) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         SG_STAMP(2)
     }
@@ -888,7 +889,12 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
             unsigned spins = 0;
             while (__hip_atomic_load(flags + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 26)) break;  // bounded: a lost hand-off shows up as a parity failure
+                if (++spins > ((p.ablate & 8) ? (1u << 12) : (1u << 26))) {
+                    // bounded (a partner that never became resident must not hang the GPU); the tile is then wrong,
+                    // so raise the context's health word: the next API call / sg_sync fails with SG_ERR_HIP
+                    if (p.err_word) __hip_atomic_fetch_or(p.err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -970,6 +976,24 @@ static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, 
                        tiles, ipw, slabs, flags, epoch);
 }
 
+// resident blocks per CU the runtime admits for a stream-K kernel (all workers must be co-resident: a waiter spins on
+// its predecessor); queried once per kind, with the dynamic-LDS opt-in applied first
+template <int KIND>
+static int streamk_blocks_per_cu() {
+    static const int n = [] {
+        constexpr int bm = KIND == 2 ? 256 : 128;
+        constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
+        const void* fn = reinterpret_cast<const void*>(conv_gemm_streamk_kernel<EPI_NONE, KIND>);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_streamk_kernel<EPI_NONE, KIND>, KIND == 2 ? 1024 : 512,
+                                                         lds) != hipSuccess)
+            nb = 0;
+        return nb;
+    }();
+    return n;
+}
+
 // returns hipErrorNotSupported when the shape does not qualify (caller falls back to the tile launch)
 static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, unsigned* flags, hipStream_t s) {
     static const int w16 = [] {
@@ -992,6 +1016,9 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 16;  // >= 16 chunks (K >= 512): tdnn4 / tdnn5 gain 4-12 %, tdnn1 (5 chunks) loses
     }();
     if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
+    // every worker has to be resident at once; if the runtime would admit fewer blocks than that, use the tile launch
+    const int per_cu = kind == 2 ? streamk_blocks_per_cu<2>() : kind == 1 ? streamk_blocks_per_cu<1>() : streamk_blocks_per_cu<0>();
+    if ((long)per_cu * cus < workers) return hipErrorNotSupported;
     static std::atomic<unsigned> launch_counter{0};
     unsigned epoch = ++launch_counter;
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
@@ -1072,9 +1099,15 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
         return e ? atoi(e) : 1;
     }();
     if (!use_quad || a.force == 2 || (a.ldw % 4) || (a.Kc % 4)) a.Wq = nullptr;
-    a.a_bytes = (unsigned)((size_t)(a.M / a.Tc) * a.Ta * a.lda * sizeof(float));
-    a.w_bytes = (unsigned)((size_t)a.taps * a.Kc * a.ldw * sizeof(float));
-    if (a.Kc % BK != 0 || a.M <= 0) return hipErrorInvalidValue;
+    if (a.Kc % BK != 0 || a.M <= 0 || a.Tc <= 0) return hipErrorInvalidValue;
+    // The staging loads address A and W through 32-bit buffer descriptors (num_records, per-lane byte offsets), and
+    // the "this tap row is outside the utterance" marker is the offset 0x80000000, which must stay out of range:
+    // an operand of 2 GiB or more is refused (the API layer reports the largest batch that fits, see check_dims).
+    const size_t a_bytes = (size_t)(a.M / a.Tc) * a.Ta * a.lda * sizeof(float);
+    const size_t w_bytes = (size_t)a.taps * a.Kc * a.ldw * sizeof(float);
+    if (a_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) return hipErrorInvalidValue;
+    a.a_bytes = (unsigned)a_bytes;
+    a.w_bytes = (unsigned)w_bytes;
     switch (tile) {
         case 0: {
             if (a.N % 128) return hipErrorInvalidValue;

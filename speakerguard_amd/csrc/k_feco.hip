@@ -36,16 +36,22 @@ int feco_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
 
 constexpr int kFecoMaxD = 64;
 
-// one block per utterance; dynamic LDS: x[F][D], c[k][D], ids[F] (int), changed flag
+// one block per utterance; dynamic LDS: [x[F][D] when X_IN_LDS,] c[k][D], ids[F] (int); changed flag.
+// X_IN_LDS = false is the long-utterance form: the frames stay in HBM (read-only, served by L1/L2), only the
+// centroids and ids live in LDS -- same arithmetic, same order, same ids.
+template <bool X_IN_LDS>
 __global__ __launch_bounds__(256) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
                                                           int max_iter, int* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;
-    float* cs = xs + (size_t)F * D;
+    float* cs = lds + (X_IN_LDS ? (size_t)F * D : 0);
     int* ids = reinterpret_cast<int*>(cs + (size_t)k * D);
     __shared__ int changed;
     const float* x = feats + (size_t)blockIdx.x * F * D;
-    for (int i = threadIdx.x; i < F * D; i += blockDim.x) xs[i] = x[i];
+    const float* xs = x;
+    if (X_IN_LDS) {
+        for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds[i] = x[i];
+        xs = lds;
+    }
     for (int i = threadIdx.x; i < F; i += blockDim.x) ids[i] = -1;
     __syncthreads();
     for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
@@ -135,14 +141,27 @@ extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, in
     if (!ctx) return SG_ERR_ARG;
     if (!feats_dev || !assign_dev || B <= 0 || F <= 0 || D <= 0 || D > kFecoMaxD || k <= 0 || k > F || max_iter <= 0)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: need 0 < k <= F, 0 < D <= %d, max_iter > 0", kFecoMaxD);
-    const size_t lds = ((size_t)F * D + (size_t)k * D) * sizeof(float) + (size_t)F * sizeof(int);
-    if (lds > 150 * 1024)
-        return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: %d frames x %d dims with %d clusters need %zu bytes of LDS (limit 150 KB)",
-                         F, D, k, lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(feco_kmeans_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (hipSetDevice(ctx->device) != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: hipSetDevice failed");
+    // Placement: frames + centroids + ids in one block's LDS when they fit (3 s .. ~8 s utterances); for longer
+    // utterances the frames stay in HBM and only centroids + ids use LDS (up to k * D * 4 + F * 4 <= 150 KB, i.e.
+    // ~23 s at D = 32, ratio 0.5); beyond that the call is refused.
+    constexpr size_t kLdsMax = 150 * 1024;
+    const size_t lds_small = ((size_t)k * D) * sizeof(float) + (size_t)F * sizeof(int);
+    const size_t lds_full = lds_small + (size_t)F * D * sizeof(float);
+    if (lds_small > kLdsMax)
+        return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: %d clusters x %d dims + %d ids need %zu bytes of LDS (limit %zu): "
+                         "utterance too long for one block", k, D, F, lds_small, kLdsMax);
+    const bool in_lds = lds_full <= kLdsMax;
+    const void* fn = in_lds ? reinterpret_cast<const void*>(feco_kmeans_kernel<true>)
+                            : reinterpret_cast<const void*>(feco_kmeans_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(feco_kmeans_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter, assign_dev);
+    if (in_lds)
+        hipLaunchKernelGGL(feco_kmeans_kernel<true>, dim3(B), dim3(256), lds_full, (hipStream_t)stream, feats_dev, F, D, k,
+                           max_iter, assign_dev);
+    else
+        hipLaunchKernelGGL(feco_kmeans_kernel<false>, dim3(B), dim3(256), lds_small, (hipStream_t)stream, feats_dev, F, D, k,
+                           max_iter, assign_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     return SG_OK;
@@ -153,6 +172,7 @@ extern "C" int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32
     if (!ctx) return SG_ERR_ARG;
     if (!feats_dev || !assign_dev || !out_dev || !counts_dev || B <= 0 || F <= 0 || D <= 0 || k <= 0 || k > F)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_compress: bad arguments");
+    if (hipSetDevice(ctx->device) != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_compress: hipSetDevice failed");
     hipLaunchKernelGGL(feco_compress_kernel, dim3((k * D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feats_dev,
                        assign_dev, F, D, k, out_dev, counts_dev);
     const hipError_t e = hipGetLastError();
@@ -166,6 +186,8 @@ extern "C" int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, con
     if (!ctx) return SG_ERR_ARG;
     if (!dout_dev || !assign_dev || !counts_dev || !dfeats_dev || B <= 0 || F <= 0 || D <= 0 || k <= 0 || k > F)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_compress_backward: bad arguments");
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return feco_fail(ctx, SG_ERR_HIP, "sg_feco_compress_backward: hipSetDevice failed");
     hipLaunchKernelGGL(feco_compress_bwd_kernel, dim3((F * D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dout_dev,
                        assign_dev, counts_dev, F, D, k, force, dfeats_dev);
     const hipError_t e = hipGetLastError();

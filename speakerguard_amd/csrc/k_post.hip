@@ -171,6 +171,7 @@ extern "C" int sg_wav_finalize(sg_ctx* ctx, const float* benign_dev, const float
     if (!ctx) return SG_ERR_ARG;
     if (!adver_dev || B <= 0 || T <= 0 || (!pcm_dev && !metrics_dev) || (metrics_dev && !benign_dev))
         return post_fail(ctx, SG_ERR_ARG, "sg_wav_finalize: need adver, B > 0, T > 0, an output, and benign for metrics");
+    if (hipSetDevice(ctx->device) != hipSuccess) return post_fail(ctx, SG_ERR_HIP, "sg_wav_finalize: hipSetDevice failed");
     hipLaunchKernelGGL(wav_finalize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, metrics_dev ? benign_dev : nullptr,
                        adver_dev, T, pcm_dev, metrics_dev);
     const hipError_t e = hipGetLastError();
@@ -183,6 +184,7 @@ extern "C" int sg_eer_threshold(sg_ctx* ctx, const float* target_dev, int32_t n_
     if (!ctx) return SG_ERR_ARG;
     if (!target_dev || !untarget_dev || !out3_dev || n_target <= 0 || n_untarget <= 0)
         return post_fail(ctx, SG_ERR_ARG, "sg_eer_threshold: need non-empty target and untarget score lists");
+    if (hipSetDevice(ctx->device) != hipSuccess) return post_fail(ctx, SG_ERR_HIP, "sg_eer_threshold: hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
     double* tmp = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)3 * n_target * sizeof(double));

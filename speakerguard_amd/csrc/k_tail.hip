@@ -184,11 +184,13 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
 
 hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     const XvModel& x = *a.m;
-    if (x.D > kMaxD || x.S > kMaxS || x.S < 1) return hipErrorInvalidValue;
+    const int S = x.enroll_override ? x.S_override : x.S;  // per-call enroll_embs= (iv_plda.py:155-165)
+    if (x.D > kMaxD || S > kMaxS || S < 1) return hipErrorInvalidValue;
     TailModelDev m;
     m.fc1_b = x.fc1_b; m.emb_mean = x.emb_mean; m.lda = x.lda; m.lda_t = x.lda_t; m.plda_mean = x.plda_mean;
-    m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi; m.enroll = x.enroll;
-    m.D = x.D; m.S = x.S; m.threshold = x.threshold;
+    m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi;
+    m.enroll = x.enroll_override ? x.enroll_override : x.enroll;
+    m.D = x.D; m.S = S; m.threshold = x.threshold;
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
     hipLaunchKernelGGL(tail_kernel, dim3(a.B), dim3(kTailThreads), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
                        a.tdnn_emb, a.emb, a.scores, a.decisions, a.loss_out, a.demb, a.loss_trace, a.decision_trace,

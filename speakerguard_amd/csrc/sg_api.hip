@@ -275,6 +275,7 @@ ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
     a.split_stride = 0;
     a.sk_slabs = ctx->sk_slabs;
     a.sk_flags = ctx->sk_flags;
+    a.err_word = ctx->err_dev;
     a.num_cus = ctx->num_cus;
     return a;
 }
@@ -333,6 +334,7 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.split_stride = 0;
         a.sk_slabs = ctx->sk_slabs;
         a.sk_flags = ctx->sk_flags;
+        a.err_word = ctx->err_dev;
         a.num_cus = ctx->num_cus;
         int splits = 1;
         if (l == 0) {  // 32 output columns: 148 tiles at B = 64 -- split K per tap to fill the chip
@@ -348,6 +350,7 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
 int check_dims(sg_ctx* ctx, int B, int TF, int flag, PassDims* d) {
     if (!ctx) return SG_ERR_ARG;
     if (!ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no x-vector model loaded (call sg_xv_load)");
+    if (int h = sg_health(ctx)) return h;
     SG_HIP(hipSetDevice(ctx->device));
     if (B < 1) return fail(ctx, SG_ERR_ARG, "B must be >= 1");
     if (flag < 0 || flag > 2) return fail(ctx, SG_ERR_ARG, "flag must be 0 (wav), 1 (raw feat) or 2 (cmvn feat)");
@@ -362,6 +365,20 @@ int check_dims(sg_ctx* ctx, int B, int TF, int flag, PassDims* d) {
     }
     int Fl[kLayers];
     if (!layer_frames(d->F, Fl)) return fail(ctx, SG_ERR_ARG, "%d frames are too few for the TDNN context", d->F);
+    // the contraction kernels address an activation tensor through 32-bit buffer offsets (k_conv_gemm.hip): the
+    // largest one, the (B, F5, 1536) tdnn5 output, has to stay below 2 GiB -- B <= 1294 at 3 s, far past the
+    // throughput plateau (B = 512); callers chunk larger sets (attack.* does, by batch_size)
+    {
+        size_t worst = 0;
+        for (int l = 0; l < kLayers; ++l) {
+            const size_t bytes = (size_t)B * Fl[l] * kCoutPad[l] * sizeof(float);
+            if (bytes > worst) worst = bytes;
+        }
+        if (worst >= 0x80000000ull)
+            return fail(ctx, SG_ERR_ARG, "batch of %d x %d frames needs a %.1f GiB activation tensor; one pass handles < 2 GiB "
+                        "(at most %d utterances of this length): split the batch", B, d->F, (double)worst / (1ull << 30),
+                        (int)(0x7FFFFFFFull / (worst / (size_t)B)));
+    }
     int rc = build_tables(ctx);
     if (rc) return rc;
     rc = ensure_workspace(ctx, d->B, d->T, d->F);
@@ -423,6 +440,13 @@ int sg_create(int device, sg_ctx** out) {
         delete ctx;
         return SG_ERR_HIP;
     }
+    void* hw = nullptr;
+    if (hipHostMalloc(&hw, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        ctx->err_host = static_cast<unsigned*>(hw);
+        *ctx->err_host = 0;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, hw, 0) == hipSuccess) ctx->err_dev = static_cast<unsigned*>(dp);
+    }
     *out = ctx;
     return SG_OK;
 }
@@ -432,7 +456,9 @@ void sg_destroy(sg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     free_pool(ctx->ws.allocs);
+    free_pool(ctx->xv.allocs);
     free_pool(ctx->model_allocs);
+    if (ctx->err_host) (void)hipHostFree(ctx->err_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -443,6 +469,17 @@ const char* sg_last_error(const sg_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 int sg_sync(sg_ctx* ctx, void* stream) {
     if (!ctx) return SG_ERR_ARG;
     SG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return sg_health(ctx);
+}
+
+int sg_health(sg_ctx* ctx) {
+    if (!ctx) return SG_ERR_ARG;
+    if (ctx->err_host && __atomic_load_n(ctx->err_host, __ATOMIC_RELAXED) != 0) {
+        __atomic_store_n(ctx->err_host, 0u, __ATOMIC_RELAXED);
+        return fail(ctx, SG_ERR_HIP, "a stream-K hand-off wait timed out inside an earlier contraction launch (partner block "
+                    "not resident: CU mask or a competing kernel?); results produced since then are invalid. "
+                    "SG_STREAMK=0 selects the one-block-per-tile launches");
+    }
     return SG_OK;
 }
 
@@ -461,8 +498,12 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
     int rc = build_tables(ctx);
     if (rc) return rc;
     XvModel& m = ctx->xv;
+    if (!m.allocs.empty()) {  // reload: release the previous model's tensors (nothing may still be reading them)
+        SG_HIP(hipDeviceSynchronize());
+        free_pool(m.allocs);
+    }
     m = XvModel();
-    std::vector<void*>& pool = ctx->model_allocs;
+    std::vector<void*>& pool = m.allocs;
     const double eps = w->bn_eps > 0.f ? w->bn_eps : 1e-5;
 
     // BatchNorm1d(affine=False) in eval mode is y = (a - mean) * r, r = 1/sqrt(var + eps), applied
@@ -551,6 +592,7 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
     if (rc) return fail(ctx, SG_ERR_HIP, "model upload failed: %s", ctx->err.c_str());
     m.D = D;
     m.S = S;
+    m.enroll_cap = S;
     m.threshold = w->threshold;
     m.loaded = true;
     return SG_OK;
@@ -559,14 +601,35 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
 int sg_xv_set_enroll(sg_ctx* ctx, const float* enroll_host, int32_t S, float threshold) {
     if (!ctx || !ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no model loaded");
     if (S < 1 || S > 1024) return fail(ctx, SG_ERR_ARG, "S must be 1..1024");
+    XvModel& m = ctx->xv;
     if (enroll_host) {
-        SG_HIP(hipDeviceSynchronize());
-        int rc = dev_upload(ctx, ctx->model_allocs, &ctx->xv.enroll,
-                            std::vector<float>(enroll_host, enroll_host + (size_t)S * ctx->xv.D));
-        if (rc) return rc;
-        ctx->xv.S = S;
+        SG_HIP(hipSetDevice(ctx->device));
+        SG_HIP(hipDeviceSynchronize());  // earlier passes may still read the table
+        if (S > m.enroll_cap) {  // grow: the old table goes back to the allocator, nothing accumulates
+            float* fresh = nullptr;
+            int rc = dev_alloc(ctx, m.allocs, &fresh, (size_t)S * m.D);
+            if (rc) return rc;
+            for (size_t i = 0; i < m.allocs.size(); ++i)
+                if (m.allocs[i] == m.enroll) {
+                    (void)hipFree(m.enroll);
+                    m.allocs.erase(m.allocs.begin() + i);
+                    break;
+                }
+            m.enroll = fresh;
+            m.enroll_cap = S;
+        }
+        SG_HIP(hipMemcpy(m.enroll, enroll_host, (size_t)S * m.D * sizeof(float), hipMemcpyHostToDevice));
+        m.S = S;
     }
-    ctx->xv.threshold = threshold;
+    m.threshold = threshold;
+    return SG_OK;
+}
+
+int sg_xv_enroll_override(sg_ctx* ctx, const float* enroll_dev, int32_t S) {
+    if (!ctx || !ctx->xv.loaded) return fail(ctx, SG_ERR_STATE, "no model loaded");
+    if (enroll_dev && (S < 1 || S > 1024)) return fail(ctx, SG_ERR_ARG, "S must be 1..1024");
+    ctx->xv.enroll_override = enroll_dev;
+    ctx->xv.S_override = enroll_dev ? S : 0;
     return SG_OK;
 }
 
@@ -778,7 +841,7 @@ int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c
     a.M = B * Tc; a.N = N; a.Ta = Ta; a.Tc = Tc; a.Kc = Kc; a.lda = Kc; a.ldw = N; a.ldc = N;
     a.taps = taps; a.tap_step = tap_step; a.tap_base = tap_base;
     a.total_chunks = taps * (Kc / 32); a.chunks_per_split = a.total_chunks;
-    a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.num_cus = ctx->num_cus; a.force = kernel;
+    a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.err_word = ctx->err_dev; a.num_cus = ctx->num_cus; a.force = kernel;
     if (e == hipSuccess) e = launch_conv_gemm(a, 0, epi, 1, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(wq);
@@ -806,7 +869,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
         a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
         a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];
         a.total_chunks = a.taps * (a.Kc / 32); a.chunks_per_split = a.total_chunks;
-        a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.num_cus = ctx->num_cus;
+        a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.err_word = ctx->err_dev; a.num_cus = ctx->num_cus;
         tile = l == 0 ? 1 : 0;
         epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;
         if (l == 0) {

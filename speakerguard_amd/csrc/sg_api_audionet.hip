@@ -202,6 +202,11 @@ int an_check(sg_ctx* ctx, int B, int TF, int flag, AnDims* d) {
     int Tin[kAnConv], Tout[kAnConv];
     if (!an_layer_frames(d->F, Tin, Tout))
         return an_fail(ctx, SG_ERR_ARG, "%d frames are too few for the AudioNet stack (need >= 3 frames at conv8)", d->F);
+    // 32-bit buffer offsets in the contraction kernels (k_conv_gemm.hip): every activation tensor < 2 GiB
+    for (int l = 0; l < kAnConv; ++l)
+        if ((size_t)B * Tout[l] * kAnCout[l] * sizeof(float) >= 0x80000000ull || (size_t)B * d->F * 32 * sizeof(float) >= 0x80000000ull)
+            return an_fail(ctx, SG_ERR_ARG, "batch of %d x %d frames exceeds the 2 GiB per-tensor limit of one pass: split the batch",
+                           B, d->F);
     int rc = an_build_tables(ctx);
     if (rc) return rc;
     rc = an_ensure_workspace(ctx, d->B, d->T, d->F);

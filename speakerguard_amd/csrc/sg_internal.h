@@ -132,6 +132,12 @@ struct XvModel {
     float* plda_pt = nullptr;   // [D][D] transposed
     float* plda_psi = nullptr;  // [D]
     float* enroll = nullptr;    // [S][D]
+    int enroll_cap = 0;         // speakers the enroll buffer holds (sg_xv_set_enroll reuses it)
+    // per-call override of the enrolled set (iv_plda.py:155-165 enroll_embs=): a caller-owned device table that the
+    // next passes score against; the model's own set is untouched
+    const float* enroll_override = nullptr;
+    int S_override = 0;
+    std::vector<void*> allocs;  // device memory owned by this model (freed on reload / destroy)
 };
 
 struct Workspace {
@@ -174,6 +180,10 @@ struct sg_ctx {
     unsigned* sk_flags = nullptr;
     sg::XvModel xv;
     sg::Workspace ws;
+    // Health word: host-pinned, device-mapped.  A kernel that gives up on a stream-K hand-off (bounded spin) ORs a
+    // bit into it; every pass entry point and sg_sync read the host side and fail loudly (no synchronisation needed).
+    unsigned* err_host = nullptr;
+    unsigned* err_dev = nullptr;
     sg::AnTables an_tab{};
     bool an_tables_ready = false;
     sg::AnModel an;
@@ -208,9 +218,11 @@ struct ConvGemmArgs {
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
     int force;          // 0 auto, 1 one b32-fed block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave,
                         // 4 one quad-fed block per tile (parity tests)
-    int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
+    int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier;
+                        // 8 = fault injection: stream-K hand-off flags are never published (health-word test)
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags
+    unsigned* err_word; // stream-K: device-visible health word (bit 0 = a hand-off wait timed out), may be null
 };
 
 // tile: 0 = auto (stream-K 128x128 8-wave blocks when the shape qualifies, else 64x128), 1 = 128x32 (4x1 waves),

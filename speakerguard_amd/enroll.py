@@ -35,16 +35,11 @@ def enroll_speaker(model, utterances):
 
 def znorm_stats(model, emb, test_utterances):
     """(mean, std) of the scores of other speakers' test utterances against `emb` (:68-92; np.std, ddof 0).
-    The model's own enrolled set is restored afterwards."""
-    saved = getattr(model, "enroll_embs", None) if getattr(model, "_has_enroll", False) else None
+    ``enroll_embs=`` is a per-call override (iv_plda.py:155-165): the model's own enrolled set is not touched."""
     scores = []
-    try:
-        for audio in test_utterances:
-            s = model.score(_as_batch(audio, model.device), enroll_embs=emb)
-            scores.append(float(s.flatten()[0].item()))
-    finally:
-        if saved is not None:
-            model.set_enroll(saved)
+    for audio in test_utterances:
+        s = model.score(_as_batch(audio, model.device), enroll_embs=emb)
+        scores.append(float(s.flatten()[0].item()))
     return float(np.mean(scores)), float(np.std(scores))
 
 

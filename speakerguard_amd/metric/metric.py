@@ -15,7 +15,11 @@ _ctx = {}
 
 
 def _context(device):
-    idx = device.index or 0
+    """One engine context per GPU.  An index-less ``cuda`` device means torch's CURRENT device (not GPU 0)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise N.NativeError("the HIP engine needs a GPU tensor/device (got %s)" % device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _ctx:
         _ctx[idx] = N.Context(idx)
     return _ctx[idx]
@@ -32,7 +36,7 @@ def batch_metrics(benign, adver, device=None):
     b, a = _rows(benign), _rows(adver)
     if b.shape != a.shape:
         raise ValueError("benign and adversarial audio must have the same shape, got %s vs %s" % (tuple(b.shape), tuple(a.shape)))
-    dev = torch.device(device) if device is not None else (a.device if a.is_cuda else torch.device("cuda:0"))
+    dev = torch.device(device) if device is not None else (a.device if a.is_cuda else torch.device("cuda", torch.cuda.current_device()))
     if dev.type != "cuda":
         raise N.NativeError("metrics run on the HIP device only (got %s)" % dev)
     b, a = b.to(dev).contiguous(), a.to(dev).contiguous()

@@ -8,11 +8,51 @@ import torch
 from .. import _native as N
 
 
+_MASK64 = (1 << 64) - 1
+
+
+def mix64(*vals):
+    """Order-dependent 64-bit hash of integers (splitmix-style); seeds of the engine's counter-based generators."""
+    h = 0x9E3779B97F4A7C15
+    for v in vals:
+        h = ((h ^ (int(v) & _MASK64)) * 0xBF58476D1CE4E5B9) & _MASK64
+        h ^= h >> 31
+    return h
+
+
 class EngineOps:
-    """Mixin: expects ``self.ctx`` (N.Context) and ``self.device``."""
+    """Mixin: expects ``self.ctx`` (N.Context) and ``self.device``.
+
+    Noise bookkeeping (dither of the MFCC front-end, NES queries): the reference draws from the process-global torch
+    RNG, which makes an utterance's noise depend on everything that ran before it.  Here every draw is keyed by
+    (user seed, attack call, restart, chunk base = GLOBAL index of the chunk's first utterance, pass number inside
+    the chunk) and, inside the kernels, by the row within the chunk -- so the noise an utterance sees does not depend
+    on how the batch is cut into per-GPU shards (shards are cut on chunk boundaries, speakerguard_amd/shard.py).
+    ``attack()`` calls ``begin_attack`` once, ``_run_batches`` calls ``begin_batch`` per chunk; without them every
+    forward simply advances ``_draw`` (fresh noise per call, like the reference).
+    """
+    _noise_epoch = 0   # attack() calls so far
+    _batch_salt = 0    # restart number + 1 (0: none)
+    _index_base = 0    # global index of the first utterance of the chunk being attacked
+    _draw = 0          # passes since begin_batch
+    _nes_draw = 0      # NES.forward calls since begin_batch
+
+    def begin_attack(self):
+        self._noise_epoch += 1
+
+    def begin_batch(self, index_base=0, salt=0):
+        self._index_base, self._batch_salt, self._draw, self._nes_draw = int(index_base), int(salt), 0, 0
+
+    def noise_seed(self, user_seed, draw):
+        return mix64(user_seed, self._noise_epoch, self._batch_salt, self._index_base, draw)
 
     def _stream(self):
         return N.current_stream_ptr(self.device)
+
+    def check_health(self):
+        """Raise NativeError if a kernel of an earlier launch flagged its own result as invalid (sg_health: a
+        stream-K hand-off wait that timed out).  No synchronisation: call it once the results were awaited."""
+        self.ctx.call("sg_health")
 
     def pgd_update(self, x, grad, lower, upper, step_size, grad_sign):
         """x <- min(max(x + step*sign(grad)*grad_sign, lower), upper) in place (attack/FGSM.py:65,68)."""
@@ -31,19 +71,20 @@ class EngineOps:
                       self._stream())
         return input_next, loss2
 
-    def nes_queries(self, x, half, with_clean, sigma, seed, pair_base, noise_in=None, want_noise=False):
+    def nes_queries(self, x, half, with_clean, sigma, seed, pair_base, noise_in=None, want_noise=False, index_base=0):
         """adaptive_attack/NES.py:19-25 -> queries (n*(2*half+with_clean), 1, T) [, noise (n, half, 1, T)]."""
         n, _, T = x.shape
         Q = 2 * half + int(with_clean)
         queries = torch.empty(n * Q, 1, T, device=x.device, dtype=torch.float32)
         noise = torch.empty(n, half, 1, T, device=x.device, dtype=torch.float32) if want_noise else None
-        self.ctx.call("sg_nes_queries", N._ptr(x), n, T, half, int(with_clean), float(sigma), C.c_uint64(seed), 0,
+        self.ctx.call("sg_nes_queries", N._ptr(x), n, T, half, int(with_clean), float(sigma), C.c_uint64(seed), int(index_base),
                       int(pair_base), N._ptr(noise_in), N._ptr(queries), N._ptr(noise), self._stream())
         return queries, noise
 
-    def nes_grad(self, loss, grad, n, T, half, with_clean, seed, pair_base, noise_in, accumulate, final_sigma, final_batches):
+    def nes_grad(self, loss, grad, n, T, half, with_clean, seed, pair_base, noise_in, accumulate, final_sigma, final_batches,
+                 index_base=0):
         """adaptive_attack/NES.py:47-54; accumulates into `grad` (n,1,T)."""
-        self.ctx.call("sg_nes_grad", N._ptr(loss), n, T, half, int(with_clean), C.c_uint64(seed), 0, int(pair_base),
+        self.ctx.call("sg_nes_grad", N._ptr(loss), n, T, half, int(with_clean), C.c_uint64(seed), int(index_base), int(pair_base),
                       N._ptr(noise_in), int(accumulate), float(final_sigma), int(final_batches), N._ptr(grad), self._stream())
         return grad
 

@@ -11,6 +11,9 @@ Differences a caller can observe, all deliberate:
     draws from the global torch RNG).  Default 1.0 like the reference; the noise comes from a
     counter-based generator keyed by ``dither_seed`` so runs are reproducible.  Use ``dither=0`` for
     bit-reproducible decisions.
+  * ``enroll_embs=`` of forward / score / make_decision is a per-call override exactly as in the reference
+    (iv_plda.py:155-165): the call scores against the given table, ``self.enroll_embs`` / ``num_spks`` and every
+    later call are unaffected (``sg_xv_enroll_override``: no allocation, no synchronisation).
   * gradients come from ``loss_grad`` (hand-coded backward), not from ``loss.backward()``;
     outputs of ``make_decision`` carry no autograd graph.
 """
@@ -162,7 +165,7 @@ class xv_plda(EngineOps):
     def _dither(self, noise=None):
         d = N.Dither()
         d.dither = self.dither
-        d.seed = (self.dither_seed * 0x9E3779B1 + self._draw) & 0xFFFFFFFFFFFFFFFF
+        d.seed = self.noise_seed(self.dither_seed, self._draw)  # chunk base is part of the seed, rows are chunk-local
         d.index_base = 0
         d.noise_dev = None if noise is None else noise.data_ptr()
         self._draw += 1  # every forward draws fresh noise, like the reference's global RNG
@@ -191,11 +194,15 @@ class xv_plda(EngineOps):
         else:
             self.ctx.call("sg_xv_set_enroll", None, self.num_spks, thr)
 
-    def _maybe_enroll(self, enroll_embs):
-        if enroll_embs is not None:
-            self.set_enroll(enroll_embs)
-        elif not self._has_enroll:
-            raise AssertionError("no enrolled speakers: pass enroll_embs (iv_plda.py:162-163)")
+    def _enroll_for_call(self, enroll_embs):
+        """Device table (S, D) for a per-call ``enroll_embs=`` override, or None for the model's own set."""
+        if enroll_embs is None:
+            if not self._has_enroll:
+                raise AssertionError("no enrolled speakers: pass enroll_embs (iv_plda.py:162-163)")
+            return None
+        if not isinstance(enroll_embs, torch.Tensor):
+            enroll_embs = torch.from_numpy(_f32(enroll_embs))
+        return enroll_embs.to(self.device, torch.float32).reshape(-1, self.dim).contiguous()
 
     # ------------------------------------------------------------------ reference API
     def compute_feat(self, x, flag=1, dither_noise=None):
@@ -251,23 +258,31 @@ class xv_plda(EngineOps):
     def cmvn(self, feats):
         return self.comput_feat_from_feat(feats)
 
-    def _forward(self, x, flag, want_emb=False, want_tdnn=False, dither_noise=None):
+    def _forward(self, x, flag, want_emb=False, want_tdnn=False, dither_noise=None, enroll=None):
         x, B, TF = self._prep(x, flag)
+        n_spk = self.num_spks if enroll is None else enroll.shape[0]
         dec = torch.empty(B, device=self.device, dtype=torch.int64)
-        scores = torch.empty(B, self.num_spks, device=self.device, dtype=torch.float32)
+        scores = torch.empty(B, n_spk, device=self.device, dtype=torch.float32)
         emb = torch.empty(B, self.dim, device=self.device, dtype=torch.float32) if want_emb else None
         temb = torch.empty(B, 512, device=self.device, dtype=torch.float32) if want_tdnn else None
         dz = self._dither(dither_noise)
-        self.ctx.call("sg_xv_forward", N._ptr(x), B, TF, flag, C.byref(dz), N._ptr(dec), N._ptr(scores), N._ptr(emb),
-                      N._ptr(temb), self._stream())
+        if enroll is not None:
+            self.ctx.call("sg_xv_enroll_override", N._ptr(enroll), enroll.shape[0])
+        try:
+            self.ctx.call("sg_xv_forward", N._ptr(x), B, TF, flag, C.byref(dz), N._ptr(dec), N._ptr(scores), N._ptr(emb),
+                          N._ptr(temb), self._stream())
+        finally:
+            if enroll is not None:
+                self.ctx.call("sg_xv_enroll_override", None, 0)
+                enroll.record_stream(torch.cuda.current_stream(self.device))  # the pass may still be reading it
         return dec, scores, emb, temb
 
     def embedding(self, x, flag=0):
         return self._forward(x, flag, want_emb=True)[2]
 
     def forward(self, x, flag=0, return_emb=False, enroll_embs=None):
-        self._maybe_enroll(enroll_embs)
-        _, scores, emb, _ = self._forward(x, flag, want_emb=return_emb)
+        enroll = self._enroll_for_call(enroll_embs)
+        _, scores, emb, _ = self._forward(x, flag, want_emb=return_emb, enroll=enroll)
         return (scores, emb) if return_emb else scores
 
     __call__ = forward
@@ -277,8 +292,8 @@ class xv_plda(EngineOps):
 
     def make_decision(self, x, flag=0, enroll_embs=None):
         """-> (decisions int64 (B,), scores (B, n_spk)); iv_plda.py:182-194."""
-        self._maybe_enroll(enroll_embs)
-        dec, scores, _, _ = self._forward(x, flag)
+        enroll = self._enroll_for_call(enroll_embs)
+        dec, scores, _, _ = self._forward(x, flag, enroll=enroll)
         return dec, scores
 
     def tdnn_activation(self, layer):

@@ -15,7 +15,11 @@ Batch-coupled details that are preserved by construction rather than by communic
   * CW2's early stop uses the mean loss of the chunk it is processing (attack/CW2.py:96-100); shards
     are cut on multiples of ``attacker.batch_size`` so chunks are the same ones the unsharded run uses;
   * random restarts draw the FULL (N,1,T) noise from the host RNG on every rank (seed all ranks
-    alike) and slice it, so the noise an utterance sees does not depend on the shard layout.
+    alike) and slice it, so the noise an utterance sees does not depend on the shard layout;
+  * device-generated noise (MFCC dither, NES queries) is keyed by (seed, attack call, restart, GLOBAL index of
+    the chunk's first utterance, pass number within the chunk) and the row within the chunk
+    (model/_engine_ops.py): a rank passes its shard offset as ``attacker.index_offset``, so a sharded run
+    draws exactly the noise of the unsharded run (tests/test_gpu_xv.py::test_device_noise_is_shard_invariant).
 
 Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
 """
@@ -61,8 +65,18 @@ class ShardedAttack:
 
     def _local_attack(self, x, y, lo, hi):
         a = self.attacker
+        a.index_offset = lo  # device-generated noise (dither, NES) is keyed by the GLOBAL chunk position
+        try:
+            return self._local_attack_at(x, y, lo, hi)
+        finally:
+            a.index_offset = 0
+
+    def _local_attack_at(self, x, y, lo, hi):
+        a = self.attacker
         restarts = getattr(a, "num_random_init", 0)
         if restarts and restarts > 0:
+            if hasattr(a, "_begin_attack"):
+                a._begin_attack()
             # PGD.attack (:48-77) with the best-of-restarts criterion evaluated on the whole batch
             world, _ = self._world()
             upper = torch.clamp(x + a.epsilon, max=1)
@@ -84,6 +98,9 @@ class ShardedAttack:
             return best
         if hi > lo:
             return a.attack(x[lo:hi], y[lo:hi])
+        base = getattr(getattr(a, "model", None), "base_model", getattr(a, "model", None))
+        if hasattr(base, "begin_attack"):  # an empty shard still counts the attack call: noise keys stay aligned over ranks
+            base.begin_attack()
         return x[lo:hi], []
 
     def attack(self, x, y):

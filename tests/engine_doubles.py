@@ -60,7 +60,7 @@ class AutogradEngine:
         nxt = torch.tanh(modifier + torch.atanh(x * 0.999999))
         return nxt, torch.sum(torch.square(nxt - x), dim=(1, 2))
 
-    def nes_queries(self, x, half, with_clean, sigma, seed, pair_base, noise_in=None, want_noise=False):
+    def nes_queries(self, x, half, with_clean, sigma, seed, pair_base, noise_in=None, want_noise=False, index_base=0):
         assert noise_in is not None, "the CPU double has no counter-based generator: pass noise_fn"
         noise = torch.cat((noise_in, -noise_in), 1)
         if with_clean:
@@ -68,7 +68,8 @@ class AutogradEngine:
         q = (noise * sigma + x.unsqueeze(1)).view(-1, x.shape[1], x.shape[2])
         return q, (noise_in if want_noise else None)
 
-    def nes_grad(self, loss, grad, n, T, half, with_clean, seed, pair_base, noise_in, accumulate, final_sigma, final_batches):
+    def nes_grad(self, loss, grad, n, T, half, with_clean, seed, pair_base, noise_in, accumulate, final_sigma, final_batches,
+                 index_base=0):
         l = loss[:, 1:] if with_clean else loss
         noise = torch.cat((noise_in, -noise_in), 1)
         g = torch.mean(l.unsqueeze(2).unsqueeze(3) * noise, 1)

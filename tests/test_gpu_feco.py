@@ -36,7 +36,9 @@ def test_kmeans_ids_bit_exact(hip_model):
     mfcc = hip_model.compute_feat(torch.from_numpy(synth.make_waveforms(3, 48000, seed=70)).to(DEV), flag=1).cpu()
     cases = [("mfcc 3x300x30", mfcc, 0.5), ("random 2x77x13", torch.from_numpy(rs.randn(2, 77, 13).astype(np.float32)), 0.3),
              ("logmel-like 2x300x32", torch.from_numpy((rs.randn(2, 300, 32) * 10 - 40).astype(np.float32)), 0.5),
-             ("duplicates", torch.from_numpy(np.repeat(rs.randn(1, 20, 8).astype(np.float32), 4, axis=1)), 0.5)]
+             ("duplicates", torch.from_numpy(np.repeat(rs.randn(1, 20, 8).astype(np.float32), 4, axis=1)), 0.5),
+             # 15 s utterance: frames + centroids exceed one block's LDS -> the frames-in-HBM form of the kernel
+             ("long 2x1500x30", torch.from_numpy((rs.randn(2, 1500, 30) * 3).astype(np.float32)), 0.5)]
     for name, feat, ratio in cases:
         _, ids, counts = _ids(feat, ratio)
         k = int(feat.shape[1] * ratio)
@@ -45,6 +47,13 @@ def test_kmeans_ids_bit_exact(hip_model):
             assert np.array_equal(ids[b], want), "%s utt %d: %d ids differ" % (name, b, (ids[b] != want).sum())
             assert np.array_equal(counts[b], np.bincount(want, minlength=k))
         log("FeCo k-means %s: ids bit-exact, empty clusters %d" % (name, int((counts == 0).sum())))
+
+
+def test_kmeans_refuses_what_does_not_fit():
+    from speakerguard_amd import _native as N
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    with pytest.raises(N.NativeError, match="too long"):
+        FeCoDefense(0.5).fwd(torch.zeros(1, 4000, 32, device=DEV))   # 2000 centroids x 32 dims = 256 KB > one block's LDS
 
 
 def test_compress_forward_backward_match_reference_step():

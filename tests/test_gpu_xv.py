@@ -198,6 +198,36 @@ def test_threshold_decisions_and_margin_variants(xv_weights, dev):
         np.testing.assert_allclose(loss.cpu().numpy(), g["margin_SV_%d" % targeted], rtol=1e-3, atol=5e-2)
 
 
+def test_enroll_embs_argument_is_a_per_call_override(xv_weights, oracle_model, dev):
+    """iv_plda.py:155-165: forward/score/make_decision(x, enroll_embs=e) score against e for THAT call only;
+    the model's enrolled set, num_spks and every later call are unchanged (it used to stick)."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.model.xv_plda import xv_plda
+    m = xv_plda.from_weights(xv_weights, device=dev, dither=0.0)
+    x = torch.from_numpy(synth.make_waveforms(3, 16000, seed=21)).to(dev)
+    dec0, sc0 = m.make_decision(x)
+    e = torch.from_numpy(xv_weights["enroll"][2:5].copy()).to(dev)       # three of the ten speakers, re-ordered set
+    sc_o = m.score(x, enroll_embs=e)
+    assert sc_o.shape == (3, 3)
+    np.testing.assert_array_equal(sc_o.cpu().numpy(), sc0[:, 2:5].cpu().numpy())   # same rows -> same scores, bit for bit
+    dec_o, _ = m.make_decision(x, enroll_embs=e)
+    assert dec_o.cpu().tolist() == sc0[:, 2:5].argmax(1).cpu().tolist()
+    with torch.no_grad():
+        o_sc = oracle_model.score(x.cpu(), enroll_embs=e.cpu())
+    np.testing.assert_allclose(sc_o.cpu().numpy(), o_sc.numpy(), rtol=2e-3, atol=0.2)
+    # nothing stuck
+    assert m.num_spks == 10 and m.enroll_embs.shape == (10, m.dim)
+    dec1, sc1 = m.make_decision(x)
+    assert dec1.cpu().tolist() == dec0.cpu().tolist()
+    np.testing.assert_array_equal(sc1.cpu().numpy(), sc0.cpu().numpy())
+    # set_enroll (the persistent form) re-uses / re-sizes the device table without leaking
+    for _ in range(3):
+        m.set_enroll(xv_weights["enroll"][:4])
+        assert m.make_decision(x)[1].shape == (3, 4)
+        m.set_enroll(xv_weights["enroll"])
+    np.testing.assert_array_equal(m.make_decision(x)[1].cpu().numpy(), sc0.cpu().numpy())
+
+
 @pytest.mark.parametrize("variant", ["osi_untargeted", "osi_targeted", "csi_targeted_margin", "sv_untargeted", "ce_targeted"])
 def test_loss_gradient_variants_match_oracle_autograd(xv_weights, dev, variant):
     """d loss / d features for every loss branch the tail kernel hand-codes (attack/utils.py:41-102)."""
@@ -592,6 +622,46 @@ def test_defended_model_passthrough_and_sharded_wrapper(hip_model, dev):
 
 
 # ------------------------------------------------------------------------------ native attack-state kernels
+def test_device_noise_is_shard_invariant(xv_weights, dev):
+    """SURVEY 8(e) / ADVICE r1: device-generated noise (MFCC dither, NES queries) is keyed by the chunk's GLOBAL
+    position, so attacking the two halves of a batch as two ranks would (attacker.index_offset = shard start, same
+    attack-call count) reproduces the unsharded run bit for bit."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.xv_plda import xv_plda
+    x = torch.from_numpy(synth.make_waveforms(4, 16000, seed=31)).to(dev)
+
+    def halves(make, model):
+        model._noise_epoch = 0
+        full = make().attack(x, y)
+        parts = []
+        for lo, hi in ((0, 2), (2, 4)):
+            model._noise_epoch = 0
+            atk = make()
+            atk.index_offset = lo
+            parts.append(atk.attack(x[lo:hi], y[lo:hi]))
+        return full, (torch.cat([p[0] for p in parts], 0), sum((list(p[1]) for p in parts), []))
+
+    # (1) PGD + EOT over random dither (the reference's default front-end, xv_plda.py:119)
+    md = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=5)
+    y = md.make_decision(x)[0]
+    full, sharded = halves(lambda: PGD(md, epsilon=0.002, step_size=0.0005, max_iter=2, batch_size=2, EOT_size=2,
+                                       EOT_batch_size=2, verbose=0), md)
+    assert torch.equal(full[0], sharded[0]) and list(full[1]) == sharded[1]
+    # different chunks really see different noise: utterance 0 attacked as "global utterance 2" moves differently
+    md._noise_epoch = 0
+    shifted = PGD(md, epsilon=0.002, step_size=0.0005, max_iter=2, batch_size=2, EOT_size=2, EOT_batch_size=2, verbose=0)
+    shifted.index_offset = 2
+    assert not torch.equal(shifted.attack(x[0:2], y[0:2])[0], full[0][0:2])
+    # (2) FAKEBOB with the engine's own NES noise (counter-based generator), deterministic front-end
+    m0 = xv_plda.from_weights(xv_weights, device=dev, dither=0.0)
+    full, sharded = halves(lambda: FAKEBOB(m0, task="CSI", epsilon=0.002, max_iter=2, samples_per_draw=4,
+                                           samples_per_draw_batch_size=4, batch_size=2, verbose=0), m0)
+    assert torch.equal(full[0], sharded[0]) and list(full[1]) == sharded[1]
+    log("device noise (dither + NES) shard-invariant: halves == full batch bit for bit")
+
+
 def test_cw2_step_kernel_matches_torch_adam(hip_model, dev):
     """sg_cw2_step vs torch.tanh/atanh + torch.optim.Adam on the same numbers (CW2.py:72-82)."""
     g = torch.Generator().manual_seed(2)
