@@ -1,11 +1,14 @@
 """AudioNet CSI-NE (log-mel front-end + 1-D CNN), restated on PyTorch-CPU fp32.  TEST INFRASTRUCTURE.
 
-PARITY UNPINNED.  Follows reference model/_audionet/Preprocessor.py:85-112 and
-model/audionet_csine.py:66-118,176-257, but nothing executable pins it: the reference class cannot
-be constructed here (``Preprocessor.__init__`` calls ``librosa.filters.mel`` -- librosa==0.8.0,
-README.md:56, not installed -- and ``torch.stft`` without ``return_complex`` raises on torch 2.10),
-and the reference holds no test or golden vector for it.  The mel basis restates the published
-librosa 0.8.0 algorithm (Slaney scale, ``norm='slaney'``, fmin 0, fmax sr/2).
+PINNED (round 2) against the reference's own code with two disclosed harness accommodations: tests/golden/an_ref.npz
+holds outputs of reference model/audionet_csine.py + model/_audionet/Preprocessor.py + attack/utils.py executed
+unmodified by tests/golden/make_golden_frontends.py, where (a) the uninstalled ``librosa.filters.mel`` (librosa==0.8.0,
+README.md:56) is supplied by the third-party ``transformers.audio_utils.mel_filter_bank(norm='slaney',
+mel_scale='slaney')`` and (b) ``torch.stft`` called without ``return_complex`` (Preprocessor.py:100-105, an error on
+torch >= 2) gets the pre-1.8 real-view return.  This file reproduces that run exactly (max abs difference 0.0 on
+log-mel, logits, loss and both gradients; tests/test_oracle_frontends.py).  What remains outside the reference's own
+arithmetic is the mel basis itself, which restates the published librosa 0.8.0 algorithm (Slaney scale,
+``norm='slaney'``, fmin 0, fmax sr/2) and agrees with the third-party one to 5e-10.
 """
 import numpy as np
 import torch

@@ -6,7 +6,14 @@ dependency that is neither vendored under /root/reference nor installed in this 
 file restates that published algorithm (Kaldi ``feature-window`` / ``feature-mfcc`` /
 ``mel-computations`` as torchaudio/compliance/kaldi.py v0.6.0 implements them) with exactly the
 keyword values of the reference call site.  The reference repo holds no test or golden vector
-for this boundary, so nothing pins it.
+for this boundary, so nothing OF THE REFERENCE pins it.
+
+Corroboration (round 2, not a pin): an independent implementation of the same specification --
+``transformers.audio_utils`` (its numpy stand-in for ``torchaudio.compliance.kaldi.fbank``) +
+``scipy.fft.dct`` -- agrees with this file to 9e-6 on the log-mel energies and 3e-4 on cepstra up
+to 40 (the latter is torchaudio's own fp32 table rounding); vectors in
+tests/golden/frontend_xcheck.npz, checked by tests/test_oracle_frontends.py.  Still restated only:
+the snip_edges=False reflect padding, c0 <- log raw energy, the lifter.
 
 Everything is differentiable torch so that ``torch.autograd`` of this file is the checker for
 the hand-written HIP backward.

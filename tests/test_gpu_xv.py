@@ -69,6 +69,23 @@ def test_mfcc_matches_oracle(hip_model, dev, T):
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=5e-3)
 
 
+@pytest.mark.parametrize("tag", ["t48000", "t16123"])
+def test_mfcc_matches_independent_implementation(hip_model, dev, tag):
+    """HIP MFCC vs vectors from an INDEPENDENT implementation of torchaudio's Kaldi front-end (transformers.audio_utils
+    + scipy DCT, tests/golden/frontend_xcheck.npz) -- the reference's own torchaudio==0.6.0 is not installable."""
+    import hashlib
+    from speakerguard_amd import synth
+    g = load_golden("frontend_xcheck.npz")
+    T, seed = (int(v) for v in g[tag + "_gen"])
+    x = synth.make_waveforms(1, T, seed=seed)
+    assert hashlib.sha256((x[0, 0] * 32768.0).astype(np.float32).tobytes()).hexdigest() == str(g[tag + "_x_sha256"])
+    got = hip_model.compute_feat(torch.from_numpy(x).to(dev), flag=1).cpu().numpy()[0]
+    want = g[tag + "_mfcc"]
+    err = np.abs(got - want).max()
+    log("mfcc vs independent implementation (%s): max abs err %.3e (values up to %.1f)" % (tag, err, np.abs(want).max()))
+    assert got.shape == want.shape and err < 1e-3   # fp32 table rounding alone: 3e-4 (DESIGN.md section 2, trap 1)
+
+
 def test_mfcc_int16_range_left_alone(hip_model, dev):
     """check_input_range: a batch already in int16 scale is NOT multiplied again (model/utils.py:11)."""
     from oracle import kaldi_mfcc
