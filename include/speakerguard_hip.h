@@ -206,14 +206,17 @@ typedef struct sg_pgd_params {
     float step_size;
     int32_t max_iter;
     int32_t grad_sign;       /* attack/utils.py:114 */
-    int32_t eot_size;        /* EOT_size / EOT_batch_size (EOT.py); repeats draw fresh dither */
-    int32_t eot_batch_size;
+    int32_t eot_size;        /* EOT.py:16-54: passes per gradient step, each with fresh dither (key = dither.seed +
+                              * step * 0x9E3779B97F4A7C15 + repeat * 0xC2B2AE3D27D4EB4F); their data gradients are summed
+                              * in pass order before the sign step.  With dither == 0 all repeats coincide: one pass. */
+    int32_t eot_batch_size;  /* how the reference groups the repeats into model calls; must divide eot_size */
     sg_dither dither;
 } sg_pgd_params;
 
 /* x_adv (B,T) dev: in = start point, out = adversarial audio; lower/upper (B,T) dev.
- * success (B) uint8, decisions (B) int64, scores (B,S), loss (B): state at the final pass.
- * loss_trace ((max_iter+1)*B) / decision_trace ((max_iter+1)*B) optional per-pass records. */
+ * success (B) uint8, decisions (B) int64, scores (B,S), loss (B): state at the final pass (a single forward,
+ * FGSM.py:45-47).  loss_trace ((max_iter+1)*B) / decision_trace ((max_iter+1)*B): optional per-step records (of the
+ * step's first EOT repeat). */
 int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev,
                   const float* upper_dev, int32_t B, int32_t T, const sg_pgd_params* params,
                   uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev, float* loss_dev,

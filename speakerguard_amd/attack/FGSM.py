@@ -1,8 +1,8 @@
 """FGSM and the shared PGD inner loop; mirrors reference attack/FGSM.py.
 
 ``attack_batch`` is the hot loop (FGSM.py:38-70).  When the model is the native x-vector engine
-and nothing between attack and model needs Python (no defense wrapper, EOT repeats that would
-all be identical), the whole loop -- max_iter x (forward, hand-coded backward, sign step,
+and nothing between attack and model needs Python (no defense wrapper), the whole loop, EOT repeats
+over the front-end's random dither included -- max_iter x (forward, hand-coded backward, sign step,
 projection) + the final forward-only pass -- is ONE C-ABI call (``model.pgd_run``).  Otherwise
 the same loop runs step by step over ``model.loss_grad`` / ``model.pgd_update``.
 """
@@ -50,16 +50,15 @@ class FGSM(Attack):
         if getattr(m, 'defense', None) is not None:
             return False
         base = getattr(m, 'base_model', m)
-        if not hasattr(base, 'pgd_run'):
-            return False
-        # EOT repeats of a deterministic model are identical; with dither they are not
-        return self.EOT_size == 1 or getattr(base, 'dither', 0.0) == 0.0
+        # EOT repeats of a deterministic model are identical (one pass stands for all of them); with random dither
+        # the engine runs the repeats itself and sums their gradients on the device
+        return hasattr(base, 'pgd_run')
 
     def _attack_batch_fused(self, x_batch, y_batch, lower, upper, batch_id):
         base = getattr(self.model, 'base_model', self.model)
         x_adv, success, dec, scores, loss, ltr, dtr = base.pgd_run(
             x_batch, y_batch, lower, upper, self.loss, self.step_size, self.max_iter, self.grad_sign,
-            1, 1, trace=bool(self.verbose))
+            self.EOT_size, self.EOT_batch_size, trace=bool(self.verbose))
         if self.verbose:
             ltr, dtr = ltr.cpu().numpy(), dtr.cpu().numpy()
             target = y_batch.detach().cpu().numpy()

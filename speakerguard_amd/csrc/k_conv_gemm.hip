@@ -35,6 +35,7 @@ namespace sg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 
@@ -330,7 +331,7 @@ __device__ __forceinline__ void gemm_segment8(const ConvGemmArgs& p, float* smem
 // tile, 96 KB (one block owns the CU).  Every wave computes 64 x 32.
 template <int WMW>
 __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
-                                               int c_end, f32x16 (&acc)[2][1]) {
+                                               int c_end, f32x16 (&acc)[2][1], unsigned long long* tr = nullptr) {
     constexpr int BM = 64 * WMW, BN = 128;
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;   // floats per LDS stage
     constexpr int ROLE_T = 128 * WMW;                     // threads per staging role
@@ -428,10 +429,12 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
     };
     if (c_begin < c_end) {
         load_chunk();
+        if (tr && threadIdx.x == 0) tr[7] = __builtin_amdgcn_s_memrealtime();   // first loads issued
         store_chunk(st_ptr0);
         if (c_begin + 1 < c_end) load_chunk();
     }
     __syncthreads();
+    if (tr && threadIdx.x == 0) tr[13] = __builtin_amdgcn_s_memrealtime();       // prologue done
     // Per-lane LDS read pointers are fixed for the whole segment (one per k-group, the XOR swizzle folded in);
     // the stage offset is a compile-time constant of the body below, so it lands in the ds_read / ds_write
     // immediate and a chunk issues no address VALU at all (every VALU instruction costs matrix-pipe cycles).
@@ -482,6 +485,7 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
     for (; c + 1 < c_end; c += 2) {
         chunk(c, std::integral_constant<int, 0>{});
         chunk(c + 1, std::integral_constant<int, 1>{});
+        if (tr && threadIdx.x == 0 && c == c_begin) tr[14] = __builtin_amdgcn_s_memrealtime();  // two chunks done
     }
     if (c < c_end) chunk(c, std::integral_constant<int, 0>{});
 }
@@ -810,14 +814,22 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
     const long it_begin = (long)w * iters_per_worker;
     const long it_end = min(total, it_begin + iters_per_worker);
     if (it_begin >= it_end) return;
-    float* my_slab = slabs + (size_t)w * BM * BN;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     f32x16 acc[MI][NI];
-    auto segment = [&](int m0, int n0, int c0, int c1) {
+    auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) {
         if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
-        else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc);
+        else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc, tr);
     };
-    auto frag = [&](int mi, int ni, int e) { return (((wid * MI + mi) * NI + ni) * 16 + e) * 64 + lane; };
+    // Parked accumulators travel as 16-byte pieces: piece q of fragment (mi, ni) of wave wid, lane-interleaved, so
+    // a wave's store/load instruction covers 1 KB contiguous.  Stores and loads are write-through / L1-bypassing
+    // (sc1) raw buffer accesses: no release fence (which would write back every dirty line of the XCD's L2, i.e.
+    // the previous layer's output) and no acquire fence are needed around them -- cdna guide G16 R1, price list
+    // "publish-large": 3.0 vs 8.2 us per 64 KB published.
+    const __amdgpu_buffer_rsrc_t slab_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)min((size_t)gridDim.x * BM * BN * sizeof(float), (size_t)0x7FFFFFFF), 0x00020000);
+    auto piece_off = [&](int wk, int mi, int ni, int q) {
+        return (unsigned)((((size_t)wk * (BM * BN / 4)) + ((((wid * MI + mi) * NI + ni) * 4 + q) * 64 + lane)) * 16);
+    };
 
     const int first_tile = (int)(it_begin / C), first_c0 = (int)(it_begin % C);
     const int last_tile = (int)((it_end - 1) / C), last_c1 = (int)((it_end - 1) % C) + 1;
@@ -856,12 +868,13 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) my_slab[frag(mi, ni, e)] = acc[mi][ni][e];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), slab_rsrc, piece_off(w, mi, ni, q), 0, 16);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores ...
+        __syncthreads();                                   // ... before ONE lane publishes the flag
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // (ablate bit 8 = fault injection for tests/test_gpu_conv.py: the flag is never published)
             if (!(p.ablate & 8)) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -896,20 +909,22 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
         SG_STAMP(9)
-        const float* slab = slabs + (size_t)(w - 1) * BM * BN;
+        // the slab was stored write-through (sc1) before the flag; sc1 loads bypass this CU's L1, so no acquire fence
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = slab[frag(mi, ni, e)];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, piece_off(w - 1, mi, ni, q), 0, 16));
+                    acc[mi][ni][4 * q] = v.x; acc[mi][ni][4 * q + 1] = v.y; acc[mi][ni][4 * q + 2] = v.z; acc[mi][ni][4 * q + 3] = v.w;
+                }
         const int c1 = first_tile == last_tile ? last_c1 : C;  // (host guarantees == C, see launcher)
         SG_STAMP(10)
-        segment(m0, n0, first_c0, c1);
+        segment(m0, n0, first_c0, c1, p.trace ? p.trace + (size_t)w * 16 : nullptr);
         SG_STAMP(11)
         tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
         SG_STAMP(12)

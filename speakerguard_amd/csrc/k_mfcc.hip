@@ -395,9 +395,10 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
 // position that maps to it -- directly, or through the reflected edges of _get_strided.
 // Optionally fuses the PGD step (attack/FGSM.py:65,68) so the gradient never round-trips HBM.
 __global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __restrict__ dframes, int B, int T, int F,
-                                                             float* __restrict__ grad_out, float* __restrict__ x_io,
+                                                             const float* acc_in, float* grad_out, float* __restrict__ x_io,
                                                              const float* __restrict__ lower,
                                                              const float* __restrict__ upper, float step, int grad_sign) {
+    // acc_in (may alias grad_out): gradient accumulated over the earlier EOT repeats of this step (EOT.py:41-47)
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= T) return;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __rest
     const int pr = 2 * T - 1 - n;
     if (pr <= (F - 1) * kShift - kPad + kWin - 1) add_pos(pr);
     const size_t o = (size_t)b * T + n;
+    if (acc_in) g = acc_in[o] + g;
     if (grad_out) grad_out[o] = g;
     if (x_io) {
         const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
@@ -444,11 +446,11 @@ hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, in
     return hipGetLastError();
 }
 
-hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, float* grad_out, float* x_io,
+hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, const float* acc_in, float* grad_out, float* x_io,
                                  const float* lower, const float* upper, float step, int grad_sign,
                                  hipStream_t s) {
     dim3 grid((T + 255) / 256, B);
-    hipLaunchKernelGGL(frames_to_wave_kernel, grid, dim3(256), 0, s, dframes, B, T, F, grad_out, x_io, lower, upper,
+    hipLaunchKernelGGL(frames_to_wave_kernel, grid, dim3(256), 0, s, dframes, B, T, F, acc_in, grad_out, x_io, lower, upper,
                        step, grad_sign);
     return hipGetLastError();
 }

@@ -389,7 +389,7 @@ int check_dims(sg_ctx* ctx, int B, int TF, int flag, PassDims* d) {
 // after the tail produced ws.demb: chain back to the caller's input level
 int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz,
                           float* grad_out, float* x_update, const float* lower, const float* upper, float step,
-                          int grad_sign, hipStream_t s) {
+                          int grad_sign, hipStream_t s, const float* grad_acc_in = nullptr) {
     Workspace& w = ctx->ws;
     int rc = run_tdnn_backward(ctx, d, s);
     if (rc) return rc;
@@ -412,7 +412,7 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
             tab.mel_cache = w.mel_cache;
         }
         SG_HIP(launch_mfcc_bwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
-        SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_out, x_update, lower, upper, step, grad_sign, s));
+        SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_acc_in, grad_out, x_update, lower, upper, step, grad_sign, s));
     }
     return SG_OK;
 }
@@ -665,7 +665,7 @@ int sg_xv_mfcc_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, c
     hipStream_t s = (hipStream_t)stream;
     Workspace& w = ctx->ws;
     SG_HIP(launch_mfcc_bwd(ctx->tab, x_dev, d.B, d.T, d.F, scale_dev, dither, dfeats_dev, w.dframes, s));
-    SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
+    SG_HIP(launch_frames_to_wave(w.dframes, d.B, d.T, d.F, nullptr, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
     return SG_OK;
 }
 
@@ -789,35 +789,44 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     if (p->max_iter < 0) return fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
     const int eot_size = p->eot_size > 0 ? p->eot_size : 1, eot_bs = p->eot_batch_size > 0 ? p->eot_batch_size : 1;
     if (eot_size % eot_bs) return fail(ctx, SG_ERR_ARG, "EOT size should be divisible by EOT batch size");
-    // Without dither the model is deterministic, every EOT repeat is the same computation and their
-    // mean is the single-pass result; repeats are only materialised when they differ.
-    if (eot_size > 1 && p->dither.dither != 0.f)
-        return fail(ctx, SG_ERR_ARG, "EOT over random dither inside the fused loop is not implemented; use the per-step API");
+    // Expectation over the front-end's random dither (adaptive_attack/EOT.py:16-54; the reference hard-codes
+    // dither = 1.0 at xv_plda.py:119, so this IS its default behaviour): every gradient step runs eot_size passes
+    // with fresh noise, the data gradients are summed in pass order and the sign step is taken on the sum
+    // (sign(mean) == sign(sum); the EOT_batch_size grouping only changes how the reference batches the repeats).
+    // The final pass of the attack is a single forward (FGSM.py:45-47).  Without dither the model is
+    // deterministic, every repeat is the same computation and their mean is the single-pass result: one pass.
+    const int reps = p->dither.dither != 0.f ? eot_size : 1;
     hipStream_t s = (hipStream_t)stream;
     Workspace& w = ctx->ws;
     for (int it = 0; it <= p->max_iter; ++it) {
         const bool last = it == p->max_iter;
-        sg_dither dz = p->dither;
-        dz.seed += (uint64_t)it * 0x9E3779B97F4A7C15ull;
-        // every iterate is clamped into [lower, upper] within [-1, 1], so check_input_range takes the
-        // same branch as for the start point: decide once
-        d.keep_scale = it > 0;
-        if ((rc = run_frontend(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, s))) return rc;
-        if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
-        TailArgs t{};
-        t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = y_dev; t.loss = p->loss;
-        t.want_grad = !last; t.demb = w.demb;
-        t.scores = last ? scores_dev : nullptr;
-        t.decisions = last ? decisions_dev : nullptr;
-        t.loss_out = last ? loss_dev : nullptr;
-        t.success = last ? success_dev : nullptr;
-        t.loss_trace = loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr;
-        t.decision_trace = decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr;
-        SG_HIP(launch_tail(t, s));
-        if (!last) {
-            rc = run_backward_to_input(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, nullptr, x_adv_dev, lower_dev, upper_dev,
-                                       p->step_size, p->grad_sign, s);
-            if (rc) return rc;
+        const int nrep = last ? 1 : reps;
+        for (int r = 0; r < nrep; ++r) {
+            sg_dither dz = p->dither;
+            dz.seed += (uint64_t)it * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xC2B2AE3D27D4EB4Full;
+            // every iterate is clamped into [lower, upper] within [-1, 1], so check_input_range takes the
+            // same branch as for the start point: decide once
+            d.keep_scale = it > 0 || r > 0;
+            if ((rc = run_frontend(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, s))) return rc;
+            if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
+            TailArgs t{};
+            t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = y_dev; t.loss = p->loss;
+            t.want_grad = !last; t.demb = w.demb;
+            t.scores = last ? scores_dev : nullptr;
+            t.decisions = last ? decisions_dev : nullptr;
+            t.loss_out = last ? loss_dev : nullptr;
+            t.success = last ? success_dev : nullptr;
+            // per-pass records (verbose printing): those of the step's first repeat
+            t.loss_trace = loss_trace_dev && r == 0 ? loss_trace_dev + (size_t)it * B : nullptr;
+            t.decision_trace = decision_trace_dev && r == 0 ? decision_trace_dev + (size_t)it * B : nullptr;
+            SG_HIP(launch_tail(t, s));
+            if (!last) {
+                const bool final_rep = r == nrep - 1;
+                rc = run_backward_to_input(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, final_rep ? nullptr : w.grad,
+                                           final_rep ? x_adv_dev : nullptr, lower_dev, upper_dev, p->step_size, p->grad_sign, s,
+                                           r > 0 ? w.grad : nullptr);
+                if (rc) return rc;
+            }
         }
     }
     return SG_OK;

@@ -238,8 +238,9 @@ hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, in
                            const sg_dither* dz, float* feats, hipStream_t s);
 hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, const float* dfeats, float* dframes, hipStream_t s);
-// overlap-add of dframes into d loss / d x; optional fused PGD update of x (in place)
-hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, float* grad_out, float* x_io,
+// overlap-add of dframes into d loss / d x (+ acc_in, the sum over earlier EOT repeats; may alias grad_out);
+// optional fused PGD update of x (in place)
+hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, const float* acc_in, float* grad_out, float* x_io,
                                  const float* lower, const float* upper, float step, int grad_sign,
                                  hipStream_t s);
 hipError_t launch_pgd_update(float* x, const float* g, const float* lo, const float* hi, int64_t n,

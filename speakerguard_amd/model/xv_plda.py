@@ -162,14 +162,22 @@ class xv_plda(EngineOps):
             raise N.NativeError("the engine context is bound to %s" % self.device)
         return self
 
-    def _dither(self, noise=None):
+    def _dither(self, noise=None, seed=None):
         d = N.Dither()
         d.dither = self.dither
-        d.seed = self.noise_seed(self.dither_seed, self._draw)  # chunk base is part of the seed, rows are chunk-local
         d.index_base = 0
         d.noise_dev = None if noise is None else noise.data_ptr()
+        if seed is not None:  # explicit generator key (tests re-play the fused loop's per-pass seeds)
+            d.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            return d
+        d.seed = self.noise_seed(self.dither_seed, self._draw)  # chunk base is part of the seed, rows are chunk-local
         self._draw += 1  # every forward draws fresh noise, like the reference's global RNG
         return d
+
+    # per-pass generator keys of the fused loop (sg_xv_pgd_run): step `it`, EOT repeat `r`
+    @staticmethod
+    def fused_pass_seed(base_seed, it, r=0):
+        return (int(base_seed) + it * 0x9E3779B97F4A7C15 + r * 0xC2B2AE3D27D4EB4F) & 0xFFFFFFFFFFFFFFFF
 
     def _prep(self, x, flag):
         assert flag in self.allowed_flags
@@ -309,7 +317,7 @@ class xv_plda(EngineOps):
         return out
 
     # ------------------------------------------------------------------ engine protocol used by attack.*
-    def loss_grad(self, x, y, loss_spec, flag=0, want_grad=True, dither_noise=None):
+    def loss_grad(self, x, y, loss_spec, flag=0, want_grad=True, dither_noise=None, dither_seed=None):
         """make_decision + per-example loss + d loss / d x in one native call (replaces EOT.py:32-35).
 
         Returns (decisions, scores, loss, grad) with grad shaped like x (None if want_grad=False).
@@ -320,7 +328,7 @@ class xv_plda(EngineOps):
         scores = torch.empty(B, self.num_spks, device=self.device, dtype=torch.float32)
         loss = torch.empty(B, device=self.device, dtype=torch.float32)
         grad = torch.empty_like(x) if want_grad else None
-        dz = self._dither(dither_noise)
+        dz = self._dither(dither_noise, dither_seed)
         spec = loss_spec.native()
         self.ctx.call("sg_xv_loss_grad", N._ptr(x), N._ptr(y), B, TF, flag, C.byref(spec), C.byref(dz), N._ptr(dec),
                       N._ptr(scores), N._ptr(loss), N._ptr(grad), self._stream())
@@ -328,7 +336,9 @@ class xv_plda(EngineOps):
 
     def pgd_run(self, x, y, lower, upper, loss_spec, step_size, max_iter, grad_sign, eot_size=1, eot_batch_size=1,
                 trace=False):
-        """attack/FGSM.py:38-70 attack_batch as one device-resident loop."""
+        """attack/FGSM.py:38-70 attack_batch as one device-resident loop, including EOT over the front-end's random
+        dither (eot_size fresh-noise passes per gradient step, gradients summed on the device; the traces record each
+        step's first pass)."""
         x, B, T = self._prep(x, 0)
         x_adv = x.clone()
         y = y.to(self.device, torch.int64).contiguous()
@@ -339,6 +349,7 @@ class xv_plda(EngineOps):
         p.step_size, p.max_iter, p.grad_sign = float(step_size), int(max_iter), int(grad_sign)
         p.eot_size, p.eot_batch_size = int(eot_size), int(eot_batch_size)
         p.dither = self._dither()
+        self.last_fused_seed = int(p.dither.seed)
         success = torch.empty(B, device=self.device, dtype=torch.uint8)
         dec = torch.empty(B, device=self.device, dtype=torch.int64)
         scores = torch.empty(B, self.num_spks, device=self.device, dtype=torch.float32)

@@ -381,6 +381,49 @@ def test_fused_loop_equals_stepwise_calls(hip_model, dev):
     assert success.bool().tolist() == (dec != y).tolist()
 
 
+def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev):
+    """The reference's default front-end is random (dither = 1.0, xv_plda.py:119) and EOT averages its gradient over
+    fresh draws (EOT.py:16-54).  The fused loop runs those repeats on the device; replaying its per-pass generator
+    keys through the per-step API (loss_grad with an explicit key, gradients summed in pass order by torch, then
+    sg_pgd_update) must give the same audio bit for bit, and the final single-pass decisions."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.xv_plda import xv_plda
+    m = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=11)
+    x = torch.from_numpy(synth.make_waveforms(3, 24000, seed=26)).to(dev)
+    y = m.make_decision(x)[0]
+    lower, upper = torch.clamp(x - 0.002, min=-1), torch.clamp(x + 0.002, max=1)
+    spec = SEC4SR_CrossEntropy()
+    iters, reps = 3, 4
+    xa, success, dec, scores, loss, _, _ = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2)
+    base = m.last_fused_seed
+    xb = x.clone()
+    grads = []
+    for it in range(iters):
+        acc = None
+        for r in range(reps):
+            _, _, _, g = m.loss_grad(xb, y, spec, dither_seed=m.fused_pass_seed(base, it, r))
+            grads.append(g)
+            acc = g if acc is None else acc + g
+        m.pgd_update(xb, acc.contiguous(), lower, upper, 0.0004, 1)
+    d2, s2, l2, _ = m.loss_grad(xb, y, spec, want_grad=False, dither_seed=m.fused_pass_seed(base, iters, 0))
+    assert torch.equal(xa, xb)
+    assert torch.equal(dec, d2) and torch.equal(scores, s2) and torch.equal(loss, l2)
+    assert success.bool().tolist() == (dec != y).tolist()
+    # the repeats really are different draws, and EOT changes the trajectory
+    assert not torch.equal(grads[0], grads[1])
+    x1 = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=1)[0]
+    assert not torch.equal(x1, xa)
+    # host class: PGD(EOT_size=4) on a dithered model takes the fused path and respects the epsilon ball
+    from speakerguard_amd.attack.PGD import PGD
+    atk = PGD(m, epsilon=0.002, step_size=0.0004, max_iter=iters, batch_size=3, EOT_size=reps, EOT_batch_size=2, verbose=0)
+    assert atk._can_fuse()
+    adv, succ = atk.attack(x, y)
+    assert (adv - x).abs().max().item() <= 0.002 + 1e-7 and len(succ) == 3
+    frac = float(((xa - x).abs() > 0).float().mean())
+    log("fused EOT(%d) over dither: equals the stepwise replay bit for bit; %.1f%% of samples moved" % (reps, 100 * frac))
+
+
 @pytest.mark.parametrize("loss_name,targeted", [("Entropy", False), ("Margin", False), ("Entropy", True)])
 def test_pgd_attack_matches_oracle(hip_model, oracle_model, dev, loss_name, targeted):
     from oracle import attacks as oatk

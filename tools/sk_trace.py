@@ -35,7 +35,7 @@ pairs = [v for v in by_place.values() if len(v) == 2]
 d = [abs(a - b) for a, b in pairs]
 print("worker-index distance of co-resident pairs: %s" % Counter(d).most_common(6))
 print("xcc of workers 0..15:", xcc[:16].tolist(), " workers 60..70:", xcc[60:70].tolist())
-ts = t[:, :13].astype(np.float64) * 0.01  # us
+ts = t[:, :15].astype(np.float64) * 0.01  # us
 # the 100 MHz counters of different XCDs are not aligned: normalise per XCD
 for x in range(8):
     sel = xcc == x
@@ -75,6 +75,10 @@ rep("whole tile 1 epilogue", 5, 6)
 rep("flag wait + acquire", 8, 9)
 rep("slab read", 9, 10)
 rep("tail piece compute", 10, 11, (C - first_c0).astype(float))
+rep("  tail: setup -> loads issued", 10, 7)
+rep("  tail: loads issued -> prologue done", 7, 13)
+rep("  tail: first two chunks", 13, 14)
+rep("  tail: remaining chunks", 14, 11, (C - first_c0 - 2).astype(float))
 rep("tail epilogue", 11, 12)
 print()
 print("busy time by XCD (median / max us):", ["%d: %.0f/%.0f" % (x, np.nanmedian(busy[xcc == x]), np.nanmax(busy[xcc == x])) for x in range(8) if (xcc == x).any()])
