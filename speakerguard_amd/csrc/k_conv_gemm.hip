@@ -789,12 +789,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int
 // else, so a waiter never waits on work that depends on it (spins are bounded regardless).  Hand-off = agent-scope release/acquire on one flag
 // per worker (cdna guide G16).  A flag holds the EPOCH of the launch that parked the slab (a process-wide
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
-// KIND 0: 8 waves, b32-fed 128x128 (no packed weights); 1: 8 waves, quad-fed 128x128; 2: 16 waves, quad-fed 256x128.
+// KIND 0: 8 waves, b32-fed 128x128 (no packed weights); 1: 8 waves, quad-fed 128x128; 2: 16 waves, quad-fed 256x128;
+// 3: 4 waves, quad-fed 64x128 (small batches: one block per CU).
 template <int EPI, int KIND>
-__global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+__global__ __launch_bounds__(KIND == 2 ? 1024 : KIND == 3 ? 256 : 512, KIND == 3 ? 1 : 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                                       int iters_per_worker, float* slabs,
                                                                                       unsigned* flags, unsigned epoch) {
-    constexpr int WM = KIND == 2 ? 4 : 2, WN = 4;
+    constexpr int WM = KIND == 2 ? 4 : KIND == 3 ? 1 : 2, WN = 4;
     constexpr int BM = 64 * WM, BN = 128;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 fragments per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BK * (BM + BN) floats
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : 512, 4) void conv_gemm_streamk_k
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) {
         if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (KIND == 3) gemm_segment_q1(p, smem, m0, n0, c0, c1, acc);
         else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc, tr);
     };
     // Parked accumulators travel as 16-byte pieces: piece q of fragment (mi, ni) of wave wid, lane-interleaved, so
@@ -974,7 +976,8 @@ static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
 template <int EPI, int KIND>
 static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, int tiles, int ipw, float* slabs,
                                 unsigned* flags, unsigned epoch, hipStream_t s) {
-    constexpr int bm = KIND == 2 ? 256 : 128;
+    constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : 128;
+    constexpr int threads = KIND == 2 ? 1024 : KIND == 3 ? 256 : 512;
     constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
     // per device: remember for which devices the > 64 KB dynamic-LDS opt-in has been made (a process may hold one
     // sg_ctx per GPU)
@@ -987,7 +990,7 @@ static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, KIND>), dim3(workers), dim3(KIND == 2 ? 1024 : 512), lds, s, a, ntiles,
+    hipLaunchKernelGGL((conv_gemm_streamk_kernel<EPI, KIND>), dim3(workers), dim3(threads), lds, s, a, ntiles,
                        tiles, ipw, slabs, flags, epoch);
 }
 
@@ -996,13 +999,13 @@ static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, 
 template <int KIND>
 static int streamk_blocks_per_cu() {
     static const int n = [] {
-        constexpr int bm = KIND == 2 ? 256 : 128;
+        constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : 128;
         constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
         const void* fn = reinterpret_cast<const void*>(conv_gemm_streamk_kernel<EPI_NONE, KIND>);
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_streamk_kernel<EPI_NONE, KIND>, KIND == 2 ? 1024 : 512,
-                                                         lds) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_streamk_kernel<EPI_NONE, KIND>,
+                                                         KIND == 2 ? 1024 : KIND == 3 ? 256 : 512, lds) != hipSuccess)
             nb = 0;
         return nb;
     }();
@@ -1015,10 +1018,30 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         const char* e = getenv("SG_STREAMK_W16");  // 0 = two 8-wave 128x128 blocks per CU
         return e ? atoi(e) : 1;
     }();
-    const int kind = !a.Wq ? 0 : ((w16 && a.force != 3) ? 2 : 1);
+    int kind = !a.Wq ? 0 : ((w16 && a.force != 3) ? 2 : 1);
     // one worker per resident slot of this device (slabs / flags are sized for 256 CUs)
     const int cus = a.num_cus > 0 && a.num_cus < 256 ? a.num_cus : 256;
-    const int bm = kind == 2 ? 256 : 128, workers = kind == 2 ? cus : 2 * cus;
+    int bm = kind == 2 ? 256 : 128, workers = kind == 2 ? cus : 2 * cus;
+    // Medium batches (B = 32 at 3 s: 136 tiles of 256 rows for 256 CUs): fewer 256-row tiles than CUs would leave the
+    // persistent launch to the 4-wave tile kernel at ~100 TFLOP/s.  128-row tiles still give every CU one: run the
+    // 8-wave 128x128 kernel with ONE block per CU (2 waves per SIMD; the CU's MFMA rate is what a lone block needs).
+    static const int mid = [] {
+        const char* e = getenv("SG_STREAMK_MID");  // 0 = off (tuning aid)
+        return e ? atoi(e) : 1;
+    }();
+    if (mid && kind == 2 && a.force == 0 && ((a.M + 255) / 256) * (a.N / 128) < cus) {
+        if (((a.M + 127) / 128) * (a.N / 128) >= cus) {
+            kind = 1;
+            bm = 128;
+            workers = cus;
+        } else if (((a.M + 63) / 64) * (a.N / 128) >= cus) {
+            // small batches (B = 16): 4-wave 64x128 blocks, one per CU -- balances the 272 tiles a one-block-per-tile
+            // launch would spread as 240 x 1 + 16 x 2
+            kind = 3;
+            bm = 64;
+            workers = cus;
+        }
+    }
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
     const int tiles = mtiles * ntiles;
     const long total = (long)tiles * a.total_chunks;
@@ -1032,8 +1055,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     }();
     if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
     // every worker has to be resident at once; if the runtime would admit fewer blocks than that, use the tile launch
-    const int per_cu = kind == 2 ? streamk_blocks_per_cu<2>() : kind == 1 ? streamk_blocks_per_cu<1>() : streamk_blocks_per_cu<0>();
+    const int per_cu = kind == 2 ? streamk_blocks_per_cu<2>() : kind == 1 ? streamk_blocks_per_cu<1>()
+                     : kind == 3 ? streamk_blocks_per_cu<3>() : streamk_blocks_per_cu<0>();
     if ((long)per_cu * cus < workers) return hipErrorNotSupported;
+    if ((size_t)workers * bm * 128 > (size_t)512 * 128 * 128) return hipErrorNotSupported;  // slab capacity (sg_api.hip)
     static std::atomic<unsigned> launch_counter{0};
     unsigned epoch = ++launch_counter;
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
@@ -1045,7 +1070,8 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     dim3 grid(workers);
 #define a at
 #define SG_SK(EPI)                                                                                          \
-    if (kind == 2) launch_streamk_kind<EPI, 2>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    if (kind == 3) launch_streamk_kind<EPI, 3>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    else if (kind == 2) launch_streamk_kind<EPI, 2>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 1) launch_streamk_kind<EPI, 1>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else launch_streamk_kind<EPI, 0>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);
     switch (epi) {

@@ -45,6 +45,12 @@ def _case(seed, B, Ta, Tc, Kc, n, taps):
 SHAPES = [
     pytest.param((64, 270, 266, 192, 512, 3, 2, 0), id="fwd_streamk_dil2"),
     pytest.param((64, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_edges"),
+    # medium / small batches: fewer 256-row tiles than CUs -> stream-K with one 8-wave 128x128 block per CU (B = 32)
+    # or one 4-wave 64x128 block per CU (B = 16)
+    pytest.param((32, 270, 266, 192, 512, 3, 2, 0), id="fwd_streamk_mid_128row"),
+    pytest.param((32, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_mid_128row"),
+    pytest.param((16, 270, 266, 192, 512, 3, 2, 0), id="fwd_streamk_small_64row"),
+    pytest.param((16, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_small_64row"),
     pytest.param((3, 50, 46, 64, 128, 5, 1, 0), id="fwd_small_ragged_tile"),
     pytest.param((2, 40, 46, 96, 256, 3, -3, 0), id="dgrad_small"),
     pytest.param((5, 33, 33, 32, 128, 3, 1, -1), id="same_padding_tap_base"),
