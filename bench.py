@@ -86,6 +86,39 @@ def cpu_baseline(weights, budget_utts=16, steps=3, gpu_model=None):
     }
 
 
+def gather_flags(mine, dist, world):
+    """The attack's only exchange: every rank's per-utterance success flags, in rank order (uint8: RCCL has no bool)."""
+    if dist is None:
+        return mine
+    mine = mine.to(torch.uint8)
+    flags = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(flags, mine)
+    return torch.cat(flags)
+
+
+def timed_region(attack, steps, warmup, dist, sync, dev):
+    """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + device synchronise on both sides;
+    returns (attack result, seconds = MAX over ranks).  Factored out so the N > 1 protocol is covered by a
+    world-size-2 gloo test on the CPU (tests/test_bench_protocol.py)."""
+    if warmup > 0:
+        attack(warmup)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    result = attack(steps)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return result, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,29 +166,9 @@ def main():
 
     def attack(k):
         out = model.pgd_run(x, y, lower, upper, spec, STEP, k, 1)
-        if dist is not None:  # the attack's only exchange: success flags of every shard
-            mine = out[1].to(torch.uint8)  # RCCL has no bool type
-            flags = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(flags, mine)
-            return out, torch.cat(flags)
-        return out, out[1]
+        return out, gather_flags(out[1], dist, world)  # inside the timed region
 
-    if args.warmup > 0:
-        attack(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out, flags = attack(args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    (out, flags), dt = timed_region(attack, args.steps, args.warmup, dist, torch.cuda.synchronize, dev)
 
     # roofline of the dominant kernel: TDNN layer 3 forward contraction (stream-K, 128x128 quad-fed tiles),
     # HIP events on the launch stream inside the library
