@@ -494,9 +494,13 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
 // stack): the same operand scheme and k order as gemm_segment_q, 48 KB of LDS so three blocks share a CU.
 // Staging roles: waves 0-1 copy the A chunk (64 rows x 8 float4: 4 per thread), waves 2-3 the W chunk (8 k4-groups
 // x 128 columns: 8 per thread).
+// MI = row fragments per wave: 2 -> 64 x 128 tile; 1 -> 32 x 128 tile (half the MFMAs per chunk and wave: the k chain of
+// a tile, which is what a nearly empty chip waits for at batch <= 8, is half as long).
+template <int MI>
 __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
-                                                int c_end, f32x16 (&acc)[2][1]) {
-    constexpr int BM = 64, BN = 128;
+                                                int c_end, f32x16 (&acc)[MI][1]) {
+    constexpr int BM = 32 * MI, BN = 128;
+    constexpr int LA = 2 * MI;  // A float4 per A-role thread and chunk (rows 16 i + ts / 8)
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;
     constexpr int ST_STRIDE = 512;  // LDS floats between a thread's consecutive float4 (16 A rows / one W k4-group)
     float* As = smem;                   // [2][BM][32]
@@ -523,8 +527,8 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = m0 + (ts >> 3) + 16 * i;
-            row_off[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
-            a_t[i] = r < p.M ? t : -(1 << 28);
+            row_off[i] = i < LA ? ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u : kOob;
+            a_t[i] = (i < LA && r < p.M) ? t : -(1 << 28);
             t += 16;
             while (t >= p.Tc) {
                 t -= p.Tc;
@@ -581,8 +585,10 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
     auto store_chunk = [&](float* d) {
         *reinterpret_cast<i32x4*>(d + 0 * ST_STRIDE) = r0;
         *reinterpret_cast<i32x4*>(d + 1 * ST_STRIDE) = r1;
-        *reinterpret_cast<i32x4*>(d + 2 * ST_STRIDE) = r2;
-        *reinterpret_cast<i32x4*>(d + 3 * ST_STRIDE) = r3;
+        if (MI == 2 || !role_a) {
+            *reinterpret_cast<i32x4*>(d + 2 * ST_STRIDE) = r2;
+            *reinterpret_cast<i32x4*>(d + 3 * ST_STRIDE) = r3;
+        }
         if (!role_a) {
             *reinterpret_cast<i32x4*>(d + 4 * ST_STRIDE) = r4;
             *reinterpret_cast<i32x4*>(d + 5 * ST_STRIDE) = r5;
@@ -609,7 +615,8 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
         constexpr int BOFF = BUF * B_STAGE;
         __builtin_amdgcn_sched_barrier(0);
         float4 a0 = *reinterpret_cast<const float4*>(a_kg0 + AOFF);
-        float4 a1 = *reinterpret_cast<const float4*>(a_kg0 + AOFF + 32 * 32);
+        float4 a1 = a0;
+        if (MI == 2) a1 = *reinterpret_cast<const float4*>(a_kg0 + AOFF + 32 * 32);
         float4 b0 = *reinterpret_cast<const float4*>(b_base + BOFF);
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
@@ -617,18 +624,19 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
             if (kg < 3) {
                 const float* an = kg == 0 ? a_kg1 : kg == 1 ? a_kg2 : a_kg3;
                 na0 = *reinterpret_cast<const float4*>(an + AOFF);
-                na1 = *reinterpret_cast<const float4*>(an + AOFF + 32 * 32);
+                na1 = na0;
+                if (MI == 2) na1 = *reinterpret_cast<const float4*>(an + AOFF + 32 * 32);
                 nb0 = *reinterpret_cast<const float4*>(b_base + BOFF + (kg + 1) * 2 * BN * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[MI - 1][0], 0, 0, 0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[MI - 1][0], 0, 0, 0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[MI - 1][0], 0, 0, 0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[MI - 1][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kg == 1) {
                 if (c + 1 < c_end) store_chunk(BUF ? st_ptr0 : st_ptr1);
@@ -757,10 +765,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int m
     tile_store<BM, BN, WM, WN, EPI>(p, p.C + (size_t)blockIdx.z * p.split_stride, m0, n0, acc);
 }
 
-// One block per tile, quad-fed 64 x 128 (needs the k4-packed weights; no split-K).
-template <int EPI>
+// One block per tile, quad-fed 64 x 128 (MI = 2) or 32 x 128 (MI = 1) (needs the k4-packed weights; no split-K).
+template <int EPI, int MI>
 __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int mtiles, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (64 + 128)];
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (32 * MI + 128)];
     const int nblk = mtiles * ntiles;
     int bid = blockIdx.x;
     {
@@ -769,11 +777,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int mt = bid / ntiles, nt = bid % ntiles;
-    const int m0 = mt * 64, n0 = nt * 128;
-    f32x16 acc[2][1];
+    const int m0 = mt * 32 * MI, n0 = nt * 128;
+    f32x16 acc[MI][1];
     acc_zero(acc);
-    gemm_segment_q1(p, smem, m0, n0, 0, p.total_chunks, acc);
-    tile_store<64, 128, 1, 4, EPI>(p, p.C, m0, n0, acc);
+    gemm_segment_q1<MI>(p, smem, m0, n0, 0, p.total_chunks, acc);
+    tile_store<32 * MI, 128, 1, 4, EPI>(p, p.C, m0, n0, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -790,13 +798,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int
 // per worker (cdna guide G16).  A flag holds the EPOCH of the launch that parked the slab (a process-wide
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
 // KIND 0: 8 waves, b32-fed 128x128 (no packed weights); 1: 8 waves, quad-fed 128x128; 2: 16 waves, quad-fed 256x128;
-// 3: 4 waves, quad-fed 64x128 (small batches: one block per CU).
+// 3: 4 waves, quad-fed 64x128 (small batches: one block per CU); 4: 4 waves, quad-fed 32x128 (batch 8).
 template <int EPI, int KIND>
-__global__ __launch_bounds__(KIND == 2 ? 1024 : KIND == 3 ? 256 : 512, KIND == 3 ? 1 : 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+__global__ __launch_bounds__(KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, KIND >= 3 ? 1 : 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                                       int iters_per_worker, float* slabs,
                                                                                       unsigned* flags, unsigned epoch) {
-    constexpr int WM = KIND == 2 ? 4 : KIND == 3 ? 1 : 2, WN = 4;
-    constexpr int BM = 64 * WM, BN = 128;
+    constexpr int WM = KIND == 2 ? 4 : KIND >= 3 ? 1 : 2, WN = 4;
+    constexpr int BM = KIND == 4 ? 32 : 64 * WM, BN = 128;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 fragments per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BK * (BM + BN) floats
     const int C = p.total_chunks;
@@ -819,7 +827,8 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : KIND == 3 ? 256 : 512, KIND == 3
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) {
         if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
-        else if constexpr (KIND == 3) gemm_segment_q1(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (KIND == 3) gemm_segment_q1<2>(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (KIND == 4) gemm_segment_q1<1>(p, smem, m0, n0, c0, c1, acc);
         else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc, tr);
     };
     // Parked accumulators travel as 16-byte pieces: piece q of fragment (mi, ni) of wave wid, lane-interleaved, so
@@ -955,16 +964,29 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
-static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
-    const int mtiles = (a.M + 63) / 64, ntiles = a.N / 128;
+template <int MI>
+static hipError_t launch_tile_q_mi(const ConvGemmArgs& a, int epi, hipStream_t s) {
+    const int mtiles = (a.M + 32 * MI - 1) / (32 * MI), ntiles = a.N / 128;
     dim3 grid(mtiles * ntiles);
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_NONE>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
-        case EPI_BIAS_RELU: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_BIAS_RELU>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
-        case EPI_RELU_MASK: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_RELU_MASK>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
+        case EPI_NONE: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_NONE, MI>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
+        case EPI_BIAS_RELU: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_BIAS_RELU, MI>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
+        case EPI_RELU_MASK: hipLaunchKernelGGL((conv_gemm_q_kernel<EPI_RELU_MASK, MI>), grid, dim3(256), 0, s, a, mtiles, ntiles); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
+    // A nearly empty chip (batch <= 8: fewer 64-row tiles than CUs) waits for the sequential k chain of one tile;
+    // 32-row tiles halve the MFMAs per wave and chunk, so the chain -- and the launch -- takes half as long.
+    static const int small_rows = [] {
+        const char* e = getenv("SG_TILE32");  // 0 = always 64-row tiles (tuning aid)
+        return e ? atoi(e) : 1;
+    }();
+    const int cus = a.num_cus > 0 ? a.num_cus : 256;
+    if (small_rows && a.force == 0 && a.total_chunks >= 8 && ((a.M + 63) / 64) * (a.N / 128) < cus) return launch_tile_q_mi<1>(a, epi, s);
+    return launch_tile_q_mi<2>(a, epi, s);
 }
 
 // Persistent workers = resident blocks: 512 8-wave blocks (64 KB LDS, two per CU) or 256 16-wave blocks (96 KB, one
@@ -976,8 +998,8 @@ static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
 template <int EPI, int KIND>
 static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, int tiles, int ipw, float* slabs,
                                 unsigned* flags, unsigned epoch, hipStream_t s) {
-    constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : 128;
-    constexpr int threads = KIND == 2 ? 1024 : KIND == 3 ? 256 : 512;
+    constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : KIND == 4 ? 32 : 128;
+    constexpr int threads = KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512;
     constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
     // per device: remember for which devices the > 64 KB dynamic-LDS opt-in has been made (a process may hold one
     // sg_ctx per GPU)
@@ -999,13 +1021,13 @@ static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, 
 template <int KIND>
 static int streamk_blocks_per_cu() {
     static const int n = [] {
-        constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : 128;
+        constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : KIND == 4 ? 32 : 128;
         constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
         const void* fn = reinterpret_cast<const void*>(conv_gemm_streamk_kernel<EPI_NONE, KIND>);
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_streamk_kernel<EPI_NONE, KIND>,
-                                                         KIND == 2 ? 1024 : KIND == 3 ? 256 : 512, lds) != hipSuccess)
+                                                         KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, lds) != hipSuccess)
             nb = 0;
         return nb;
     }();
@@ -1040,6 +1062,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
             kind = 3;
             bm = 64;
             workers = cus;
+        } else if (((a.M + 31) / 32) * (a.N / 128) >= cus) {
+            kind = 4;  // batch 8: 32-row tiles, half the k chain per tile, balanced over the CUs
+            bm = 32;
+            workers = cus;
         }
     }
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
@@ -1056,7 +1082,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
     // every worker has to be resident at once; if the runtime would admit fewer blocks than that, use the tile launch
     const int per_cu = kind == 2 ? streamk_blocks_per_cu<2>() : kind == 1 ? streamk_blocks_per_cu<1>()
-                     : kind == 3 ? streamk_blocks_per_cu<3>() : streamk_blocks_per_cu<0>();
+                     : kind == 3 ? streamk_blocks_per_cu<3>() : kind == 4 ? streamk_blocks_per_cu<4>() : streamk_blocks_per_cu<0>();
     if ((long)per_cu * cus < workers) return hipErrorNotSupported;
     if ((size_t)workers * bm * 128 > (size_t)512 * 128 * 128) return hipErrorNotSupported;  // slab capacity (sg_api.hip)
     static std::atomic<unsigned> launch_counter{0};
@@ -1070,7 +1096,8 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     dim3 grid(workers);
 #define a at
 #define SG_SK(EPI)                                                                                          \
-    if (kind == 3) launch_streamk_kind<EPI, 3>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    if (kind == 4) launch_streamk_kind<EPI, 4>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    else if (kind == 3) launch_streamk_kind<EPI, 3>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 2) launch_streamk_kind<EPI, 2>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 1) launch_streamk_kind<EPI, 1>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else launch_streamk_kind<EPI, 0>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);

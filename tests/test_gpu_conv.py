@@ -51,6 +51,8 @@ SHAPES = [
     pytest.param((32, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_mid_128row"),
     pytest.param((16, 270, 266, 192, 512, 3, 2, 0), id="fwd_streamk_small_64row"),
     pytest.param((16, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_small_64row"),
+    pytest.param((8, 270, 266, 192, 512, 3, 2, 0), id="fwd_streamk_tiny_32row"),
+    pytest.param((8, 266, 270, 192, 512, 3, -2, 0), id="dgrad_streamk_tiny_32row"),
     pytest.param((3, 50, 46, 64, 128, 5, 1, 0), id="fwd_small_ragged_tile"),
     pytest.param((2, 40, 46, 96, 256, 3, -3, 0), id="dgrad_small"),
     pytest.param((5, 33, 33, 32, 128, 3, 1, -1), id="same_padding_tap_base"),
