@@ -4,9 +4,10 @@ With ``defense=None`` (reference :127-128,156-157) every call is passed straight
 including the native ``loss_grad`` / ``pgd_run`` entry points the attacks use.  Input- and
 feature-level defenses are applied for the forward calls exactly like ``process_sequential``
 (:46-65).  The gradient THROUGH feature-level defenses is chained by hand for
-defenses that expose ``fwd`` / ``bwd`` (``speakerguard_amd.defense.feature_level.FeCoDefense``) on the native
-xv_plda / audionet_csine base models in sequential order; any other defended configuration raises in ``loss_grad`` instead of silently
-ignoring the defense.
+defenses that expose ``fwd`` / ``bwd`` (``speakerguard_amd.defense.feature_level.FeCoDefense`` at the feature levels,
+``speakerguard_amd.adaptive_attack.BPDA.BPDA(f, sub_f)`` -- the reference's straight-through wrapper, BPDA.py:7-65 -- around any
+input-level transform) on the native xv_plda / audionet_csine base models in sequential order; any other defended
+configuration raises in ``loss_grad`` instead of silently ignoring the defense.
 """
 import warnings
 
@@ -116,11 +117,23 @@ class defended_model:
         The order is process_sequential's (:52-63).  Each stage's backward is the native one: the model's own
         loss_grad from the last defended level, the defenses' ``bwd``, CMVN / MFCC backward in between."""
         bm = self.base_model
-        chainable = (self.order == sequential and hasattr(bm, 'frontend_forward') and not self.flag2defense.get(0)
-                     and all(hasattr(d, 'fwd') and hasattr(d, 'bwd') for f in (1, 2) for d in self.flag2defense.get(f, [])))
+        chainable = (self.order == sequential and hasattr(bm, 'frontend_forward')
+                     and all(hasattr(d, 'fwd') and hasattr(d, 'bwd') for f in (0, 1, 2) for d in self.flag2defense.get(f, [])))
         if not chainable:
             raise NotImplementedError('gradient through this defense configuration is not built: needs a native base '
-                                      'model, sequential order, and feature-level defenses with fwd/bwd (FeCoDefense)')
+                                      'model, sequential order, and defenses exposing fwd/bwd (FeCoDefense at the feature '
+                                      'levels; adaptive_attack.BPDA.BPDA(f, sub_f) around any input-level transform)')
+        # input-level defenses (flag 0: wav -> wav), e.g. BPDA-wrapped quantisation (defense/time_domain.py:44)
+        tape0 = []
+        for d in self.flag2defense.get(0, []):
+            x, sv = d.fwd(x)
+            tape0.append((d, sv))
+        if not self.flag2defense.get(1) and not self.flag2defense.get(2):
+            # nothing sits between front-end and network: one native call from the (defended) waveform
+            decisions, scores, loss, g = bm.loss_grad(x, y, loss_spec, flag=0, want_grad=True)
+            for d, sv in reversed(tape0):
+                g = d.bwd(sv, g)
+            return decisions, scores, loss, g
         feats, saved_front = bm.frontend_forward(x)
         tape1, tape2 = [], []
         for d in self.flag2defense[1]:
@@ -139,7 +152,10 @@ class defended_model:
             decisions, scores, loss, g = bm.loss_grad(feats, y, loss_spec, flag=1, want_grad=True)
         for d, sv in reversed(tape1):
             g = d.bwd(sv, g)
-        return decisions, scores, loss, bm.frontend_backward(saved_front, g)
+        g = bm.frontend_backward(saved_front, g)
+        for d, sv in reversed(tape0):
+            g = d.bwd(sv, g)
+        return decisions, scores, loss, g
 
     def pgd_update(self, *a, **k):
         return self.base_model.pgd_update(*a, **k)

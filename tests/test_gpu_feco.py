@@ -148,6 +148,40 @@ def test_gradient_through_feco_matches_oracle_autograd(hip_model, oracle_model, 
     assert same > 0.97
 
 
+def test_bpda_input_defense_in_the_gradient_chain(hip_model):
+    """BASELINE configs[3] names "EOT/BPDA": a non-differentiable input transform wrapped in the reference's
+    straight-through BPDA (BPDA.py:7-65, used for QT at defense/time_domain.py:44) has gradient identity, so
+    d loss/d x of the defended model at x is the base model's gradient AT the transformed input -- alone, and stacked
+    in front of a feature-level FeCo."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.adaptive_attack.BPDA import straight_through
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.defended_model import defended_model
+    x = torch.from_numpy(synth.make_waveforms(3, 24000, seed=74)).to(DEV)
+    quant = straight_through(lambda a: torch.round(a * 32768.0 / 256.0) * 256.0 / 32768.0)   # 8-bit depth reduction
+    spec = SEC4SR_CrossEntropy()
+    y = hip_model.make_decision(x)[0]
+    dm = defended_model(hip_model, defense=[(0, quant)])
+    dec, scores, loss, grad = dm.loss_grad(x, y, spec)
+    d0, s0, l0, g0 = hip_model.loss_grad(quant(x), y, spec)
+    assert torch.equal(grad, g0) and torch.equal(scores, s0) and torch.equal(loss, l0)
+    assert torch.equal(dm.make_decision(x)[1], s0)
+    # stacked: quantisation (flag 0) then FeCo on the raw features (flag 1)
+    feco = FeCoDefense(0.5)
+    dm2 = defended_model(hip_model, defense=[(0, quant), (1, feco)])
+    ref = defended_model(hip_model, defense=[(1, feco)])
+    _, s2, _, g2 = dm2.loss_grad(x, y, spec)
+    _, s2r, _, g2r = ref.loss_grad(quant(x), y, spec)
+    assert torch.equal(s2, s2r) and torch.equal(g2, g2r)
+    # and the attack loop runs against it (step path: a defense sits between attack and model)
+    adv, success = PGD(dm2, epsilon=0.002, step_size=0.0004, max_iter=3, batch_size=3, EOT_size=2, EOT_batch_size=1,
+                       verbose=0).attack(x, y)
+    assert (adv - x).abs().max().item() <= 0.002 + 1e-7 and len(success) == 3
+    log("BPDA(quantise) + FeCo in the gradient chain: identity backward verified, PGD+EOT ran, success %s" % success)
+
+
 def test_pgd_against_feco_defended_model(hip_model):
     from speakerguard_amd import synth
     from speakerguard_amd.attack.PGD import PGD
