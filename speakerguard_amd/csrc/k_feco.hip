@@ -36,68 +36,137 @@ int feco_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
 
 constexpr int kFecoMaxD = 64;
 
-// one block per utterance; dynamic LDS: [x[F][D] when X_IN_LDS,] c[k][D], ids[F] (int); changed flag.
-// X_IN_LDS = false is the long-utterance form: the frames stay in HBM (read-only, served by L1/L2), only the
-// centroids and ids live in LDS -- same arithmetic, same order, same ids.
-template <bool X_IN_LDS>
-__global__ __launch_bounds__(256) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
-                                                          int max_iter, int* __restrict__ assign) {
+// One 1024-thread block per utterance.  Round 1 kept frames and centroids in LDS and gave every thread a frame whose
+// D floats it re-read from LDS for every centroid: at D = 32 the 64 lanes of a wave hit ONE bank (stride 32 words) --
+// 3.1 ms per call at 64 x 300 x 32, 80 % of a step against a FeCo-defended AudioNet.  Now:
+//   * a thread keeps ITS frame in registers for the whole call (frames are read once, coalescing irrelevant), the
+//     centroids sit in LDS padded to DPAD floats per row and are read as 16-byte broadcasts;
+//   * the centroid range is cut into JC = 1024 / F chunks so that all 1024 threads work on the assignment (thread =
+//     (frame, chunk)); chunk minima are merged in ascending centroid order with a strict <, i.e. the lowest index still
+//     wins ties;
+//   * the update walks per-cluster member lists (built by a stable counting pass: ascending frame order, as the
+//     contract demands) instead of scanning all F ids for each of the k x D centroid entries.
+// Same arithmetic, same order, same ids as before (oracle/feco.py restates the contract; tests compare bit for bit).
+// Dynamic LDS: cs[k][DPAD], ids[F], cnt[k], start[k + 1], members[F], pd[1024], pj[1024].
+template <int DPAD>
+__global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
+                                                           int max_iter, int* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* cs = lds + (X_IN_LDS ? (size_t)F * D : 0);
-    int* ids = reinterpret_cast<int*>(cs + (size_t)k * D);
+    float* cs = lds;                                             // [k][DPAD], pad columns zero
+    int* ids = reinterpret_cast<int*>(cs + (size_t)k * DPAD);   // [F]
+    int* cnt = ids + F;                                          // [k]
+    int* start = cnt + k;                                        // [k + 1]
+    int* members = start + k + 1;                                // [F] frames grouped by cluster, ascending inside a group
+    float* pd = reinterpret_cast<float*>(members + F);           // [1024] chunk minima
+    int* pj = reinterpret_cast<int*>(pd + 1024);                 // [1024]
     __shared__ int changed;
+    const int tid = threadIdx.x;
     const float* x = feats + (size_t)blockIdx.x * F * D;
-    const float* xs = x;
-    if (X_IN_LDS) {
-        for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds[i] = x[i];
-        xs = lds;
+    for (int i = tid; i < F; i += 1024) ids[i] = -1;
+    for (int e = tid; e < k * DPAD; e += 1024) {
+        const int j = e / DPAD, d = e - j * DPAD;
+        cs[e] = d < D ? x[(size_t)(int)((long long)j * F / k) * D + d] : 0.f;
     }
-    for (int i = threadIdx.x; i < F; i += blockDim.x) ids[i] = -1;
-    __syncthreads();
-    for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
-        const int j = i / D, d = i - j * D;
-        cs[i] = xs[(size_t)(int)((long long)j * F / k) * D + d];
-    }
+    // thread = (frame slot li, centroid chunk jc); F <= 1024: one pass, the frame stays in registers
+    const int fpp = F <= 1024 ? F : 1024;
+    const int JC = F <= 1024 ? max(1, min(8, 1024 / F)) : 1;
+    const int li = tid % fpp, jc = tid / fpp;
+    const bool worker = jc < JC;
+    const int jlo = (int)((long long)k * jc / JC), jhi = worker ? (int)((long long)k * (jc + 1) / JC) : 0;
+    float xr[DPAD];
+#pragma unroll
+    for (int d = 0; d < DPAD; ++d) xr[d] = (worker && li < F && d < D) ? x[(size_t)li * D + d] : 0.f;
     __syncthreads();
     for (int it = 0; it < max_iter; ++it) {
-        if (threadIdx.x == 0) changed = 0;
+        if (tid == 0) changed = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < F; i += blockDim.x) {
+        for (int f0 = 0; f0 < F; f0 += fpp) {
+            const int i = f0 + li;
+            if (F > fpp) {  // long utterances (several passes): load the frame of this pass
+#pragma unroll
+                for (int d = 0; d < DPAD; ++d) xr[d] = (worker && i < F && d < D) ? x[(size_t)i * D + d] : 0.f;
+            }
             float best = INFINITY;
-            int bj = 0;
-            for (int j = 0; j < k; ++j) {
-                float acc = 0.f;
-                for (int d = 0; d < D; ++d) {
-                    const float df = xs[(size_t)i * D + d] - cs[(size_t)j * D + d];
-                    acc = acc + df * df;
-                }
-                if (acc < best) {
-                    best = acc;
-                    bj = j;
+            int bj = jlo;
+            if (worker && i < F) {
+                for (int j = jlo; j < jhi; ++j) {
+                    const float4* c4 = reinterpret_cast<const float4*>(cs + (size_t)j * DPAD);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < DPAD / 4; ++q) {  // d ascending; pad dims add +0 (x = c = 0), acc unchanged
+                        const float4 c = c4[q];
+                        float df = xr[4 * q] - c.x;
+                        acc = acc + df * df;
+                        df = xr[4 * q + 1] - c.y;
+                        acc = acc + df * df;
+                        df = xr[4 * q + 2] - c.z;
+                        acc = acc + df * df;
+                        df = xr[4 * q + 3] - c.w;
+                        acc = acc + df * df;
+                    }
+                    if (acc < best) {
+                        best = acc;
+                        bj = j;
+                    }
                 }
             }
-            if (ids[i] != bj) {
-                ids[i] = bj;
-                changed = 1;
+            pd[tid] = best;
+            pj[tid] = bj;
+            __syncthreads();
+            if (jc == 0 && i < F) {  // merge the chunks in ascending centroid order: the lowest index wins ties
+                float b = pd[li];
+                int bb = pj[li];
+                for (int c = 1; c < JC; ++c) {
+                    const float v = pd[c * fpp + li];
+                    if (v < b) {
+                        b = v;
+                        bb = pj[c * fpp + li];
+                    }
+                }
+                if (ids[i] != bb) {
+                    ids[i] = bb;
+                    changed = 1;
+                }
             }
+            __syncthreads();
+        }
+        if (!changed) break;
+        // member lists: thread j counts its frames, thread 0 scans, thread j writes them in ascending frame order
+        for (int j = tid; j < k; j += 1024) {
+            int n = 0;
+            for (int i = 0; i < F; ++i) n += ids[i] == j;
+            cnt[j] = n;
         }
         __syncthreads();
-        if (!changed) break;
-        // update: thread (j, d) sums its cluster's frames in ascending frame order
-        for (int e = threadIdx.x; e < k * D; e += blockDim.x) {
-            const int j = e / D, d = e - j * D;
-            float sum = 0.f;
-            int cnt = 0;
+        if (tid == 0) {
+            int run = 0;
+            for (int j = 0; j < k; ++j) {
+                start[j] = run;
+                run += cnt[j];
+            }
+            start[k] = run;
+        }
+        __syncthreads();
+        for (int j = tid; j < k; j += 1024) {
+            int o = start[j];
             for (int i = 0; i < F; ++i)
-                if (ids[i] == j) {
-                    sum = sum + xs[(size_t)i * D + d];
-                    ++cnt;
-                }
-            if (cnt > 0) cs[e] = sum / (float)cnt;
+                if (ids[i] == j) members[o++] = i;
+        }
+        __syncthreads();
+        // update: thread (j, d) sums its cluster's frames in ascending frame order; an empty cluster keeps its centroid
+        for (int e = tid; e < k * DPAD; e += 1024) {
+            const int j = e / DPAD, d = e - j * DPAD;
+            const int n = cnt[j];
+            if (d < D && n > 0) {
+                float sum = 0.f;
+                const int o = start[j];
+                for (int m = 0; m < n; ++m) sum = sum + x[(size_t)members[o + m] * D + d];
+                cs[e] = sum / (float)n;
+            }
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < F; i += blockDim.x) assign[(size_t)blockIdx.x * F + i] = ids[i];
+    for (int i = tid; i < F; i += 1024) assign[(size_t)blockIdx.x * F + i] = ids[i];
 }
 
 // out[b][j][d] = mean over frames with id j (ascending order) or, for an empty cluster, feats[b][j][d]
@@ -142,26 +211,24 @@ extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, in
     if (!feats_dev || !assign_dev || B <= 0 || F <= 0 || D <= 0 || D > kFecoMaxD || k <= 0 || k > F || max_iter <= 0)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: need 0 < k <= F, 0 < D <= %d, max_iter > 0", kFecoMaxD);
     if (hipSetDevice(ctx->device) != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: hipSetDevice failed");
-    // Placement: frames + centroids + ids in one block's LDS when they fit (3 s .. ~8 s utterances); for longer
-    // utterances the frames stay in HBM and only centroids + ids use LDS (up to k * D * 4 + F * 4 <= 150 KB, i.e.
-    // ~23 s at D = 32, ratio 0.5); beyond that the call is refused.
+    // LDS holds the centroids (rows padded to 32 / 64 floats), ids, member lists and the chunk minima; the frames stay
+    // in registers / HBM.  150 KB of it covers ~23 s at D <= 32, ratio 0.5 (k = 1150); beyond that the call is refused.
     constexpr size_t kLdsMax = 150 * 1024;
-    const size_t lds_small = ((size_t)k * D) * sizeof(float) + (size_t)F * sizeof(int);
-    const size_t lds_full = lds_small + (size_t)F * D * sizeof(float);
-    if (lds_small > kLdsMax)
-        return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: %d clusters x %d dims + %d ids need %zu bytes of LDS (limit %zu): "
-                         "utterance too long for one block", k, D, F, lds_small, kLdsMax);
-    const bool in_lds = lds_full <= kLdsMax;
-    const void* fn = in_lds ? reinterpret_cast<const void*>(feco_kmeans_kernel<true>)
-                            : reinterpret_cast<const void*>(feco_kmeans_kernel<false>);
+    const int dpad = D <= 32 ? 32 : 64;
+    const size_t lds = (size_t)k * dpad * sizeof(float) + ((size_t)2 * F + 2 * (size_t)k + 1) * sizeof(int) + 2 * 1024 * sizeof(float);
+    if (lds > kLdsMax)
+        return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: %d clusters x %d dims + %d frames need %zu bytes of LDS (limit %zu): "
+                         "utterance too long for one block", k, D, F, lds, kLdsMax);
+    const void* fn = dpad == 32 ? reinterpret_cast<const void*>(feco_kmeans_kernel<32>)
+                                : reinterpret_cast<const void*>(feco_kmeans_kernel<64>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
-    if (in_lds)
-        hipLaunchKernelGGL(feco_kmeans_kernel<true>, dim3(B), dim3(256), lds_full, (hipStream_t)stream, feats_dev, F, D, k,
-                           max_iter, assign_dev);
+    if (dpad == 32)
+        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
+                           assign_dev);
     else
-        hipLaunchKernelGGL(feco_kmeans_kernel<false>, dim3(B), dim3(256), lds_small, (hipStream_t)stream, feats_dev, F, D, k,
-                           max_iter, assign_dev);
+        hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
+                           assign_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     return SG_OK;

@@ -1,0 +1,72 @@
+"""Throughput of the other BASELINE.json configurations on one GPU (informational: the metric is configs[1], bench.py).
+
+    configs[2]  CW2 L2 targeted on xv_plda SV task, batch 32, Adam inner optimiser
+    configs[3]  PGD + EOT vs FeCo-defended AudioNet, 64 utterances (= one GPU's shard of the batch of 512)
+    configs[4]  FAKEBOB / NES on xv_plda OSI, samples_per_draw 50: queries per second
+"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speakerguard_amd import synth
+from speakerguard_amd.attack.CW2 import CW2
+from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+from speakerguard_amd.attack.PGD import PGD
+from speakerguard_amd.defense.feature_level import FeCoDefense
+from speakerguard_amd.model.audionet_csine import audionet_csine
+from speakerguard_amd.model.defended_model import defended_model
+from speakerguard_amd.model.xv_plda import xv_plda
+
+dev = torch.device("cuda:0")
+w = synth.make_xv_weights()
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t0
+
+
+# ---- configs[2]: CW2, SV (one enrolled speaker, finite threshold), batch 32
+w1 = dict(w); w1["enroll"] = w["enroll"][:1]
+sv = xv_plda.from_weights(w1, threshold=-10.0, device=dev, dither=0.0)
+x = torch.from_numpy(synth.make_waveforms(32, 48000, seed=2)).to(dev)
+y = torch.zeros(32, dtype=torch.int64, device=dev)
+iters, steps = 30, 2
+atk = CW2(sv, task="SV", targeted=True, initial_const=1e-3, binary_search_steps=steps, max_iter=iters, stop_early=False,
+          lr=1e-2, batch_size=32, verbose=0)
+atk.attack(x[:32], y)  # warm
+(_, succ), dt = timed(lambda: atk.attack(x, y))
+n_it = steps * (iters + 1)
+print("configs[2] CW2 targeted SV, batch 32 x 3 s: %d iterations in %.2f s -> %.1f iterations/s (%.0f utterance-iterations/s), success %d/32"
+      % (n_it, dt, n_it / dt, 32 * n_it / dt, sum(succ)))
+
+# ---- configs[3]: PGD + EOT vs FeCo-defended AudioNet, 64 utterances per GPU
+an = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)
+dm = defended_model(an, defense=[(1, FeCoDefense(0.5))])
+xa = torch.from_numpy(synth.make_waveforms(64, 48000, seed=3)).to(dev)
+ya = dm.make_decision(xa)[0]
+K = 10
+pgd = PGD(dm, epsilon=0.002, step_size=0.0004, max_iter=K, batch_size=64, EOT_size=2, EOT_batch_size=1, verbose=0)
+pgd.attack(xa[:64], ya)
+(_, succ), dt = timed(lambda: pgd.attack(xa, ya))
+print("configs[3] PGD-%d + EOT 2 vs FeCo-defended AudioNet, batch 64 x 3 s (host-chained gradient): %.2f ms per step (%.2f ms per model pass), %.0f utterance-passes/s"
+      % (K, 1e3 * dt / K, 1e3 * dt / (2 * K + 1), 64 * (2 * K + 1) / dt))
+plain = PGD(an, epsilon=0.002, step_size=0.0004, max_iter=K, batch_size=64, verbose=0)
+plain.attack(xa, ya)
+(_, _), dt0 = timed(lambda: plain.attack(xa, ya))
+print("           undefended AudioNet, fused loop: %.2f ms per step" % (1e3 * dt0 / K))
+
+# ---- configs[4]: FAKEBOB / NES, OSI, samples_per_draw 50
+osi = xv_plda.from_weights(w, threshold=-10.0, device=dev, dither=0.0)
+xq = torch.from_numpy(synth.make_waveforms(8, 48000, seed=4)).to(dev)
+yq = (osi.make_decision(xq)[0].clamp(min=0) + 3) % 10   # targeted at another speaker: no example finishes in 5 iterations
+iters = 5
+fb = FAKEBOB(osi, threshold=-10.0, task="OSI", targeted=True, epsilon=0.002, max_iter=iters, samples_per_draw=50, samples_per_draw_batch_size=50,
+             stop_early=False, batch_size=8, verbose=0)
+fb.attack(xq[:8], yq)
+(_, succ), dt = timed(lambda: fb.attack(xq, yq))
+q = 8 * 51 * (iters + 1)
+print("configs[4] FAKEBOB (NES 50 + 1 queries per example and iteration), batch 8 x 3 s: %d queries in %.2f s -> %.0f queries/s, success %s" % (q, dt, q / dt, succ))
