@@ -343,6 +343,35 @@ def test_short_and_ragged_lengths(hip_model, oracle_model, dev):
         hip_model.make_decision(torch.zeros(1, 1, 2000, device=dev))  # too few frames for the 30-frame context
 
 
+def test_long_utterance_sliding_cmvn_and_gradient(hip_model, oracle_model, dev):
+    """12 s utterances (1200 frames): the 300-frame sliding CMVN window (iv_plda.py:296-377) is no longer the global
+    mean, a tile of the contractions no longer spans a whole utterance; forward and d loss/d waveform vs the oracle."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    T = 192000
+    x = torch.from_numpy(synth.make_waveforms(2, T, seed=29))
+    xin = x.clone().requires_grad_(True)
+    odec, osc = oracle_model.make_decision(xin)
+    y = (odec + 1) % 10
+    lo = oatk.cross_entropy_loss(osc, y)
+    lo.backward(torch.ones_like(lo))
+    dec, scores, loss, grad = hip_model.loss_grad(x.to(dev), y.to(dev), SEC4SR_CrossEntropy())
+    assert dec.cpu().tolist() == odec.tolist()
+    np.testing.assert_allclose(scores.cpu().numpy(), osc.detach().numpy(), rtol=2e-3, atol=0.2)
+    np.testing.assert_allclose(loss.cpu().numpy(), lo.detach().numpy(), rtol=2e-3, atol=2e-2)
+    want, got = xin.grad.numpy(), grad.cpu().numpy()
+    gs = np.abs(want).max()
+    err, sm = np.abs(got - want).max() / gs, float((np.sign(got) != np.sign(want)).mean())
+    log("12 s utterances: score err %.3e, d loss/d wav err/max %.3e, sign mismatch %.3e" % (
+        (scores.cpu() - osc.detach()).abs().max().item(), err, sm))
+    # four times the frames of the 3 s case: a ReLU whose pre-activation is within round-off of 0 flips between the two
+    # fp32 implementations somewhere and moves the gradient of its receptive field (same effect and policy as in
+    # tests/test_gpu_feco.py): bulk tolerance + a bound on the outliers
+    bad = float((np.abs(got - want) > 3e-3 * gs).mean())
+    assert bad < 5e-3 and err < 2e-2 and sm < 5e-3, (bad, err, sm)
+
+
 # ------------------------------------------------------------------------------ PGD update + loops
 def test_pgd_update_kernel_is_bit_exact(hip_model, dev):
     g = torch.Generator().manual_seed(0)

@@ -1,0 +1,22 @@
+"""PGD + EOT vs FeCo-defended AudioNet at batch 64 (one GPU's shard of BASELINE configs[3]) for rocprofv3."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speakerguard_amd import synth
+from speakerguard_amd.attack.PGD import PGD
+from speakerguard_amd.defense.feature_level import FeCoDefense
+from speakerguard_amd.model.audionet_csine import audionet_csine
+from speakerguard_amd.model.defended_model import defended_model
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+an = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)
+dm = defended_model(an, defense=[(1, FeCoDefense(0.5))])
+xa = torch.from_numpy(synth.make_waveforms(B, 48000, seed=3)).to(dev)
+ya = dm.make_decision(xa)[0]
+K = 10
+pgd = PGD(dm, epsilon=0.002, step_size=0.0004, max_iter=K, batch_size=B, EOT_size=2, EOT_batch_size=1, verbose=0)
+pgd.attack(xa, ya)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+pgd.attack(xa, ya)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("B=%d: %.2f ms per step (%d model passes), %.0f utterance-passes/s" % (B, 1e3 * dt / K, 2 * K + 1, B * (2 * K + 1) / dt))
