@@ -12,6 +12,9 @@
 // (1.2 MB per utterance): un-unrolled they issued one dependent load at a time (157 us for the kernel), unrolled
 // 8-16x with 256 threads 97 us; now the K range of every product is split over the four 256-thread quarters of
 // the block (4x the loads in flight), partial sums are combined in a fixed order through LDS.
+#include <cstdio>
+#include <cstdlib>
+
 #include "loss_device.h"
 #include "sg_internal.h"
 
@@ -28,6 +31,7 @@ struct TailModelDev {
 
 constexpr int kTailThreads = 1024;
 constexpr int kTailParts = kTailThreads / 256;
+static_assert(kTailThreads == 2 * kEmb && kTailParts >= 2, "step 1 splits the fc1 slabs over two half-blocks");
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
@@ -69,7 +73,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
                                                    float* __restrict__ scores_out, int64_t* __restrict__ dec_out,
                                                    float* __restrict__ loss_out, float* __restrict__ demb,
                                                    float* __restrict__ loss_trace, int64_t* __restrict__ dec_trace,
-                                                   uint8_t* __restrict__ success) {
+                                                   uint8_t* __restrict__ success, unsigned long long* __restrict__ trace) {
+#define TSTAMP(i) if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[i] = __builtin_amdgcn_s_memrealtime();
+    TSTAMP(0)
     __shared__ float e1[kEmb];
     __shared__ float e2[kMaxD], e4[kMaxD], e5[kMaxD], dv[kMaxD];
     __shared__ float sc[kMaxS], dsc[kMaxS];
@@ -79,16 +85,61 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     const int b = blockIdx.x, tid = threadIdx.x;
     const int D = m.D, S = m.S;
     const float sqrtD = sqrtf((float)D);
-
-    // 1. fc1 output, global-mean subtraction
-    for (int i = tid; i < kEmb; i += NT) {
+    // 1. fc1 output = sum of the split-K slabs (+ folded bias), global-mean subtraction.  The block's two halves take
+    //    half of the slabs each, all loads issued before the first add; halves are added in order.
+    //    Interleaved with it: the four matrices of the products below (1.2 MB at D = 200) were evicted from every XCD's
+    //    L2 by the 2.6 ms of contractions since the last tail launch, and a mat-vec is a chain of dependent load
+    //    batches, each of which would pay an HBM / Infinity-Cache round trip (measured 7.6 + 4.0 + 4.0 + 8.7 us for the
+    //    four products).  Every 128-byte line of them is touched once here, AFTER the slab loads were issued (vmcnt
+    //    retires in order): the misses overlap each other and the slab sum, the products then hit in L2 (14 us).
+    {
+        constexpr int kHalf = kFc1SplitK / 2;
+        const int i = tid & (kEmb - 1), h = tid >> 9;
+        float sv[kHalf];
         float v = 0.f;
-        for (int z = 0; z < nsplit; ++z) v += fc1_part[((size_t)z * B + b) * kEmb + i];
+        if (nsplit == kFc1SplitK) {
+#pragma unroll
+            for (int z = 0; z < kHalf; ++z) sv[z] = fc1_part[((size_t)(h * kHalf + z) * B + b) * kEmb + i];
+        }
+        float sink = 0.f;
+        {
+            // A CU pulls only ~11 B/cycle from HBM (MI355X_MICROARCH.md, prologue burst), so the blocks that share an XCD
+            // (blockIdx % 8 -- a speed assumption only) split the lines between them: block b takes every nq-th line
+            // starting at (b / 8) % nq.  Independent, clamped loads: all of a thread's lines are in flight at once.
+            const int nq = min(8, max(1, (B + 7) >> 3)), q = (b >> 3) % nq;
+            const size_t n_lda = (size_t)(kEmb + 1) * D, n_p = (size_t)D * D;
+            const size_t step = (size_t)NT * nq * 32;
+            float pa[2], pb[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const size_t j = min(((size_t)tid * nq + q) * 32 + r * step, n_lda - 1);
+                pa[r] = m.lda_t[j];
+                pb[r] = want_grad ? m.lda[j] : 0.f;
+            }
+            const size_t jp = min(((size_t)tid * nq + q) * 32, n_p - 1);
+            const float pc = m.plda_pt[jp], pd2 = want_grad ? m.plda_p[jp] : 0.f;
+            for (size_t j = ((size_t)tid * nq + q) * 32 + 2 * step; j < n_lda; j += step) sink += m.lda_t[j] + (want_grad ? m.lda[j] : 0.f);
+            for (size_t j = ((size_t)tid * nq + q) * 32 + step; j < n_p; j += step) sink += m.plda_pt[j] + (want_grad ? m.plda_p[j] : 0.f);
+            sink += (pa[0] + pa[1]) + (pb[0] + pb[1]) + (pc + pd2);
+        }
+        if (nsplit == kFc1SplitK) {
+#pragma unroll
+            for (int z = 0; z < kHalf; ++z) v += sv[z];
+        } else if (h == 0) {
+            for (int z = 0; z < nsplit; ++z) v += fc1_part[((size_t)z * B + b) * kEmb + i];
+        }
+        part[h * kMaxD + i] = v;
+        if (sink == 1.2345e38f && demb) demb[0] = sink;  // never true: keeps the prefetch loads alive
+    }
+    __syncthreads();
+    for (int i = tid; i < kEmb; i += NT) {
+        float v = part[i] + part[kMaxD + i];
         v += m.fc1_b[i];
         if (tdnn_emb) tdnn_emb[(size_t)b * kEmb + i] = v;
         e1[i] = v - m.emb_mean[i];
     }
     __syncthreads();
+    TSTAMP(1)
     // 2. LDA (the offset column of the (D, 513) matrix is row kEmb of the transposed copy)
     matvec_cols(m.lda_t, D, kEmb, D, e1, e2, part);
     float n2 = 0.f;
@@ -97,12 +148,15 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         e2[d] = acc;
         n2 += acc * acc;
     }
+    TSTAMP(2)
     // 3. length normalisation (ratio is a constant for the backward pass)
     const float ratio = sqrtD / sqrtf(block_sum(n2, red));
     for (int d = tid; d < D; d += NT) e2[d] = e2[d] * ratio - m.plda_mean[d];
     __syncthreads();
+    TSTAMP(3)
     // 4. PLDA transform + normalisation factor
     matvec_cols(m.plda_pt, D, D, D, e2, e4, part);
+    TSTAMP(4)
     float qp = 0.f;
     for (int d = tid; d < D; d += NT) qp += e4[d] * e4[d] / (m.plda_psi[d] + 1.f);
     const float q = block_sum(qp, red);
@@ -112,6 +166,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         if (emb_out) emb_out[(size_t)b * D + d] = e5[d];
     }
     __syncthreads();
+    TSTAMP(5)
     // 5. PLDA scores: one wave per enrolled speaker
     {
         const int lane = tid & 63, wid = tid >> 6;
@@ -143,6 +198,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         dsc[s] = 0.f;
     }
     __syncthreads();
+    TSTAMP(6)
     // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
     if (tid == 0) {
         int64_t dec;
@@ -154,6 +210,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         if (loss_trace) loss_trace[b] = loss;
     }
     __syncthreads();
+    TSTAMP(7)
     if (!want_grad || !demb) return;
     // 9. d/d e5 of the score combination
     float dotp = 0.f;
@@ -169,17 +226,23 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         dv[d] = g;
         dotp += g * e4[d];
     }
+    TSTAMP(8)
     // 10. through the PLDA normalisation factor (differentiable, plda.py:92-97)
     const float dot = block_sum(dotp, red);
     for (int d = tid; d < D; d += NT) dv[d] = fac * dv[d] - dot * (fac / q) * e4[d] / (m.plda_psi[d] + 1.f);
     __syncthreads();
+    TSTAMP(9)
     // 11-12. P^T, length-norm ratio
     matvec_cols(m.plda_p, D, D, D, dv, e2, part);
+    TSTAMP(10)
     for (int j = tid; j < D; j += NT) e2[j] *= ratio;
     __syncthreads();
     // 13. LDA^T -> d loss / d fc1 output
     matvec_cols(m.lda, kEmb + 1, D, kEmb, e2, e1, part);
+    TSTAMP(11)
     for (int i = tid; i < kEmb; i += NT) demb[(size_t)b * kEmb + i] = e1[i];
+    TSTAMP(12)
+#undef TSTAMP
 }
 
 hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
@@ -192,9 +255,21 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     m.enroll = x.enroll_override ? x.enroll_override : x.enroll;
     m.D = x.D; m.S = S; m.threshold = x.threshold;
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
+    // tuning aid: SG_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
+    static const bool tr_on = getenv("SG_TAIL_TRACE") != nullptr;
+    static unsigned long long* tr_dev = nullptr;
+    if (tr_on && !tr_dev) (void)hipMalloc(reinterpret_cast<void**>(&tr_dev), 16 * 8);
     hipLaunchKernelGGL(tail_kernel, dim3(a.B), dim3(kTailThreads), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
                        a.tdnn_emb, a.emb, a.scores, a.decisions, a.loss_out, a.demb, a.loss_trace, a.decision_trace,
-                       a.success);
+                       a.success, tr_on ? tr_dev : nullptr);
+    if (tr_on && tr_dev && hipStreamSynchronize(s) == hipSuccess) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, tr_dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "tail phases (us):");
+            for (int i = 1; i <= 12; ++i) fprintf(stderr, " %d:%.2f", i, (double)(h[i] - h[i - 1]) * 0.01);
+            fprintf(stderr, "  total %.2f\n", (double)(h[12] - h[0]) * 0.01);
+        }
+    }
     return hipGetLastError();
 }
 
