@@ -550,6 +550,56 @@ def test_full_size_pgd_properties(hip_model, dev):
     assert moved > 0.99
 
 
+def test_full_size_shard_invariance_down_to_eight(hip_model, dev):
+    """BASELINE metric shape (64 x 3 s) cut the way 2, 4 and 8 GPUs would cut it: the shards of 32 / 16 / 8 utterances run
+    different contraction kernels (round-2 stream-K variants, 32-row tiles) and must still reproduce the full batch
+    bit for bit -- audio, scores and success flags."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    B, eps = 64, 0.002
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=4321)).to(dev)
+    y = hip_model.make_decision(x)[0]
+    lower, upper = torch.clamp(x - eps, min=-1), torch.clamp(x + eps, max=1)
+    spec = SEC4SR_CrossEntropy()
+    run = lambda sl: hip_model.pgd_run(x[sl], y[sl], lower[sl], upper[sl], spec, 0.0004, 2, 1)
+    full = run(slice(0, B))
+    for world in (2, 4, 8):
+        n = B // world
+        parts = [run(slice(r * n, (r + 1) * n)) for r in range(world)]
+        assert torch.equal(full[0], torch.cat([p[0] for p in parts])), "audio differs when cut into %d shards" % world
+        assert torch.equal(full[3], torch.cat([p[3] for p in parts])) and torch.equal(full[1], torch.cat([p[1] for p in parts]))
+    # one utterance alone (the reference's default batch_size = 1) too
+    one = run(slice(5, 6))
+    assert torch.equal(one[0], full[0][5:6]) and torch.equal(one[3], full[3][5:6])
+    log("full-size shard invariance: 64 == 2x32 == 4x16 == 8x8 == single utterances, bit for bit")
+
+
+def test_size_independent_attack_identities(hip_model, dev):
+    """Properties that hold at any size, checked at 64 x 3 s: a zero step leaves the audio untouched; FGSM is PGD with one
+    step of size epsilon (FGSM.py:35-36); an int16-scaled copy of the batch is attacked identically up to the scale
+    (check_input_range, model/utils.py:7-19, decides once per batch)."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FGSM import FGSM
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    B, eps = 64, 0.002
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=777)).to(dev)
+    y = hip_model.make_decision(x)[0]
+    lower, upper = torch.clamp(x - eps, min=-1), torch.clamp(x + eps, max=1)
+    spec = SEC4SR_CrossEntropy()
+    still = hip_model.pgd_run(x, y, lower, upper, spec, 0.0, 2, 1)
+    assert torch.equal(still[0], x)
+    a1, s1 = FGSM(hip_model, epsilon=eps, batch_size=B, verbose=0).attack(x, y)
+    a2, s2 = PGD(hip_model, epsilon=eps, step_size=eps, max_iter=1, batch_size=B, verbose=0).attack(x, y)
+    assert torch.equal(a1, a2) and s1 == s2
+    # the gradient of the int16-scaled waveform is the [-1,1] gradient divided by 2^15 (the model sees the same samples)
+    _, sc_a, _, g_a = hip_model.loss_grad(x, y, spec)
+    _, sc_b, _, g_b = hip_model.loss_grad(x * 32768.0, y, spec)
+    assert torch.equal(sc_a, sc_b)
+    np.testing.assert_allclose((g_b * 32768.0).cpu().numpy(), g_a.cpu().numpy(), rtol=1e-6, atol=0)
+    log("size-independent identities at 64 x 3 s: zero step, FGSM == PGD-1(eps), int16-scale covariance")
+
+
 def test_gradient_is_a_descent_direction_at_full_size(hip_model, dev):
     """Size-independent sanity of the hand-coded backward at B=64 x 3 s: moving a small distance along
     +grad changes the loss by h * |grad| (first-order Taylor).  Margin loss: the cross-entropy saturates
