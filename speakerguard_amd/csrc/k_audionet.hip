@@ -408,16 +408,32 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
     __shared__ float demb[32];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* a = act8 + (size_t)b * T8 * 32;
-    if (tid < 32) {  // x.max(2): first maximum
-        float mx = a[tid];
-        int at = 0;
-        for (int t = 1; t < T8; ++t) {
-            const float v = a[(size_t)t * 32 + tid];
+    {   // x.max(2): first maximum.  Eight time slices per channel (thread = (slice, channel): 32 consecutive floats
+        // per load), each a short chain of loads instead of one chain of T8; slices merged in time order with a strict
+        // >, so the earliest frame still wins ties.
+        __shared__ float pmx[8][32];
+        __shared__ int pat[8][32];
+        const int c = tid & 31, sl = tid >> 5;
+        const int t0 = (int)((long long)T8 * sl / 8), t1 = (int)((long long)T8 * (sl + 1) / 8);
+        float mx = -INFINITY;
+        int at = t0;
+        for (int t = t0; t < t1; ++t) {
+            const float v = a[(size_t)t * 32 + c];
             if (v > mx) { mx = v; at = t; }
         }
-        emb[tid] = mx;
-        arg[tid] = at;
-        if (emb_out) emb_out[(size_t)b * 32 + tid] = mx;
+        pmx[sl][c] = mx;
+        pat[sl][c] = at;
+        __syncthreads();
+        if (tid < 32) {
+            mx = pmx[0][tid];
+            at = pat[0][tid];
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+                if (pmx[i][tid] > mx) { mx = pmx[i][tid]; at = pat[i][tid]; }
+            emb[tid] = mx;
+            arg[tid] = at;
+            if (emb_out) emb_out[(size_t)b * 32 + tid] = mx;
+        }
     }
     __syncthreads();
     for (int s = tid; s < S; s += 256) {
