@@ -446,14 +446,18 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         if (scores_out) scores_out[(size_t)b * S + s] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
-        int64_t dec;
-        const float loss = loss_and_dscores(sc, dsc, S, threshold, y ? y[b] : 0, y != nullptr, ls, &dec);
-        if (dec_out) dec_out[b] = dec;
-        if (dec_trace) dec_trace[b] = dec;
-        if (y && success) success[b] = ls.targeted ? (dec == y[b]) : (dec != y[b]);
-        if (loss_out) loss_out[b] = loss;
-        if (loss_trace) loss_trace[b] = loss;
+    {
+        __shared__ float ex[kLossMaxS];
+        __shared__ float bc[4];
+        int64_t dec = 0;
+        const float loss = loss_and_dscores_block(sc, dsc, ex, bc, S, threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, 256);
+        if (tid == 0) {
+            if (dec_out) dec_out[b] = dec;
+            if (dec_trace) dec_trace[b] = dec;
+            if (y && success) success[b] = ls.targeted ? (dec == y[b]) : (dec != y[b]);
+            if (loss_out) loss_out[b] = loss;
+            if (loss_trace) loss_trace[b] = loss;
+        }
     }
     __syncthreads();
     if (!want_grad || !dact8) return;

@@ -200,14 +200,16 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     __syncthreads();
     TSTAMP(6)
     // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
-    if (tid == 0) {
-        int64_t dec;
-        const float loss = loss_and_dscores(sc, dsc, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec);
-        if (dec_out) dec_out[b] = dec;
-        if (dec_trace) dec_trace[b] = dec;
-        if (y && success) success[b] = ls.targeted ? (dec == y[b]) : (dec != y[b]);
-        if (loss_out) loss_out[b] = loss;
-        if (loss_trace) loss_trace[b] = loss;
+    {
+        int64_t dec = 0;  // scratch: `part` (kTailParts x kMaxD floats >= kMaxS) and `red` (16 floats), both idle here
+        const float loss = loss_and_dscores_block(sc, dsc, part, red, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, NT);
+        if (tid == 0) {
+            if (dec_out) dec_out[b] = dec;
+            if (dec_trace) dec_trace[b] = dec;
+            if (y && success) success[b] = ls.targeted ? (dec == y[b]) : (dec != y[b]);
+            if (loss_out) loss_out[b] = loss;
+            if (loss_trace) loss_trace[b] = loss;
+        }
     }
     __syncthreads();
     TSTAMP(7)

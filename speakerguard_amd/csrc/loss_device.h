@@ -1,5 +1,6 @@
 // Decision + per-example attack loss + d loss / d scores, shared by the x-vector tail and the AudioNet
-// head.  Serial code for ONE thread of the block (the number of classes is small).
+// head: serial code for ONE thread (loss_and_dscores) and a block-cooperative wrapper for the cross-entropy over many
+// classes (loss_and_dscores_block).
 //   decision: argmax, rejected (-1) unless max > threshold     model/iv_plda.py:182-194, audionet_csine.py:246-257
 //   losses:   SEC4SR_CrossEntropy / SEC4SR_MarginLoss           attack/utils.py:7-102
 #pragma once
@@ -87,6 +88,52 @@ __device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, i
             }
         }
     }
+    return loss;
+}
+
+// Block-cooperative form, called by ALL threads of the block (it synchronises); the returned loss and *dec_out are valid
+// on thread 0.  Only the cross-entropy branch differs from the serial function: its 2 S expf evaluations -- 40 us on one
+// thread for the 251 classes of the AudioNet head -- are spread over the block, while every reduction stays on thread 0
+// in index order, so the result is bit-identical to loss_and_dscores.  ex: S floats of LDS scratch, bc: 4 floats.
+__device__ __forceinline__ float loss_and_dscores_block(const float* sc, float* dsc, float* ex, float* bc, int S, float threshold,
+                                                        int64_t yy, bool has_y, const sg_loss_spec& ls, int64_t* dec_out, int tid,
+                                                        int nt) {
+    const bool ce = has_y && ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI && yy >= 0;  // block-uniform
+    if (!ce) {
+        float loss = 0.f;
+        if (tid == 0) loss = loss_and_dscores(sc, dsc, S, threshold, yy, has_y, ls, dec_out);
+        __syncthreads();
+        return loss;
+    }
+    if (tid == 0) {
+        int ja = 0;
+        float mx = sc[0];
+        for (int s = 1; s < S; ++s)
+            if (sc[s] > mx) { mx = sc[s]; ja = s; }
+        *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
+        bc[0] = mx;
+        bc[1] = __int_as_float(ja);
+    }
+    __syncthreads();
+    const float mx = bc[0];
+    const int ja = __float_as_int(bc[1]);
+    for (int s = tid; s < S; s += nt) ex[s] = expf(sc[s] - mx);
+    __syncthreads();
+    float loss = 0.f;
+    if (tid == 0) {
+        float so = 0.f;
+        for (int s = 0; s < S; ++s)
+            if (s != ja) so += ex[s];
+        const float lse = logf(1.f + so);
+        loss = lse - (sc[yy] - mx);
+        bc[2] = lse;
+    }
+    __syncthreads();
+    const float lse = bc[2];
+    for (int s = tid; s < S; s += nt) dsc[s] = expf((sc[s] - mx) - lse);
+    __syncthreads();
+    if (tid == 0) dsc[yy] -= 1.f;
+    __syncthreads();
     return loss;
 }
 
