@@ -118,7 +118,7 @@ def load():
         "sg_eer_threshold": (C.c_int, [vp, vp, i32, vp, i32, vp, vp]),
         "sg_xv_mfcc_backward": (C.c_int, [vp, vp, i32, i32, vp, C.POINTER(Dither), vp, vp, vp]),
         "sg_xv_cmvn_backward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
-        "sg_an_logmel_backward": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+        "sg_an_logmel_backward": (C.c_int, [vp, vp, i32, i32, vp, vp, i32, vp]),
         "sg_feco_kmeans": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         "sg_feco_compress": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "sg_feco_compress_backward": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),

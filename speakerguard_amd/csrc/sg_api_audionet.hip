@@ -227,6 +227,7 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
         if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
         AnTables tab = ctx->an_tab;
         tab.mel_cache = w.mel_cache;  // the backward of this pass starts from the stored mel energies
+        w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T;
         AN_HIP(launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
         feats = w.feats;
     }
@@ -370,27 +371,38 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
     int rc = an_build_tables(ctx);
     if (rc) return rc;
     float* scale = nullptr;
-    if (!ctx->an_ws.scale) {
+    hipStream_t s = (hipStream_t)stream;
+    AnTables tab = ctx->an_tab;
+    if (ctx->an.loaded) {
+        // with a model loaded the workspace is sized for (B, T) anyway: leave the mel energies there so that
+        // sg_an_logmel_backward(reuse_forward) on the same input need not recompute the forward
+        AnDims d;
+        if ((rc = an_check(ctx, B, T, 0, &d))) return rc;
+        AnWorkspace& w = ctx->an_ws;
+        tab.mel_cache = w.mel_cache;
+        w.cache_x = x_dev; w.cache_B = B; w.cache_T = T;
+    } else if (!ctx->an_ws.scale) {
         rc = an_ensure_workspace(ctx, 1, kAnFft, an_num_frames(kAnFft) + 40);
         if (rc) return rc;
     }
     scale = ctx->an_ws.scale;
-    hipStream_t s = (hipStream_t)stream;
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, scale, 1, s));
-    AN_HIP(launch_an_logmel_fwd(ctx->an_tab, x_dev, B, T, an_num_frames(T), scale, feats_dev, s));
+    AN_HIP(launch_an_logmel_fwd(tab, x_dev, B, T, an_num_frames(T), scale, feats_dev, s));
     return SG_OK;
 }
 
 int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* dfeats_dev, float* grad_dev,
-                          void* stream) {
+                          int32_t reuse_forward, void* stream) {
     if (!x_dev || !dfeats_dev || !grad_dev) return an_fail(ctx, SG_ERR_ARG, "bad argument");
     AnDims d;
     int rc = an_check(ctx, B, T, 0, &d);  // sizes the per-frame gradient scratch
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     AnWorkspace& w = ctx->an_ws;
+    AnTables tab = ctx->an_tab;
+    if (reuse_forward && w.cache_x == x_dev && w.cache_B == B && w.cache_T == T) tab.mel_cache = w.mel_cache;
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, w.scale, 1, s));
-    AN_HIP(launch_an_logmel_bwd(ctx->an_tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, s));
+    AN_HIP(launch_an_logmel_bwd(tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, s));
     AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
     return SG_OK;
 }

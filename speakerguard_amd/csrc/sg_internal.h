@@ -88,6 +88,9 @@ struct AnWorkspace {
     float* dfeats = nullptr;   // (B, F, 32)
     float* dframes = nullptr;  // (B, F, 800)
     float* mel_cache = nullptr;  // (B, F, 32) mel energies of the forward pass, kept for the backward of the same pass
+    // which input the mel cache belongs to (sg_an_logmel_backward(reuse_forward) checks pointer and shape, not contents)
+    const float* cache_x = nullptr;
+    int cache_B = 0, cache_T = 0;
     std::vector<void*> allocs;
 };
 

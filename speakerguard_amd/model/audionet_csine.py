@@ -111,7 +111,9 @@ class audionet_csine(EngineOps):
         x = saved
         dfeats = dfeats.to(self.device, torch.float32).contiguous()
         grad = torch.empty_like(x)
-        self.ctx.call("sg_an_logmel_backward", N._ptr(x), x.shape[0], x.shape[2], N._ptr(dfeats), N._ptr(grad),
+        # reuse_forward = 1: `saved` is the tensor frontend_forward just transformed; if another pass has used the
+        # context's mel cache in between (pointer / shape no longer match) the library recomputes the forward by itself
+        self.ctx.call("sg_an_logmel_backward", N._ptr(x), x.shape[0], x.shape[2], N._ptr(dfeats), N._ptr(grad), 1,
                       self._stream())
         return grad
 

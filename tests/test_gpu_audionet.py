@@ -232,3 +232,29 @@ def test_int16_scaled_input_against_reference_run(hip, dev):
     dec, scores = hip.make_decision(x16)
     assert dec.cpu().tolist() == g["int16_decisions"].tolist()
     np.testing.assert_allclose(scores.cpu().numpy(), g["int16_scores"], rtol=1e-3, atol=5e-3)
+
+
+def test_logmel_backward_reusing_the_forward_pass(hip, dev):
+    """sg_an_logmel_backward(reuse_forward=1) starts from the mel energies the last sg_an_logmel left in the workspace;
+    it must give what the recomputing form gives, and must fall back to recomputing when pointer or shape differ."""
+    from speakerguard_amd import _native as N
+    from speakerguard_amd import synth
+    x = torch.from_numpy(synth.make_waveforms(3, 32000, seed=48)).to(dev)
+    other = torch.from_numpy(synth.make_waveforms(3, 32000, seed=49)).to(dev)
+    feats = hip.compute_feat(x)
+    dfe = torch.randn_like(feats)
+
+    def bwd(t, reuse):
+        g = torch.empty_like(t)
+        hip.ctx.call("sg_an_logmel_backward", N._ptr(t), 3, 32000, N._ptr(dfe), N._ptr(g), reuse, N.current_stream_ptr(dev))
+        return g
+
+    hip.compute_feat(x)
+    g_reuse = bwd(x, 1)
+    g_plain = bwd(x, 0)
+    scale = g_plain.abs().max().item()
+    assert (g_reuse - g_plain).abs().max().item() <= 1e-6 * scale
+    # the cache belongs to x: a backward for ANOTHER tensor must not use it even when asked to
+    g_other = bwd(other, 1)
+    assert torch.equal(g_other, bwd(other, 0))
+    assert not torch.allclose(g_other, g_plain)
