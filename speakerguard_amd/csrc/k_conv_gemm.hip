@@ -429,7 +429,6 @@ __device__ __forceinline__ void gemm_segment_q(const ConvGemmArgs& p, float* sme
     };
     if (c_begin < c_end) {
         load_chunk();
-        if (tr && threadIdx.x == 0) tr[7] = __builtin_amdgcn_s_memrealtime();   // first loads issued
         store_chunk(st_ptr0);
         if (c_begin + 1 < c_end) load_chunk();
     }

@@ -75,8 +75,7 @@ rep("whole tile 1 epilogue", 5, 6)
 rep("flag wait + acquire", 8, 9)
 rep("slab read", 9, 10)
 rep("tail piece compute", 10, 11, (C - first_c0).astype(float))
-rep("  tail: setup -> loads issued", 10, 7)
-rep("  tail: loads issued -> prologue done", 7, 13)
+rep("  tail: set-up + first loads -> prologue done", 10, 13)
 rep("  tail: first two chunks", 13, 14)
 rep("  tail: remaining chunks", 14, 11, (C - first_c0 - 2).astype(float))
 rep("tail epilogue", 11, 12)
