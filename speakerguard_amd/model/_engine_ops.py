@@ -36,6 +36,7 @@ class EngineOps:
     _index_base = 0    # global index of the first utterance of the chunk being attacked
     _draw = 0          # passes since begin_batch
     _nes_draw = 0      # NES.forward calls since begin_batch
+    _row_base = 0      # position of this call's row 0 inside the full model call it is a slice of (shard.QueryShardedModel)
 
     def begin_attack(self):
         self._noise_epoch += 1

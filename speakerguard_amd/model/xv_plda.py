@@ -165,7 +165,7 @@ class xv_plda(EngineOps):
     def _dither(self, noise=None, seed=None):
         d = N.Dither()
         d.dither = self.dither
-        d.index_base = 0
+        d.index_base = int(self._row_base)  # 0 unless this call scores a row slice of a larger call (shard.QueryShardedModel)
         d.noise_dev = None if noise is None else noise.data_ptr()
         if seed is not None:  # explicit generator key (tests re-play the fused loop's per-pass seeds)
             d.seed = int(seed) & 0xFFFFFFFFFFFFFFFF

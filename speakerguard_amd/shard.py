@@ -21,6 +21,14 @@ Batch-coupled details that are preserved by construction rather than by communic
     (model/_engine_ops.py): a rank passes its shard offset as ``attacker.index_offset``, so a sharded run
     draws exactly the noise of the unsharded run (tests/test_gpu_xv.py::test_device_noise_is_shard_invariant).
 
+``QueryShardedModel`` is the other cut (BASELINE.json configs[4]: "query batch sharded over 8 x MI355X"): the
+black-box attacks score n * (samples_per_draw + 1) perturbed copies of FEW utterances per iteration
+(adaptive_attack/NES.py:19-34), so the ROWS OF ONE MODEL CALL are split over the ranks and the per-row results
+(decision, scores, loss -- and the gradient when one is asked for) are all-gathered: one real exchange per model
+call, a few hundred bytes per query.  Everything around the call (query construction, the loss-weighted noise
+average, the FAKEBOB step) is cheap elementwise work that every rank repeats on identical data, so the attack
+state stays replicated without further communication.
+
 Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
 """
 import numpy as np
@@ -120,3 +128,76 @@ class ShardedAttack:
         if self.gather_audio:
             adv = self._gather_rows(adv.contiguous(), bounds, n)
         return adv, [bool(v) for v in all_flags.tolist()]
+
+
+def row_slices(n, world):
+    """[start, end) of the rows of one model call per rank.  A rank that would get nothing (n < world) re-scores
+    row 0 and its result is dropped: every rank makes the same sequence of model calls, so per-call state (the
+    front-end's noise draw counter) stays aligned over ranks."""
+    return [(s, e) if e > s else (0, 1) for s, e in shard_bounds(n, world)], shard_bounds(n, world)
+
+
+class QueryShardedModel:
+    """Model proxy that splits the rows of every ``loss_grad`` call over the ranks of `group` and all-gathers the
+    per-row results.  Use it as the model of a black-box attack -- ``FAKEBOB(QueryShardedModel(model), ...)`` -- with
+    identical (x, y) on every rank: each rank returns the full result.  Row r of a call is computed exactly as in
+    the unsharded call (per-row arithmetic does not depend on batch composition; device noise is keyed by the
+    row's position in the FULL call through ``_row_base``), so the sharded attack reproduces the single-GPU one
+    bit for bit (tests/test_shard_gloo.py on the CPU double, tests/test_gpu_xv.py with emulated ranks)."""
+
+    def __init__(self, model, group=None):
+        self.model = model
+        self.base_model = getattr(model, 'base_model', model)
+        self.group = group
+
+    def __getattr__(self, name):  # threshold, make_decision, nes_queries, fakebob_step, ...: the wrapped model's
+        return getattr(self.model, name)
+
+    def eval(self):
+        return self
+
+    def _world(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1, 0
+        return dist.get_world_size(self.group), dist.get_rank(self.group)
+
+    def _call_rows(self, x, y, loss_spec, lo, hi, want_grad, kw):
+        base = self.base_model
+        had = hasattr(base, '_row_base')
+        if had:
+            base._row_base = lo
+        try:
+            return self.model.loss_grad(x[lo:hi], y[lo:hi], loss_spec, want_grad=want_grad, **kw)
+        finally:
+            if had:
+                base._row_base = 0
+
+    def loss_grad(self, x, y, loss_spec, want_grad=True, **kw):
+        world, rank = self._world()
+        if world == 1:
+            return self.model.loss_grad(x, y, loss_spec, want_grad=want_grad, **kw)
+        n = x.shape[0]
+        run, keep = row_slices(n, world)
+        dec, scores, loss, grad = self._call_rows(x, y, loss_spec, run[rank][0], run[rank][1], want_grad, kw)
+        # one exchange for (decision, loss, scores): packed as float32 columns (decisions are small integers)
+        S = scores.shape[1]
+        width = max(e - s for s, e in run)
+        pack = torch.zeros(width, S + 2, dtype=torch.float32, device=scores.device)
+        m = dec.shape[0]
+        pack[:m, 0] = dec.to(torch.float32)
+        pack[:m, 1] = loss
+        pack[:m, 2:] = scores
+        parts = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(parts, pack, group=self.group)
+        full = torch.cat([p[: e - s] for p, (s, e) in zip(parts, keep)], 0)
+        out_dec = full[:, 0].round().to(torch.int64)
+        out_loss = full[:, 1].contiguous()
+        out_scores = full[:, 2:].contiguous()
+        out_grad = None
+        if want_grad:
+            gpad = torch.zeros((width,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
+            gpad[:m] = grad
+            gparts = [torch.empty_like(gpad) for _ in range(world)]
+            dist.all_gather(gparts, gpad, group=self.group)
+            out_grad = torch.cat([p[: e - s] for p, (s, e) in zip(gparts, keep)], 0)
+        return out_dec, out_scores, out_loss, out_grad

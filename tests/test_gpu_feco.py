@@ -139,7 +139,7 @@ def test_gradient_through_feco_matches_oracle_autograd(hip_model, oracle_model, 
         level, same, err, (scores.cpu() - sc.detach()).abs().max().item()))
     assert dec.cpu().tolist() == sc.argmax(1).tolist()
     assert (scores.cpu() - sc.detach()).abs().max().item() < 5e-3
-    # Stage by stage (tools/feco_debug.py) the FeCo and MFCC backward are exact given the oracle's upstream
+    # Stage by stage (tests/tools/feco_debug.py) the FeCo and MFCC backward are exact given the oracle's upstream
     # gradient (0 and 2.5e-6); what remains is the TDNN's own fp32 behaviour: one ReLU whose pre-activation is
     # within round-off of 0 flips between the two implementations and changes the gradient of its receptive
     # field (seen at flag 2: 0.1 % of the samples, 6e-3 of max).  Hence a bulk tolerance plus a bound on outliers.

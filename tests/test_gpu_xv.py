@@ -801,6 +801,64 @@ def test_device_noise_is_shard_invariant(xv_weights, dev):
     log("device noise (dither + NES) shard-invariant: halves == full batch bit for bit")
 
 
+def test_query_sharded_model_call_is_the_unsharded_call(xv_weights, dev):
+    """BASELINE.json configs[4] (query batch sharded over the GPUs): speakerguard_amd.shard.QueryShardedModel splits
+    the ROWS of one model call over the ranks.  The exchange itself is covered on the CPU by a 2-rank gloo test
+    (tests/test_shard_gloo.py); here the ranks are emulated one after the other on the one GPU, with the random
+    dither of the reference's default front-end on: every row slice (2, 3 and 8 ranks, uneven cuts, more ranks than
+    rows) must reproduce its rows of the full call bit for bit, and FAKEBOB on the sliced model must be FAKEBOB on
+    the plain one."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.xv_plda import xv_plda
+    from speakerguard_amd.shard import QueryShardedModel, row_slices
+
+    class SerialRanks(QueryShardedModel):
+        """world emulated ranks, one after the other; every rank starts from the same per-call draw counter."""
+        world = 2
+
+        def loss_grad(self, x, y, loss_spec, want_grad=True, **kw):
+            base = self.base_model
+            run, keep = row_slices(x.shape[0], self.world)
+            draw0, outs = base._draw, []
+            for (lo, hi), (ks, ke) in zip(run, keep):
+                base._draw = draw0
+                out = self._call_rows(x, y, loss_spec, lo, hi, want_grad, kw)
+                outs.append([None if t is None else t[: ke - ks] for t in out])
+            return tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs], 0) for i in range(4))
+
+    md = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=11)
+    x = torch.from_numpy(synth.make_waveforms(7, 16000, seed=41)).to(dev)
+    y = (torch.arange(7) % 10).to(dev)
+    spec = SEC4SR_CrossEntropy()
+    md._draw = 0
+    full = md.loss_grad(x, y, spec, want_grad=True)
+    proxy = SerialRanks(md)
+    for world in (2, 3, 8):
+        proxy.world = world
+        md._draw = 0
+        got = proxy.loss_grad(x, y, spec, want_grad=True)
+        assert md._draw == 1 and md._row_base == 0
+        for a, b in zip(got, full):
+            assert torch.equal(a, b), world
+    md._draw = 0
+    md._row_base = 3  # the row key matters: the same rows scored as "rows 3.." see other noise
+    assert not torch.equal(md.loss_grad(x[:2], y[:2], spec, want_grad=False)[1], full[1][:2])
+    md._row_base = 0
+
+    kw = dict(task="CSI", epsilon=0.002, max_iter=3, samples_per_draw=6, samples_per_draw_batch_size=6, batch_size=2,
+              EOT_size=2, EOT_batch_size=2, verbose=0)
+    md._noise_epoch = 0
+    ref_adv, ref_succ = FAKEBOB(md, **kw).attack(x[:2], y[:2])
+    for world in (2, 8):
+        proxy.world = world
+        md._noise_epoch = 0
+        adv, succ = FAKEBOB(proxy, **kw).attack(x[:2], y[:2])
+        assert torch.equal(adv, ref_adv) and list(succ) == list(ref_succ), world
+    log("query-sharded model call (2 / 3 / 8 emulated ranks, dither on, EOT 2): rows and FAKEBOB result bit-identical")
+
+
 def test_cw2_step_kernel_matches_torch_adam(hip_model, dev):
     """sg_cw2_step vs torch.tanh/atanh + torch.optim.Adam on the same numbers (CW2.py:72-82)."""
     g = torch.Generator().manual_seed(2)

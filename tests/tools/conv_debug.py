@@ -1,7 +1,8 @@
+# Debug aid (imports the oracle as the checker, hence it lives under tests/, not tools/).
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from oracle.conv_rows import conv1d_rows
 from speakerguard_amd import _native as N
 import test_gpu_conv as T

@@ -1,6 +1,7 @@
+# Debug aid (imports the oracle as the checker, hence it lives under tests/, not tools/).
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from speakerguard_amd import synth
 from speakerguard_amd.model.xv_plda import xv_plda
 from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy

@@ -1,3 +1,4 @@
+# Debug aid (imports the oracle as the checker, hence it lives under tests/, not tools/).
 import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np, torch
 from speakerguard_amd import synth
