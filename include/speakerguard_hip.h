@@ -321,11 +321,18 @@ int sg_eer_threshold(sg_ctx* ctx, const float* target_dev, int32_t n_target, con
  * groups and replace every group by the mean of its frames; feats (B,F,D), D <= 64.
  * sg_feco_kmeans: cluster ids (B,F) under this library's determinism contract (k_feco.hip header; the reference
  *   delegates to a randomly initialised third-party k-means, so its ids are not reproducible).
+ * sg_feco_kmeans_seeded: the same clustering started from k distinct RANDOM frames (the reference's third-party k-means
+ *   starts from a random draw of numpy's global generator, kmeans_pytorch initialize(): np.random.choice(F, k,
+ *   replace=False)); here the draw is a function of (seed, index_base + utterance) only -- Philox4x32-10, k_feco.hip
+ *   header -- so a pass is reproducible and independent of the shard layout, and fresh seeds per pass give the
+ *   randomised defense that expectation-over-transformation attacks (adaptive_attack/EOT.py) average over.
  * sg_feco_compress: :204-216 given the ids: out (B,k,D) = cluster means, an empty cluster i takes frame i (the
  *   reference's `force` fallback; with B == 1 the reference drops such rows -- the host compacts using counts).
  * sg_feco_compress_backward: the gradient autograd derives for that step. */
 int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
                    int32_t* assign_dev, void* stream);
+int sg_feco_kmeans_seeded(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
+                          uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream);
 int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_dev, int32_t B, int32_t F, int32_t D,
                      int32_t k, float* out_dev, int32_t* counts_dev, void* stream);
 int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev, const int32_t* counts_dev,

@@ -11,12 +11,13 @@ import numpy as np
 import torch
 
 
-def kmeans_ids(x, k, max_iter=10):
+def kmeans_ids(x, k, max_iter=10, init_frames=None):
     """x (F,D) float32 -> int32 ids (F,).  Sequential-in-d float32 distances, first minimum wins, centroids are
-    float32 sums in ascending frame order divided by the count, empty clusters keep their centroid."""
+    float32 sums in ascending frame order divided by the count, empty clusters keep their centroid.  Centroid j starts
+    at frame floor(j F / k), or at init_frames[j] (the seeded form: oracle.philox.feco_random_init)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     F, D = x.shape
-    c = x[[int(j * F // k) for j in range(k)]].copy()
+    c = x[[int(j * F // k) for j in range(k)] if init_frames is None else [int(f) for f in init_frames]].copy()
     ids = np.full(F, -1, dtype=np.int32)
     for _ in range(max_iter):
         acc = np.zeros((F, k), dtype=np.float32)

@@ -5,7 +5,12 @@
 // The reference calls a third-party k-means with a RANDOM initialisation (libKMCUDA / kmeans_pytorch), so its
 // cluster ids are not reproducible even between two runs of the reference.  The clustering here follows its own
 // DETERMINISM CONTRACT (restated in oracle/feco.py, checked bit for bit):
-//   * k = int(F * ratio) centroids, centroid j initialised to frame floor(j * F / k);
+//   * k = int(F * ratio) centroids, centroid j initialised to frame floor(j * F / k) -- or, for the SEEDED form
+//     (sg_feco_kmeans_seeded: what makes expectation-over-transformation against this defense meaningful, like
+//     the reference's randomly initialised k-means), to the frame of rank j when the frames are ordered by
+//     (Philox4x32-10(counter = (frame, 0, utterance lo, utterance hi), key = seed) word 0, frame) ascending:
+//     k distinct frames, a uniformly random subset in random order, a function of (seed, GLOBAL utterance index)
+//     only (oracle/philox.py feco_random_init);
 //   * assignment: squared L2 distance accumulated over d = 0..D-1 in fp32 without FMA contraction, nearest
 //     centroid wins, ties go to the lowest centroid index;
 //   * stop when no assignment changed or after max_iter assignment steps; otherwise update: centroid j = (sum of its
@@ -17,6 +22,7 @@
 #include <cstdio>
 
 #include "sg_internal.h"
+#include "philox.h"
 
 #pragma clang fp contract(off)
 
@@ -50,7 +56,8 @@ constexpr int kFecoMaxD = 64;
 // Dynamic LDS: cs[k][DPAD], ids[F], cnt[k], start[k + 1], members[F], pd[1024], pj[1024].
 template <int DPAD>
 __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
-                                                           int max_iter, int* __restrict__ assign) {
+                                                           int max_iter, int seeded, uint64_t seed, int64_t index_base,
+                                                           int* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* cs = lds;                                             // [k][DPAD], pad columns zero
     int* ids = reinterpret_cast<int*>(cs + (size_t)k * DPAD);   // [F]
@@ -63,9 +70,30 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
     const int tid = threadIdx.x;
     const float* x = feats + (size_t)blockIdx.x * F * D;
     for (int i = tid; i < F; i += 1024) ids[i] = -1;
+    if (seeded) {
+        // random initialisation: rank the frames by (key, frame); `members` holds the keys, `cnt` the k chosen frames
+        // (both are free until the first update)
+        unsigned* keys = reinterpret_cast<unsigned*>(members);
+        int* chosen = cnt;
+        const int64_t utt = index_base + blockIdx.x;
+        for (int i = tid; i < F; i += 1024)
+            keys[i] = philox4x32_10_w0(seed, (uint32_t)i, 0u, (uint32_t)utt, (uint32_t)((uint64_t)utt >> 32));
+        __syncthreads();
+        for (int i = tid; i < F; i += 1024) {
+            const unsigned ki = keys[i];
+            int rank = 0;
+            for (int g = 0; g < F; ++g) {
+                const unsigned kg = keys[g];
+                rank += (kg < ki) || (kg == ki && g < i);
+            }
+            if (rank < k) chosen[rank] = i;
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < k * DPAD; e += 1024) {
         const int j = e / DPAD, d = e - j * DPAD;
-        cs[e] = d < D ? x[(size_t)(int)((long long)j * F / k) * D + d] : 0.f;
+        const int f0 = seeded ? cnt[j] : (int)((long long)j * F / k);
+        cs[e] = d < D ? x[(size_t)f0 * D + d] : 0.f;
     }
     // thread = (frame slot li, centroid chunk jc); F <= 1024: one pass, the frame stays in registers
     const int fpp = F <= 1024 ? F : 1024;
@@ -205,8 +233,8 @@ __global__ void feco_compress_bwd_kernel(const float* __restrict__ dout, const i
 
 }  // namespace
 
-extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
-                              int32_t max_iter, int32_t* assign_dev, void* stream) {
+static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
+                            int seeded, uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream) {
     if (!ctx) return SG_ERR_ARG;
     if (!feats_dev || !assign_dev || B <= 0 || F <= 0 || D <= 0 || D > kFecoMaxD || k <= 0 || k > F || max_iter <= 0)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: need 0 < k <= F, 0 < D <= %d, max_iter > 0", kFecoMaxD);
@@ -225,13 +253,23 @@ extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, in
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     if (dpad == 32)
         hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
-                           assign_dev);
+                           seeded, seed, index_base, assign_dev);
     else
         hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
-                           assign_dev);
+                           seeded, seed, index_base, assign_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     return SG_OK;
+}
+
+extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
+                              int32_t max_iter, int32_t* assign_dev, void* stream) {
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 0, 0, 0, assign_dev, stream);
+}
+
+extern "C" int sg_feco_kmeans_seeded(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
+                                     int32_t max_iter, uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream) {
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 1, seed, index_base, assign_dev, stream);
 }
 
 extern "C" int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_dev, int32_t B, int32_t F,

@@ -5,9 +5,13 @@
 ``FeCoDefense`` is the same transform as an object with ``fwd`` / ``bwd`` so that ``defended_model`` can chain
 the hand-coded backward through it (adaptive attacks against a FeCo-defended model).
 
-The cluster ids come from the library's deterministic k-means (contract in csrc/k_feco.hip); the reference's
-ids come from a randomly initialised third-party k-means and are not reproducible, so parity with the reference
-exists only for the step after the ids (cluster means + empty-cluster fallback, :204-216).
+The cluster ids come from the library's k-means (contract in csrc/k_feco.hip); the reference's ids come from a
+randomly initialised third-party k-means and are not reproducible, so parity with the reference exists only for
+the step after the ids (cluster means + empty-cluster fallback, :204-216).  ``init='even'`` (default) starts from
+evenly spaced frames: one input, one output.  ``init='random'`` starts every call from k distinct random frames like
+the reference's k-means does -- a randomised defense, the case expectation-over-transformation attacks are for --
+with draws that are a function of (seed, call number, global utterance index) only (Philox4x32-10), i.e.
+reproducible and independent of how a batch is cut into shards (``index_base``).
 'warped_kmeans' and the cosine distance are not built.
 """
 import torch
@@ -18,12 +22,21 @@ from ..metric.metric import _context
 
 class FeCoDefense:
 
-    def __init__(self, param=0.5, method='kmeans', other_param='L2', max_iter=10):
+    def __init__(self, param=0.5, method='kmeans', other_param='L2', max_iter=10, init='even', seed=0):
         if method != 'kmeans':
             raise NotImplementedError('Currently FEATURE COMPRESSION only supports kmeans on the native engine')
         if other_param != 'L2':
             raise NotImplementedError("only the 'L2' distance is built (the reference notes 'cos' works poorly, :178)")
-        self.param, self.max_iter = param, max_iter
+        if init not in ('even', 'random'):
+            raise ValueError("init must be 'even' or 'random'")
+        self.param, self.max_iter, self.init, self.seed = param, max_iter, init, int(seed)
+        self.calls = 0       # fwd calls so far: every call of the randomised defense draws fresh initial frames
+        self.index_base = 0  # global index of row 0 (set by sharded callers)
+
+    def call_seed(self, call):
+        """Generator key of fwd call number `call` (0-based)."""
+        from ..model._engine_ops import mix64
+        return mix64(self.seed ^ 0x4665436F, call)
 
     # ---- forward with saved state ------------------------------------------------------------------
     def fwd(self, feat):
@@ -37,7 +50,13 @@ class FeCoDefense:
         ids = torch.empty(B, F, device=feat.device, dtype=torch.int32)
         out = torch.empty(B, k, D, device=feat.device, dtype=torch.float32)
         counts = torch.empty(B, k, device=feat.device, dtype=torch.int32)
-        ctx.call("sg_feco_kmeans", N._ptr(feat), B, F, D, k, self.max_iter, N._ptr(ids), s)
+        if self.init == 'random':
+            import ctypes as C
+            ctx.call("sg_feco_kmeans_seeded", N._ptr(feat), B, F, D, k, self.max_iter, C.c_uint64(self.call_seed(self.calls)),
+                     int(self.index_base), N._ptr(ids), s)
+        else:
+            ctx.call("sg_feco_kmeans", N._ptr(feat), B, F, D, k, self.max_iter, N._ptr(ids), s)
+        self.calls += 1
         ctx.call("sg_feco_compress", N._ptr(feat), N._ptr(ids), B, F, D, k, N._ptr(out), N._ptr(counts), s)
         force = B > 1  # :33 force=feat.shape[0] > 1
         keep = None

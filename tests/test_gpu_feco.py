@@ -49,6 +49,42 @@ def test_kmeans_ids_bit_exact(hip_model):
         log("FeCo k-means %s: ids bit-exact, empty clusters %d" % (name, int((counts == 0).sum())))
 
 
+def test_seeded_random_init_matches_restatement_and_is_keyed_by_position():
+    """The randomised form of the defense (what EOT attacks average over; the reference's k-means starts from a random
+    draw of numpy's global generator): initial frames from Philox4x32-10 keyed by (seed, call, GLOBAL utterance) --
+    ids bit-exact against oracle.feco.kmeans_ids started from oracle.philox.feco_random_init; a second call draws
+    afresh; a shard that names its offset reproduces its rows of the full batch."""
+    from oracle import feco, philox
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    rs = np.random.RandomState(9)
+    for name, feat, ratio in [("logmel-like 3x300x32", torch.from_numpy((rs.randn(3, 300, 32) * 10 - 40).astype(np.float32)), 0.5),
+                              ("random 2x77x13", torch.from_numpy(rs.randn(2, 77, 13).astype(np.float32)), 0.3),
+                              ("long 1x1500x30", torch.from_numpy((rs.randn(1, 1500, 30) * 3).astype(np.float32)), 0.5)]:
+        B, F, _ = feat.shape
+        k = int(F * ratio)
+        d = FeCoDefense(ratio, init='random', seed=21)
+        d.index_base = 5
+        per_call = []
+        for call in range(2):
+            _, (ids, counts, _, _, _) = d.fwd(feat.to(DEV))
+            ids = ids.cpu().numpy()
+            for b in range(B):
+                init = philox.feco_random_init(d.call_seed(call), 5 + b, F, k)
+                assert len(set(init.tolist())) == k
+                want = feco.kmeans_ids(feat[b].numpy(), k, init_frames=init)
+                assert np.array_equal(ids[b], want), "%s call %d utt %d: %d ids differ" % (name, call, b, (ids[b] != want).sum())
+            per_call.append(ids)
+        assert not np.array_equal(per_call[0], per_call[1]), "every call of the randomised defense draws fresh frames"
+        if B > 1:  # rows 1.. attacked as their own shard
+            tail = FeCoDefense(ratio, init='random', seed=21)
+            tail.index_base = 6
+            _, (ids_t, _, _, _, _) = tail.fwd(feat[1:].to(DEV))
+            assert np.array_equal(ids_t.cpu().numpy(), per_call[0][1:])
+        even = _ids(feat, ratio)[1]
+        assert not np.array_equal(even, per_call[0])
+        log("FeCo k-means, seeded random init %s: ids bit-exact vs Philox restatement; fresh per call; shard-invariant" % name)
+
+
 def test_kmeans_refuses_what_does_not_fit():
     from speakerguard_amd import _native as N
     from speakerguard_amd.defense.feature_level import FeCoDefense

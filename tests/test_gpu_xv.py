@@ -120,6 +120,46 @@ def test_internal_dither_is_reproducible_and_changes_features(xv_weights, dev):
     assert (fa - fc).abs().max().item() > 1e-3
 
 
+def test_device_noise_streams_match_the_philox_restatement(xv_weights, hip_model, dev):
+    """SURVEY 8(a) rows A2 / A16 are "fp32 + RNG".  The reference's draws come from torch's process-global generator
+    and cannot be reproduced by anyone; the engine's streams are a function of (seed, global utterance, frame /
+    pair, sample) only, and oracle/philox.py -- Philox4x32-10, checked against the Random123 known-answer vectors on
+    the CPU -- restates them.  NES normals: compared directly.  Dither: the features computed with the kernel's own
+    draws equal the features computed from the restated noise handed in as an explicit tensor."""
+    from oracle import kaldi_mfcc, philox
+    from speakerguard_amd import synth
+    from speakerguard_amd.model.xv_plda import xv_plda
+    x = torch.from_numpy(synth.make_waveforms(2, 16000, seed=8)).to(dev)
+    T, half, base = 16000, 3, (1 << 33) + 5  # a global example index beyond 32 bits exercises the high counter word
+    _, z = hip_model.nes_queries(x, half, True, 0.001, 11, 4, None, want_noise=True, index_base=base)
+    worst = 0.0
+    for e in range(2):
+        for p in range(half):
+            want = philox.nes_normal(11, base + e, 4 + p, T)
+            worst = max(worst, float(np.abs(z[e, p, 0].cpu().numpy() - want).max()))
+    assert worst < 5e-6, worst  # same 24-bit uniforms; logf / cosf / sqrtf of two libms
+    md = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=3)
+    quiet = x * 1e-3  # quiet input: the dither moves the features visibly
+    md.begin_batch(index_base=6)
+    seed = md.noise_seed(md.dither_seed, 0)
+    own = md.compute_feat(quiet, flag=1)
+    F = kaldi_mfcc.num_frames(T)
+    noise = torch.from_numpy(np.stack([philox.dither_noise(seed, b, F) for b in range(2)])).to(dev)
+    fed = md.compute_feat(quiet, flag=1, dither_noise=noise.contiguous())
+    silent = xv_plda.from_weights(xv_weights, device=dev, dither=0.0).compute_feat(quiet, flag=1)
+    err = float((own - fed).abs().max())
+    assert err < 2e-4 and float((own - silent).abs().max()) > 1e-2, err
+    md._row_base = 4  # rows keyed as rows 4, 5 of a larger call (shard.QueryShardedModel)
+    md._draw = 0
+    own4 = md.compute_feat(quiet, flag=1)
+    md._row_base = 0
+    noise4 = torch.from_numpy(np.stack([philox.dither_noise(seed, 4 + b, F) for b in range(2)])).to(dev)
+    err4 = float((own4 - md.compute_feat(quiet, flag=1, dither_noise=noise4.contiguous())).abs().max())
+    assert err4 < 2e-4 and not torch.equal(own4, own)
+    log("device noise vs Philox restatement: NES normals max |diff| %.2e; MFCC with own dither vs restated noise fed in %.2e"
+        % (worst, max(err, err4)))
+
+
 @pytest.mark.parametrize("tag", ["f300", "f331"])
 def test_cmvn_matches_reference_fixture(hip_model, dev, tag):
     g = load_golden("xv_%s.npz" % tag)
