@@ -338,6 +338,26 @@ int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_
 int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev, const int32_t* counts_dev,
                               int32_t B, int32_t F, int32_t D, int32_t k, int32_t force, float* dfeats_dev, void* stream);
 
+/* BASELINE.json configs[3]: PGD + EOT against the FeCo-defended AudioNet as ONE device-resident loop --
+ * attack/FGSM.py:38-70 attack_batch with the model of model/defended_model.py:46-65 (FeCo at feature level 1:
+ * waveform -> log-mel -> FeCo -> AudioNet CNN) and the gradient chained back through the defense by hand.
+ * k = int(F * cl_r) is computed by the caller (Python float arithmetic, feature_level.py:184).  random_init != 0: every
+ * pass (step it, EOT repeat r) clusters from fresh random frames, key = seed + it * 0x9E3779B97F4A7C15 + r *
+ * 0xC2B2AE3D27D4EB4F (sg_feco_kmeans_seeded), params->eot_size passes per step, gradients summed in pass order.
+ * random_init == 0: deterministic defense, one pass per step.  Needs B >= 2 (with one utterance the reference drops
+ * empty clusters, feature_level.py:209-212: host path).  Outputs as sg_an_pgd_run. */
+typedef struct sg_feco_params {
+    int32_t k;
+    int32_t max_iter;     /* k-means assignment steps */
+    int32_t random_init;
+    uint64_t seed;
+    int64_t index_base;   /* global index of utterance 0 (shard offset) */
+} sg_feco_params;
+int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev,
+                       const float* upper_dev, int32_t B, int32_t T, const sg_pgd_params* params,
+                       const sg_feco_params* feco, uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev,
+                       float* loss_dev, float* loss_trace_dev, int64_t* decision_trace_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ EXPORTS = (
     "sg_xv_loss_grad", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
     "sg_cw2_step", "sg_nes_queries", "sg_nes_grad", "sg_fakebob_step",
     "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
-    "sg_an_pgd_run", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
+    "sg_an_pgd_run", "sg_an_pgd_run_feco", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
     "sg_xv_mfcc_backward", "sg_xv_cmvn_backward", "sg_feco_kmeans", "sg_feco_kmeans_seeded", "sg_feco_compress", "sg_feco_compress_backward",
     "sg_an_logmel_backward", "sg_xv_enroll_override", "sg_health",
 )
@@ -62,6 +62,11 @@ class Dither(C.Structure):
 class PgdParams(C.Structure):
     _fields_ = [("loss", LossSpec), ("step_size", C.c_float), ("max_iter", C.c_int32), ("grad_sign", C.c_int32),
                 ("eot_size", C.c_int32), ("eot_batch_size", C.c_int32), ("dither", Dither)]
+
+
+class FecoParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("max_iter", C.c_int32), ("random_init", C.c_int32), ("seed", C.c_uint64),
+                ("index_base", C.c_int64)]
 
 
 _lib = None
@@ -112,6 +117,8 @@ def load():
         "sg_an_debug_activation": (C.c_int, [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), vp]),
         "sg_an_loss_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, C.POINTER(LossSpec), vp, vp, vp, vp, vp]),
         "sg_an_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
+        "sg_an_pgd_run_feco": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), C.POINTER(FecoParams), vp, vp, vp,
+                                         vp, vp, vp, vp]),
         "sg_xv_time_layer": (C.c_int, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32), vp]),
         "sg_conv1d_rows": (C.c_int, [vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]),
         "sg_wav_finalize": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),

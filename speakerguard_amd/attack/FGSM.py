@@ -45,6 +45,20 @@ class FGSM(Attack):
         self.EOT_wrapper = EOT(self.model, self.loss, self.EOT_size, self.EOT_batch_size, True)
 
     # ---- fused device loop -----------------------------------------------------------------
+    def _fused_feco(self, n_audios):
+        """The FeCoDefense of ``defended_model(base, [(1, FeCoDefense)])`` when the base model runs the defended loop on
+        the device (BASELINE.json configs[3]: audionet_csine.pgd_run_feco), else None."""
+        m = self.model
+        defense = getattr(m, 'defense', None)
+        base = getattr(m, 'base_model', None)
+        if not self.fuse_defended or defense is None or base is None or not hasattr(base, 'pgd_run_feco') or n_audios < 2:
+            return None  # one utterance: the reference drops empty clusters (variable frame count) -> host path
+        if getattr(m, 'order', None) != 'sequential' or len(defense) != 1:
+            return None
+        flag, d = defense[0]
+        from ..defense.feature_level import FeCoDefense
+        return d if flag == 1 and isinstance(d, FeCoDefense) else None
+
     def _can_fuse(self):
         m = self.model
         if getattr(m, 'defense', None) is not None:
@@ -54,11 +68,18 @@ class FGSM(Attack):
         # the engine runs the repeats itself and sums their gradients on the device
         return hasattr(base, 'pgd_run')
 
-    def _attack_batch_fused(self, x_batch, y_batch, lower, upper, batch_id):
+    fuse_defended = True  # False: PGD against a FeCo-defended model runs the host-chained loop (tests compare the two)
+
+    def _attack_batch_fused(self, x_batch, y_batch, lower, upper, batch_id, feco=None):
         base = getattr(self.model, 'base_model', self.model)
-        x_adv, success, dec, scores, loss, ltr, dtr = base.pgd_run(
-            x_batch, y_batch, lower, upper, self.loss, self.step_size, self.max_iter, self.grad_sign,
-            self.EOT_size, self.EOT_batch_size, trace=bool(self.verbose))
+        if feco is not None:
+            x_adv, success, dec, scores, loss, ltr, dtr = base.pgd_run_feco(
+                x_batch, y_batch, lower, upper, self.loss, self.step_size, self.max_iter, self.grad_sign, feco,
+                self.EOT_size, self.EOT_batch_size, trace=bool(self.verbose))
+        else:
+            x_adv, success, dec, scores, loss, ltr, dtr = base.pgd_run(
+                x_batch, y_batch, lower, upper, self.loss, self.step_size, self.max_iter, self.grad_sign,
+                self.EOT_size, self.EOT_batch_size, trace=bool(self.verbose))
         if self.verbose:
             ltr, dtr = ltr.cpu().numpy(), dtr.cpu().numpy()
             target = y_batch.detach().cpu().numpy()
@@ -70,6 +91,9 @@ class FGSM(Attack):
     def attack_batch(self, x_batch, y_batch, lower, upper, batch_id):
         if self._can_fuse():
             return self._attack_batch_fused(x_batch, y_batch, lower, upper, batch_id)
+        feco = self._fused_feco(x_batch.shape[0])
+        if feco is not None:
+            return self._attack_batch_fused(x_batch, y_batch, lower, upper, batch_id, feco=feco)
         x_batch = x_batch.clone()
         lower = lower.expand_as(x_batch).contiguous()
         upper = upper.expand_as(x_batch).contiguous()

@@ -161,6 +161,11 @@ int an_ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
     rc |= an_alloc(ctx, w.allocs, &w.dfeats, b * cf * kAnMel);
     rc |= an_alloc(ctx, w.allocs, &w.dframes, b * cf * kAnWin);
     rc |= an_alloc(ctx, w.allocs, &w.mel_cache, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.feco_ids, b * cf);
+    rc |= an_alloc(ctx, w.allocs, &w.feco_cnt, b * cf);
+    rc |= an_alloc(ctx, w.allocs, &w.feco_out, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.dfeco, b * cf * kAnMel);
+    rc |= an_alloc(ctx, w.allocs, &w.gsum, b * (size_t)(ct > 0 ? ct : 1));
     for (int l = 0; l < kAnConv; ++l) {
         const size_t n = b * (size_t)(Tout[l] > 0 ? Tout[l] : 1) * kAnCout[l];
         rc |= an_alloc(ctx, w.allocs, &w.act[l], n);
@@ -219,19 +224,24 @@ const float* an_layer_input(const AnWorkspace& w, int l) {
     return kAnPool[l - 1] ? w.pool[l - 1] : w.act[l - 1];
 }
 
-int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipStream_t s) {
+// waveform -> log-mel features in ws.feats (the backward of the same pass starts from the stored mel energies)
+int an_frontend_forward(sg_ctx* ctx, const float* x, const AnDims& d, hipStream_t s) {
+    AnWorkspace& w = ctx->an_ws;
+    if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
+    AnTables tab = ctx->an_tab;
+    tab.mel_cache = w.mel_cache;
+    w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T;
+    AN_HIP(launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
+    return SG_OK;
+}
+
+// features (B, Fnet, 32) -> conv stack; Fnet is the frame count the network sees (the front-end's, or the number of
+// FeCo clusters when the defense sits between front-end and network)
+int an_net_forward(sg_ctx* ctx, const float* feats, int B, int Fnet, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
-    const float* feats = x;
-    if (flag == 0) {
-        if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
-        AnTables tab = ctx->an_tab;
-        tab.mel_cache = w.mel_cache;  // the backward of this pass starts from the stored mel energies
-        w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T;
-        AN_HIP(launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
-        feats = w.feats;
-    }
-    AN_HIP(launch_an_prefilter(feats, w.pre, d.B, d.F, m.w25, m.pre_bias, 0, s));
+    an_layer_frames(Fnet, w.Tin, w.Tout);
+    AN_HIP(launch_an_prefilter(feats, w.pre, B, Fnet, m.w25, m.pre_bias, 0, s));
     for (int l = 0; l < kAnConv; ++l) {
         ConvGemmArgs a{};
         a.A = an_layer_input(w, l);
@@ -240,7 +250,7 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
         a.bias = m.bias[l];
         a.Ta = w.Tin[l];
         a.Tc = w.Tout[l];
-        a.M = d.B * a.Tc;
+        a.M = B * a.Tc;
         a.N = kAnCout[l];
         a.Kc = kAnCin[l];
         a.lda = kAnCin[l];
@@ -253,14 +263,23 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
         a.chunks_per_split = a.total_chunks;
         a.Wq = m.wfq[l];
         AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, EPI_BIAS_RELU, 1, s));
-        if (kAnPool[l]) AN_HIP(launch_an_pool_fwd(w.act[l], w.pool[l], d.B, w.Tout[l], kAnCout[l], s));
+        if (kAnPool[l]) AN_HIP(launch_an_pool_fwd(w.act[l], w.pool[l], B, w.Tout[l], kAnCout[l], s));
     }
     return SG_OK;
 }
 
-// d loss / d conv8 pre-activation (ws.dact[6]) -> input level
-int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, float* grad_out, float* x_update,
-                    const float* lower, const float* upper, float step, int grad_sign, hipStream_t s) {
+int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipStream_t s) {
+    const float* feats = x;
+    if (flag == 0) {
+        int rc = an_frontend_forward(ctx, x, d, s);
+        if (rc) return rc;
+        feats = ctx->an_ws.feats;
+    }
+    return an_net_forward(ctx, feats, d.B, d.F, s);
+}
+
+// d loss / d conv8 pre-activation (ws.dact[6]) -> d loss / d features (B, Fnet, 32) in dfeats_out
+int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
     for (int l = kAnConv - 1; l >= 0; --l) {
@@ -273,7 +292,7 @@ int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, floa
         a.mask = (l == 0 || in_pooled) ? nullptr : w.act[l - 1];
         a.Ta = w.Tout[l];
         a.Tc = w.Tin[l];
-        a.M = d.B * a.Tc;
+        a.M = B * a.Tc;
         a.N = kAnCin[l];
         a.Kc = kAnCout[l];
         a.lda = kAnCout[l];
@@ -287,18 +306,32 @@ int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, floa
         a.Wq = m.wbq[l];
         AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, a.mask ? EPI_RELU_MASK : EPI_NONE, 1, s));
         if (in_pooled)
-            AN_HIP(launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], d.B, w.Tout[l - 1], kAnCout[l - 1], s));
+            AN_HIP(launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], B, w.Tout[l - 1], kAnCout[l - 1], s));
     }
-    float* dfeats = flag == 1 ? grad_out : w.dfeats;
-    AN_HIP(launch_an_prefilter(w.dpre, dfeats, d.B, d.F, m.w25, 0.f, 1, s));
-    if (flag == 0) {
-        AnTables tab = ctx->an_tab;
-        tab.mel_cache = w.mel_cache;
-        AN_HIP(launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, w.dfeats, w.dframes, s));
-        AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step,
-                                        grad_sign, s));
-    }
+    AN_HIP(launch_an_prefilter(w.dpre, dfeats_out, B, Fnet, m.w25, 0.f, 1, s));
     return SG_OK;
+}
+
+// d loss / d log-mel (B, F, 32) -> d loss / d waveform: written to grad_out and / or applied as the fused PGD update;
+// accum_in: gradients of earlier EOT repeats of the step, added before either
+int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const float* dfeats, const float* accum_in,
+                         float* grad_out, float* x_update, const float* lower, const float* upper, float step, int grad_sign,
+                         hipStream_t s) {
+    AnWorkspace& w = ctx->an_ws;
+    AnTables tab = ctx->an_tab;
+    tab.mel_cache = w.mel_cache;
+    AN_HIP(launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, dfeats, w.dframes, s));
+    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, accum_in, grad_out, x_update, lower, upper, step,
+                                    grad_sign, s));
+    return SG_OK;
+}
+
+int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, float* grad_out, float* x_update,
+                    const float* lower, const float* upper, float step, int grad_sign, hipStream_t s) {
+    AnWorkspace& w = ctx->an_ws;
+    int rc = an_net_backward(ctx, d.B, d.F, flag == 1 ? grad_out : w.dfeats, s);
+    if (rc || flag == 1) return rc;
+    return an_frontend_backward(ctx, x, d, w.dfeats, nullptr, grad_out, x_update, lower, upper, step, grad_sign, s);
 }
 
 }  // namespace
@@ -403,7 +436,7 @@ int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T,
     if (reuse_forward && w.cache_x == x_dev && w.cache_B == B && w.cache_T == T) tab.mel_cache = w.mel_cache;
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, w.scale, 1, s));
     AN_HIP(launch_an_logmel_bwd(tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, s));
-    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
+    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, nullptr, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
     return SG_OK;
 }
 
@@ -484,6 +517,65 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
                               last ? success_dev : nullptr, s));
         if (!last) {
             rc = an_backward_net(ctx, x_adv_dev, d, 0, nullptr, x_adv_dev, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
+            if (rc) return rc;
+        }
+    }
+    return SG_OK;
+}
+
+int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev, const float* upper_dev,
+                       int32_t B, int32_t T, const sg_pgd_params* p, const sg_feco_params* f, uint8_t* success_dev,
+                       int64_t* decisions_dev, float* scores_dev, float* loss_dev, float* loss_trace_dev,
+                       int64_t* decision_trace_dev, void* stream) {
+    AnDims d;
+    int rc = an_check(ctx, B, T, 0, &d);
+    if (rc) return rc;
+    if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p || !f) return an_fail(ctx, SG_ERR_ARG, "NULL argument");
+    if (p->max_iter < 0) return an_fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
+    // defense/feature_level.py:33: with a single utterance the reference DROPS empty clusters (variable frame count);
+    // that case stays on the host-chained path (model/defended_model.py)
+    if (B < 2) return an_fail(ctx, SG_ERR_ARG, "the fused FeCo loop needs a batch of at least 2 utterances");
+    const int k = f->k;
+    int Tin[kAnConv], Tout[kAnConv];
+    if (k < 1 || k > d.F || f->max_iter < 1 || !an_layer_frames(k, Tin, Tout))
+        return an_fail(ctx, SG_ERR_ARG, "FeCo: need 1 <= k <= %d frames, enough of them for the AudioNet stack, max_iter >= 1", d.F);
+    const int eot_size = p->eot_size > 0 ? p->eot_size : 1, eot_bs = p->eot_batch_size > 0 ? p->eot_batch_size : 1;
+    if (eot_size % eot_bs) return an_fail(ctx, SG_ERR_ARG, "EOT size should be divisible by EOT batch size");
+    // Expectation over the defense's randomness (adaptive_attack/EOT.py:16-54): eot_size passes per gradient step, each
+    // clustering started from fresh random frames, data gradients summed in pass order, sign step on the sum
+    // (sign(mean) == sign(sum)).  The evenly-started clustering is a deterministic function of its input: every
+    // repeat is the same computation, one pass stands for all of them.  The final pass is a single forward.
+    const int reps = f->random_init ? eot_size : 1;
+    hipStream_t s = (hipStream_t)stream;
+    AnWorkspace& w = ctx->an_ws;
+    const int L = kAnConv - 1;
+    for (int it = 0; it <= p->max_iter; ++it) {
+        const bool last = it == p->max_iter;
+        const int nrep = last ? 1 : reps;
+        for (int r = 0; r < nrep; ++r) {
+            d.keep_scale = it > 0 || r > 0;  // iterates stay in [-1, 1]
+            if ((rc = an_frontend_forward(ctx, x_adv_dev, d, s))) return rc;
+            if (f->random_init) {
+                const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xC2B2AE3D27D4EB4Full;
+                rc = sg_feco_kmeans_seeded(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, key, f->index_base, w.feco_ids, s);
+            } else {
+                rc = sg_feco_kmeans(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, w.feco_ids, s);
+            }
+            if (rc) return rc;
+            if ((rc = sg_feco_compress(ctx, w.feats, w.feco_ids, B, d.F, kAnMel, k, w.feco_out, w.feco_cnt, s))) return rc;
+            if ((rc = an_net_forward(ctx, w.feco_out, B, k, s))) return rc;
+            const bool rec = r == 0;  // per-step records: those of the step's first repeat
+            AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
+                                  nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
+                                  w.dact[L], loss_trace_dev && rec ? loss_trace_dev + (size_t)it * B : nullptr,
+                                  decision_trace_dev && rec ? decision_trace_dev + (size_t)it * B : nullptr,
+                                  last ? success_dev : nullptr, s));
+            if (last) break;
+            if ((rc = an_net_backward(ctx, B, k, w.dfeco, s))) return rc;
+            if ((rc = sg_feco_compress_backward(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, w.dfeats, s))) return rc;
+            const bool final_rep = r == nrep - 1;
+            rc = an_frontend_backward(ctx, x_adv_dev, d, w.dfeats, r > 0 ? w.gsum : nullptr, final_rep ? nullptr : w.gsum,
+                                      final_rep ? x_adv_dev : nullptr, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
             if (rc) return rc;
         }
     }

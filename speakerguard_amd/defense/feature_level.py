@@ -39,8 +39,9 @@ class FeCoDefense:
         return mix64(self.seed ^ 0x4665436F, call)
 
     # ---- forward with saved state ------------------------------------------------------------------
-    def fwd(self, feat):
-        """feat (B,F,D) -> (compressed (B,k,D) [or (1,k',D) with empty clusters dropped when B == 1], saved)."""
+    def fwd(self, feat, seed=None):
+        """feat (B,F,D) -> (compressed (B,k,D) [or (1,k',D) with empty clusters dropped when B == 1], saved).
+        `seed`: explicit generator key for this call of the randomised defense (tests replay the fused loop's keys)."""
         feat = feat.to(torch.float32).contiguous()
         if not feat.is_cuda:
             raise N.NativeError("FeCo runs on the HIP device only")
@@ -52,7 +53,8 @@ class FeCoDefense:
         counts = torch.empty(B, k, device=feat.device, dtype=torch.int32)
         if self.init == 'random':
             import ctypes as C
-            ctx.call("sg_feco_kmeans_seeded", N._ptr(feat), B, F, D, k, self.max_iter, C.c_uint64(self.call_seed(self.calls)),
+            key = self.call_seed(self.calls) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+            ctx.call("sg_feco_kmeans_seeded", N._ptr(feat), B, F, D, k, self.max_iter, C.c_uint64(key),
                      int(self.index_base), N._ptr(ids), s)
         else:
             ctx.call("sg_feco_kmeans", N._ptr(feat), B, F, D, k, self.max_iter, N._ptr(ids), s)

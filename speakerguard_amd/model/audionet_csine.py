@@ -161,6 +161,44 @@ class audionet_csine(EngineOps):
                       N._ptr(loss), N._ptr(grad), self._stream())
         return dec, scores, loss, grad
 
+    # per-pass generator keys of the fused FeCo loop (sg_an_pgd_run_feco): step `it`, EOT repeat `r`
+    @staticmethod
+    def fused_pass_seed(base_seed, it, r=0):
+        return (int(base_seed) + it * 0x9E3779B97F4A7C15 + r * 0xC2B2AE3D27D4EB4F) & 0xFFFFFFFFFFFFFFFF
+
+    def pgd_run_feco(self, x, y, lower, upper, loss_spec, step_size, max_iter, grad_sign, feco, eot_size=1, eot_batch_size=1,
+                     trace=False):
+        """attack/FGSM.py:38-70 attack_batch against defended_model(self, [(1, feco)]) (BASELINE.json configs[3]) as one
+        device-resident loop: log-mel -> FeCo -> CNN forward, hand-chained backward, EOT repeats over the defense's
+        random initial frames (``feco.init == 'random'``) summed on the device.  `feco`: a FeCoDefense."""
+        x, B, T = self._prep(x, 0)
+        x_adv = x.clone()
+        y = y.to(self.device, torch.int64).contiguous()
+        lower = lower.to(self.device, torch.float32).expand_as(x).contiguous()
+        upper = upper.to(self.device, torch.float32).expand_as(x).contiguous()
+        p = N.PgdParams()
+        p.loss = loss_spec.native()
+        p.step_size, p.max_iter, p.grad_sign = float(step_size), int(max_iter), int(grad_sign)
+        p.eot_size, p.eot_batch_size = int(eot_size), int(eot_batch_size)
+        f = N.FecoParams()
+        f.k = int(N.load().sg_an_num_frames(T) * feco.param)  # feature_level.py:184
+        f.max_iter = int(feco.max_iter)
+        f.random_init = int(feco.init == 'random')
+        f.seed = feco.call_seed(feco.calls)  # one key per fused call; the passes inside derive theirs from it
+        feco.calls += 1
+        self.last_fused_seed = int(f.seed)
+        f.index_base = int(feco.index_base) + int(self._index_base)
+        success = torch.empty(B, device=self.device, dtype=torch.uint8)
+        dec = torch.empty(B, device=self.device, dtype=torch.int64)
+        scores = torch.empty(B, self.num_spks, device=self.device, dtype=torch.float32)
+        loss = torch.empty(B, device=self.device, dtype=torch.float32)
+        ltr = torch.empty(max_iter + 1, B, device=self.device, dtype=torch.float32) if trace else None
+        dtr = torch.empty(max_iter + 1, B, device=self.device, dtype=torch.int64) if trace else None
+        self.ctx.call("sg_an_pgd_run_feco", N._ptr(x_adv), N._ptr(y), N._ptr(lower), N._ptr(upper), B, T, C.byref(p),
+                      C.byref(f), N._ptr(success), N._ptr(dec), N._ptr(scores), N._ptr(loss), N._ptr(ltr), N._ptr(dtr),
+                      self._stream())
+        return x_adv, success, dec, scores, loss, ltr, dtr
+
     def pgd_run(self, x, y, lower, upper, loss_spec, step_size, max_iter, grad_sign, eot_size=1, eot_batch_size=1,
                 trace=False):
         x, B, T = self._prep(x, 0)

@@ -45,15 +45,29 @@ print("configs[2] CW2 targeted SV, batch 32 x 3 s: %d iterations in %.2f s -> %.
 
 # ---- configs[3]: PGD + EOT vs FeCo-defended AudioNet, 64 utterances per GPU
 an = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)
-dm = defended_model(an, defense=[(1, FeCoDefense(0.5))])
 xa = torch.from_numpy(synth.make_waveforms(64, 48000, seed=3)).to(dev)
-ya = dm.make_decision(xa)[0]
-K = 10
-pgd = PGD(dm, epsilon=0.002, step_size=0.0004, max_iter=K, batch_size=64, EOT_size=2, EOT_batch_size=1, verbose=0)
-pgd.attack(xa[:64], ya)
-(_, succ), dt = timed(lambda: pgd.attack(xa, ya))
-print("configs[3] PGD-%d + EOT 2 vs FeCo-defended AudioNet, batch 64 x 3 s (host-chained gradient): %.2f ms per step (%.2f ms per model pass), %.0f utterance-passes/s"
-      % (K, 1e3 * dt / K, 1e3 * dt / (2 * K + 1), 64 * (2 * K + 1) / dt))
+K = 20
+
+
+def feco_run(label, init, eot, fused, passes_per_step):
+    dm = defended_model(an, defense=[(1, FeCoDefense(0.5, init=init, seed=1))])
+    ya = defended_model(an, defense=[(1, FeCoDefense(0.5))]).make_decision(xa)[0]
+    pgd = PGD(dm, epsilon=0.002, step_size=0.0004, max_iter=K, batch_size=64, EOT_size=eot, EOT_batch_size=1, verbose=0)
+    pgd.fuse_defended = fused
+    pgd.attack(xa, ya)
+    (_, succ), dt = timed(lambda: pgd.attack(xa, ya))
+    n_pass = passes_per_step * K + 1
+    print("configs[3] PGD-%d + EOT %d vs FeCo-defended AudioNet (%s), batch 64 x 3 s: %.2f ms per step (%.2f ms per model pass), "
+          "%.0f utterance-passes/s, success %d/64" % (K, eot, label, 1e3 * dt / K, 1e3 * dt / n_pass, 64 * n_pass / dt, sum(succ)))
+
+
+# the randomised defense (fresh random initial frames per pass): EOT repeats are distinct passes
+feco_run("random-init k-means, host-chained gradient", "random", 2, False, 2)
+feco_run("random-init k-means, ONE device loop sg_an_pgd_run_feco", "random", 2, True, 2)
+# the deterministic defense: its EOT repeats coincide -- the host loop still runs them, the device loop runs one
+feco_run("evenly started k-means, host-chained gradient", "even", 2, False, 2)
+feco_run("evenly started k-means, ONE device loop", "even", 2, True, 1)
+ya = an.make_decision(xa)[0]
 plain = PGD(an, epsilon=0.002, step_size=0.0004, max_iter=K, batch_size=64, verbose=0)
 plain.attack(xa, ya)
 (_, _), dt0 = timed(lambda: plain.attack(xa, ya))
