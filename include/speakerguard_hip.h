@@ -335,6 +335,12 @@ int sg_feco_kmeans_seeded(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_
                           uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream);
 int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_dev, int32_t B, int32_t F, int32_t D,
                      int32_t k, float* out_dev, int32_t* counts_dev, void* stream);
+/* The whole forward of the defense in one launch: the clustering (random_init != 0: seeded form) and the cluster means
+ * with the `force` fallback -- the means ARE the centroids of the clustering's last update (same ids, same ascending
+ * sums), so out / counts equal sg_feco_compress of the returned ids bit for bit. */
+int sg_feco_kmeans_compress(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
+                            int32_t random_init, uint64_t seed, int64_t index_base, int32_t* assign_dev, float* out_dev,
+                            int32_t* counts_dev, void* stream);
 int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev, const int32_t* counts_dev,
                               int32_t B, int32_t F, int32_t D, int32_t k, int32_t force, float* dfeats_dev, void* stream);
 

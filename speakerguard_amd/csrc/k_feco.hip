@@ -41,6 +41,24 @@ int feco_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 constexpr int kFecoMaxD = 64;
+__host__ __device__ constexpr int al4(int n) { return (n + 3) & ~3; }
+typedef float float2v __attribute__((ext_vector_type(2)));
+// centroid j, dimension d inside the pair-interleaved image (rows of 2 * DPAD floats)
+#define CS_AT(j, d) ((size_t)((j) >> 1) * (2 * DPAD) + 2 * (size_t)(d) + ((j) & 1))
+
+// (x.lo - c.lo, x.lo - c.hi) and (x.hi - c.lo, x.hi - c.hi): one v_pk_add_f32 each.  The operand-select bits broadcast
+// one half of the x register pair to both lanes and the neg bits turn the add into an IEEE subtraction, so no
+// register is spent on splats (hipcc builds them with v_mov pairs and spills at 1024 threads per block).
+__device__ __forceinline__ float2v pk_sub_xlo(float2v x, float2v c) {
+    float2v r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float2v pk_sub_xhi(float2v x, float2v c) {
+    float2v r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(c));
+    return r;
+}
 
 // One 1024-thread block per utterance.  Round 1 kept frames and centroids in LDS and gave every thread a frame whose
 // D floats it re-read from LDS for every centroid: at D = 32 the 64 lanes of a wave hit ONE bank (stride 32 words) --
@@ -52,24 +70,46 @@ constexpr int kFecoMaxD = 64;
 //     wins ties;
 //   * the update walks per-cluster member lists (built by a stable counting pass: ascending frame order, as the
 //     contract demands) instead of scanning all F ids for each of the k x D centroid entries.
+//   * the assignment is VALU-bound on the one CU an utterance gets (F x k x D x {sub, mul, add}: 4.3 M lane-operations at
+//     300 x 150 x 32 = 28 us per assignment step at 64 lanes per clock): centroids are kept in PAIRS, interleaved
+//     per dimension ([pair][d][2]), and a thread measures its frame against both centroids of a pair with packed-fp32
+//     instructions (v_pk_add_f32 / v_pk_mul_f32: two lane-operations per lane and clock) -- per centroid still
+//     sub, mul, add in ascending d with separate roundings, so the distances are the same bits.
+//   * what was left after that was LATENCY: the member lists were built by one thread per cluster walking all F ids
+//     (one LDS round trip per id), their offsets by thread 0 walking all k counts, and the update summed its members
+//     through a chain of dependent L2 loads -- together ~20 us of the ~30 us an iteration took.  Now the counts come
+//     from LDS atomics (one per frame), every cluster adds up the counts below it with 16-byte broadcast reads, every
+//     FRAME finds its own slot (number of earlier frames with its id: 16-byte reads again -- ascending frame order
+//     inside a cluster by construction), and the frames are staged in LDS once so the update never leaves the CU
+//     (utterances too long for that keep reading HBM / L2).
+//   * the cluster means the reference takes next (feature_level.py:204-216) ARE the centroids of the last update --
+//     same ids, same ascending sums, same division -- so the kernel can hand them out itself (out / counts, an empty
+//     cluster i taking frame i): the separate compress launch walked all F ids per output element (28 us).
 // Same arithmetic, same order, same ids as before (oracle/feco.py restates the contract; tests compare bit for bit).
-// Dynamic LDS: cs[k][DPAD], ids[F], cnt[k], start[k + 1], members[F], pd[1024], pj[1024].
+// Dynamic LDS (every array 16-byte aligned): cs[ceil(k/2)][DPAD][2], ids[F], cnt[k], start[k + 1], members[F], pd[1024],
+// pj[1024], xs[F][D] (when it fits).
 template <int DPAD>
 __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
                                                            int max_iter, int seeded, uint64_t seed, int64_t index_base,
-                                                           int* __restrict__ assign) {
+                                                           int x_in_lds, int* __restrict__ assign, float* __restrict__ out,
+                                                           int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* cs = lds;                                             // [k][DPAD], pad columns zero
-    int* ids = reinterpret_cast<int*>(cs + (size_t)k * DPAD);   // [F]
-    int* cnt = ids + F;                                          // [k]
-    int* start = cnt + k;                                        // [k + 1]
-    int* members = start + k + 1;                                // [F] frames grouped by cluster, ascending inside a group
-    float* pd = reinterpret_cast<float*>(members + F);           // [1024] chunk minima
+    const int npair = (k + 1) >> 1;
+    float* cs = lds;                                             // [npair][DPAD][2], pad columns / odd partner zero
+    int* ids = reinterpret_cast<int*>(cs + (size_t)npair * 2 * DPAD);   // [F]
+    int* cnt = ids + al4(F);                                     // [k]
+    int* start = cnt + al4(k);                                   // [k + 1]
+    int* members = start + al4(k + 1);                           // [F] frames grouped by cluster, ascending inside a group
+    float* pd = reinterpret_cast<float*>(members + al4(F));      // [1024] chunk minima
     int* pj = reinterpret_cast<int*>(pd + 1024);                 // [1024]
+    float* xs = reinterpret_cast<float*>(pj + 1024);             // [F][D] the frames, if x_in_lds
     __shared__ int changed;
     const int tid = threadIdx.x;
     const float* x = feats + (size_t)blockIdx.x * F * D;
-    for (int i = tid; i < F; i += 1024) ids[i] = -1;
+    for (int i = tid; i < al4(F); i += 1024) ids[i] = -1;  // the pad entries stay -1: no cluster
+    if (x_in_lds)
+        for (int e = tid; e < F * D; e += 1024) xs[e] = x[e];
+    const float* xu = x_in_lds ? xs : x;  // what the update reads
     if (seeded) {
         // random initialisation: rank the frames by (key, frame); `members` holds the keys, `cnt` the k chosen frames
         // (both are free until the first update)
@@ -90,20 +130,27 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
         }
         __syncthreads();
     }
-    for (int e = tid; e < k * DPAD; e += 1024) {
+    for (int e = tid; e < npair * 2 * DPAD; e += 1024) {
         const int j = e / DPAD, d = e - j * DPAD;
-        const int f0 = seeded ? cnt[j] : (int)((long long)j * F / k);
-        cs[e] = d < D ? x[(size_t)f0 * D + d] : 0.f;
+        float v = 0.f;
+        if (j < k && d < D) {
+            const int f0 = seeded ? cnt[j] : (int)((long long)j * F / k);
+            v = x[(size_t)f0 * D + d];
+        }
+        cs[CS_AT(j, d)] = v;
     }
     // thread = (frame slot li, centroid chunk jc); F <= 1024: one pass, the frame stays in registers
     const int fpp = F <= 1024 ? F : 1024;
     const int JC = F <= 1024 ? max(1, min(8, 1024 / F)) : 1;
     const int li = tid % fpp, jc = tid / fpp;
     const bool worker = jc < JC;
-    const int jlo = (int)((long long)k * jc / JC), jhi = worker ? (int)((long long)k * (jc + 1) / JC) : 0;
-    float xr[DPAD];
+    const int plo = (int)((long long)npair * jc / JC), phi = worker ? (int)((long long)npair * (jc + 1) / JC) : 0;
+    float2v xr[DPAD / 2];  // the frame, dimensions (2q, 2q + 1) per register pair
 #pragma unroll
-    for (int d = 0; d < DPAD; ++d) xr[d] = (worker && li < F && d < D) ? x[(size_t)li * D + d] : 0.f;
+    for (int q = 0; q < DPAD / 2; ++q) {
+        xr[q].x = (worker && li < F && 2 * q < D) ? x[(size_t)li * D + 2 * q] : 0.f;
+        xr[q].y = (worker && li < F && 2 * q + 1 < D) ? x[(size_t)li * D + 2 * q + 1] : 0.f;
+    }
     __syncthreads();
     for (int it = 0; it < max_iter; ++it) {
         if (tid == 0) changed = 0;
@@ -112,29 +159,33 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
             const int i = f0 + li;
             if (F > fpp) {  // long utterances (several passes): load the frame of this pass
 #pragma unroll
-                for (int d = 0; d < DPAD; ++d) xr[d] = (worker && i < F && d < D) ? x[(size_t)i * D + d] : 0.f;
+                for (int q = 0; q < DPAD / 2; ++q) {
+                    xr[q].x = (worker && i < F && 2 * q < D) ? x[(size_t)i * D + 2 * q] : 0.f;
+                    xr[q].y = (worker && i < F && 2 * q + 1 < D) ? x[(size_t)i * D + 2 * q + 1] : 0.f;
+                }
             }
             float best = INFINITY;
-            int bj = jlo;
+            int bj = 2 * plo;
             if (worker && i < F) {
-                for (int j = jlo; j < jhi; ++j) {
-                    const float4* c4 = reinterpret_cast<const float4*>(cs + (size_t)j * DPAD);
-                    float acc = 0.f;
+                for (int pr = plo; pr < phi; ++pr) {
+                    const float4* c4 = reinterpret_cast<const float4*>(cs + (size_t)pr * 2 * DPAD);
+                    float2v acc = {0.f, 0.f};  // (distance to centroid 2 pr, to centroid 2 pr + 1)
 #pragma unroll
-                    for (int q = 0; q < DPAD / 4; ++q) {  // d ascending; pad dims add +0 (x = c = 0), acc unchanged
-                        const float4 c = c4[q];
-                        float df = xr[4 * q] - c.x;
+                    for (int q = 0; q < DPAD / 2; ++q) {  // d ascending; pad dims add +0 (x = c = 0), acc unchanged
+                        const float4 c = c4[q];            // c[2q] of both centroids, c[2q + 1] of both
+                        const float2v c0 = {c.x, c.y}, c1 = {c.z, c.w};
+                        float2v df = pk_sub_xlo(xr[q], c0);
                         acc = acc + df * df;
-                        df = xr[4 * q + 1] - c.y;
-                        acc = acc + df * df;
-                        df = xr[4 * q + 2] - c.z;
-                        acc = acc + df * df;
-                        df = xr[4 * q + 3] - c.w;
+                        df = pk_sub_xhi(xr[q], c1);
                         acc = acc + df * df;
                     }
-                    if (acc < best) {
-                        best = acc;
-                        bj = j;
+                    if (acc.x < best) {
+                        best = acc.x;
+                        bj = 2 * pr;
+                    }
+                    if (2 * pr + 1 < k && acc.y < best) {
+                        best = acc.y;
+                        bj = 2 * pr + 1;
                     }
                 }
             }
@@ -159,26 +210,34 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
             __syncthreads();
         }
         if (!changed) break;
-        // member lists: thread j counts its frames, thread 0 scans, thread j writes them in ascending frame order
-        for (int j = tid; j < k; j += 1024) {
-            int n = 0;
-            for (int i = 0; i < F; ++i) n += ids[i] == j;
-            cnt[j] = n;
-        }
+        // member lists.  Counts: one LDS atomic per frame.
+        for (int j = tid; j < k; j += 1024) cnt[j] = 0;
         __syncthreads();
-        if (tid == 0) {
+        for (int i = tid; i < F; i += 1024) atomicAdd(&cnt[ids[i]], 1);
+        __syncthreads();
+        // offsets: cluster j adds up the counts below it (16-byte broadcast reads)
+        for (int j = tid; j <= k; j += 1024) {
             int run = 0;
-            for (int j = 0; j < k; ++j) {
-                start[j] = run;
-                run += cnt[j];
+            const int j4 = j & ~3;
+            for (int q = 0; q < j4; q += 4) {
+                const int4 c = *reinterpret_cast<const int4*>(cnt + q);
+                run += c.x + c.y + c.z + c.w;
             }
-            start[k] = run;
+            for (int q = j4; q < j; ++q) run += cnt[q];
+            start[j] = run;
         }
         __syncthreads();
-        for (int j = tid; j < k; j += 1024) {
-            int o = start[j];
-            for (int i = 0; i < F; ++i)
-                if (ids[i] == j) members[o++] = i;
+        // slots: frame i goes behind the earlier frames of its cluster -> ascending frame order inside a cluster
+        for (int i = tid; i < F; i += 1024) {
+            const int j = ids[i];
+            int pos = 0;
+            const int i4 = i & ~3;
+            for (int q = 0; q < i4; q += 4) {
+                const int4 v = *reinterpret_cast<const int4*>(ids + q);
+                pos += (v.x == j) + (v.y == j) + (v.z == j) + (v.w == j);
+            }
+            for (int q = i4; q < i; ++q) pos += ids[q] == j;
+            members[start[j] + pos] = i;
         }
         __syncthreads();
         // update: thread (j, d) sums its cluster's frames in ascending frame order; an empty cluster keeps its centroid
@@ -188,11 +247,22 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
             if (d < D && n > 0) {
                 float sum = 0.f;
                 const int o = start[j];
-                for (int m = 0; m < n; ++m) sum = sum + x[(size_t)members[o + m] * D + d];
-                cs[e] = sum / (float)n;
+#pragma unroll 4
+                for (int m = 0; m < n; ++m) sum = sum + xu[(size_t)members[o + m] * D + d];
+                cs[CS_AT(j, d)] = sum / (float)n;
             }
         }
         __syncthreads();
+    }
+    // cnt / cs describe the final ids in both exits: "nothing changed" leaves the previous iteration's lists and means
+    // valid, the max_iter exit has just rebuilt them
+    if (out) {
+        float* o = out + (size_t)blockIdx.x * k * D;
+        for (int e = tid; e < k * D; e += 1024) {
+            const int j = e / D, d = e - j * D;
+            o[e] = cnt[j] > 0 ? cs[CS_AT(j, d)] : x[(size_t)j * D + d];  // feature_level.py:213-214 `force` fallback
+        }
+        for (int j = tid; j < k; j += 1024) counts[(size_t)blockIdx.x * k + j] = cnt[j];
     }
     for (int i = tid; i < F; i += 1024) assign[(size_t)blockIdx.x * F + i] = ids[i];
 }
@@ -234,7 +304,8 @@ __global__ void feco_compress_bwd_kernel(const float* __restrict__ dout, const i
 }  // namespace
 
 static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
-                            int seeded, uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream) {
+                            int seeded, uint64_t seed, int64_t index_base, int32_t* assign_dev, float* out_dev,
+                            int32_t* counts_dev, void* stream) {
     if (!ctx) return SG_ERR_ARG;
     if (!feats_dev || !assign_dev || B <= 0 || F <= 0 || D <= 0 || D > kFecoMaxD || k <= 0 || k > F || max_iter <= 0)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: need 0 < k <= F, 0 < D <= %d, max_iter > 0", kFecoMaxD);
@@ -243,7 +314,11 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     // in registers / HBM.  150 KB of it covers ~23 s at D <= 32, ratio 0.5 (k = 1150); beyond that the call is refused.
     constexpr size_t kLdsMax = 150 * 1024;
     const int dpad = D <= 32 ? 32 : 64;
-    const size_t lds = (size_t)k * dpad * sizeof(float) + ((size_t)2 * F + 2 * (size_t)k + 1) * sizeof(int) + 2 * 1024 * sizeof(float);
+    size_t lds = (size_t)((k + 1) / 2) * 2 * dpad * sizeof(float) +
+                 ((size_t)2 * al4(F) + al4(k) + al4(k + 1)) * sizeof(int) + 2 * 1024 * sizeof(float);
+    const size_t xbytes = (size_t)F * D * sizeof(float);
+    const int x_in_lds = lds + xbytes <= kLdsMax;  // the frames too, so the update never leaves the CU
+    if (x_in_lds) lds += xbytes;
     if (lds > kLdsMax)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: %d clusters x %d dims + %d frames need %zu bytes of LDS (limit %zu): "
                          "utterance too long for one block", k, D, F, lds, kLdsMax);
@@ -253,10 +328,10 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     if (dpad == 32)
         hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
-                           seeded, seed, index_base, assign_dev);
+                           seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
     else
         hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
-                           seeded, seed, index_base, assign_dev);
+                           seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     return SG_OK;
@@ -264,12 +339,20 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
 
 extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
                               int32_t max_iter, int32_t* assign_dev, void* stream) {
-    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 0, 0, 0, assign_dev, stream);
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 0, 0, 0, assign_dev, nullptr, nullptr, stream);
 }
 
 extern "C" int sg_feco_kmeans_seeded(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
                                      int32_t max_iter, uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream) {
-    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 1, seed, index_base, assign_dev, stream);
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 1, seed, index_base, assign_dev, nullptr, nullptr, stream);
+}
+
+extern "C" int sg_feco_kmeans_compress(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
+                                       int32_t max_iter, int32_t random_init, uint64_t seed, int64_t index_base,
+                                       int32_t* assign_dev, float* out_dev, int32_t* counts_dev, void* stream) {
+    if (!out_dev || !counts_dev) return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans_compress: out and counts are required");
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, random_init != 0, seed, index_base, assign_dev, out_dev,
+                            counts_dev, stream);
 }
 
 extern "C" int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_dev, int32_t B, int32_t F,

@@ -555,14 +555,10 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
         for (int r = 0; r < nrep; ++r) {
             d.keep_scale = it > 0 || r > 0;  // iterates stay in [-1, 1]
             if ((rc = an_frontend_forward(ctx, x_adv_dev, d, s))) return rc;
-            if (f->random_init) {
-                const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xC2B2AE3D27D4EB4Full;
-                rc = sg_feco_kmeans_seeded(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, key, f->index_base, w.feco_ids, s);
-            } else {
-                rc = sg_feco_kmeans(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, w.feco_ids, s);
-            }
+            const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xC2B2AE3D27D4EB4Full;
+            rc = sg_feco_kmeans_compress(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, f->random_init, key, f->index_base,
+                                         w.feco_ids, w.feco_out, w.feco_cnt, s);
             if (rc) return rc;
-            if ((rc = sg_feco_compress(ctx, w.feats, w.feco_ids, B, d.F, kAnMel, k, w.feco_out, w.feco_cnt, s))) return rc;
             if ((rc = an_net_forward(ctx, w.feco_out, B, k, s))) return rc;
             const bool rec = r == 0;  // per-step records: those of the step's first repeat
             AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,

@@ -51,15 +51,14 @@ class FeCoDefense:
         ids = torch.empty(B, F, device=feat.device, dtype=torch.int32)
         out = torch.empty(B, k, D, device=feat.device, dtype=torch.float32)
         counts = torch.empty(B, k, device=feat.device, dtype=torch.int32)
+        import ctypes as C
+        key = 0
         if self.init == 'random':
-            import ctypes as C
             key = self.call_seed(self.calls) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
-            ctx.call("sg_feco_kmeans_seeded", N._ptr(feat), B, F, D, k, self.max_iter, C.c_uint64(key),
-                     int(self.index_base), N._ptr(ids), s)
-        else:
-            ctx.call("sg_feco_kmeans", N._ptr(feat), B, F, D, k, self.max_iter, N._ptr(ids), s)
         self.calls += 1
-        ctx.call("sg_feco_compress", N._ptr(feat), N._ptr(ids), B, F, D, k, N._ptr(out), N._ptr(counts), s)
+        # clustering + cluster means (:204-216) in one launch
+        ctx.call("sg_feco_kmeans_compress", N._ptr(feat), B, F, D, k, self.max_iter, int(self.init == 'random'), C.c_uint64(key),
+                 int(self.index_base), N._ptr(ids), N._ptr(out), N._ptr(counts), s)
         force = B > 1  # :33 force=feat.shape[0] > 1
         keep = None
         if not force and bool((counts == 0).any()):

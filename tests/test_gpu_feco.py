@@ -23,9 +23,25 @@ def oracle_model(xv_weights):
     return XvPlda(xv_weights, threshold=None)
 
 
+def _standalone_compress(feat, ids, k):
+    """sg_feco_compress (feature_level.py:204-216 given the ids) as its own launch."""
+    from speakerguard_amd import _native as N
+    from speakerguard_amd.metric.metric import _context
+    B, F, D = feat.shape
+    out = torch.empty(B, k, D, device=DEV)
+    counts = torch.empty(B, k, device=DEV, dtype=torch.int32)
+    _context(DEV).call("sg_feco_compress", N._ptr(feat), N._ptr(ids), B, F, D, k, N._ptr(out), N._ptr(counts),
+                       N.current_stream_ptr(DEV))
+    return out, counts
+
+
 def _ids(feat, ratio=0.5, max_iter=10):
     from speakerguard_amd.defense.feature_level import FeCoDefense
-    out, (ids, counts, dims, force, keep) = FeCoDefense(ratio, max_iter=max_iter).fwd(feat.to(DEV))
+    feat = feat.to(DEV).contiguous()
+    out, (ids, counts, dims, force, keep) = FeCoDefense(ratio, max_iter=max_iter).fwd(feat)
+    if keep is None:  # the means the clustering launch hands out are the standalone compress step of its ids, bit for bit
+        out2, counts2 = _standalone_compress(feat, ids, dims[3])
+        assert torch.equal(out, out2) and torch.equal(counts, counts2)
     return out, ids.cpu().numpy(), counts.cpu().numpy()
 
 
@@ -66,7 +82,9 @@ def test_seeded_random_init_matches_restatement_and_is_keyed_by_position():
         d.index_base = 5
         per_call = []
         for call in range(2):
-            _, (ids, counts, _, _, _) = d.fwd(feat.to(DEV))
+            out, (ids, counts, _, _, _) = d.fwd(feat.to(DEV))
+            out2, counts2 = _standalone_compress(feat.to(DEV).contiguous(), ids, k)
+            assert torch.equal(out, out2) and torch.equal(counts, counts2)
             ids = ids.cpu().numpy()
             for b in range(B):
                 init = philox.feco_random_init(d.call_seed(call), 5 + b, F, k)

@@ -9,8 +9,9 @@ from speakerguard_amd.model.audionet_csine import audionet_csine
 from speakerguard_amd.model.defended_model import defended_model
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+INIT = sys.argv[2] if len(sys.argv) > 2 else "random"   # 'random': the randomised defense (EOT repeats are distinct passes)
 an = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)
-dm = defended_model(an, defense=[(1, FeCoDefense(0.5))])
+dm = defended_model(an, defense=[(1, FeCoDefense(0.5, init=INIT, seed=1))])
 xa = torch.from_numpy(synth.make_waveforms(B, 48000, seed=3)).to(dev)
 ya = dm.make_decision(xa)[0]
 K = 10
@@ -19,4 +20,5 @@ pgd.attack(xa, ya)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 pgd.attack(xa, ya)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("B=%d: %.2f ms per step (%d model passes), %.0f utterance-passes/s" % (B, 1e3 * dt / K, 2 * K + 1, B * (2 * K + 1) / dt))
+n_pass = (2 if INIT == "random" else 1) * K + 1  # the device loop runs the coinciding repeats of the deterministic defense once
+print("B=%d, %s-init FeCo, fused device loop: %.2f ms per step (%d model passes), %.0f utterance-passes/s" % (B, INIT, 1e3 * dt / K, n_pass, B * n_pass / dt))
