@@ -337,10 +337,18 @@ int sg_feco_compress(sg_ctx* ctx, const float* feats_dev, const int32_t* assign_
                      int32_t k, float* out_dev, int32_t* counts_dev, void* stream);
 /* The whole forward of the defense in one launch: the clustering (random_init != 0: seeded form) and the cluster means
  * with the `force` fallback -- the means ARE the centroids of the clustering's last update (same ids, same ascending
- * sums), so out / counts equal sg_feco_compress of the returned ids bit for bit. */
+ * sums), so out / counts equal sg_feco_compress of the returned ids bit for bit.
+ * reps > 1 (seeded form only): the SAME features clustered reps times, repeat r from key seed + r * 0xC2B2AE3D27D4EB4F --
+ * the EOT repeats of an adaptive attack (adaptive_attack/EOT.py:24-25 x_batch.repeat) without repeating the front-end;
+ * assign (reps,B,F), out (reps,B,k,D), counts (reps,B,k).  sg_feco_compress_backward_reps is the matching gradient:
+ * dout (reps,B,k,D) -> dfeats (B,F,D) = sum over the repeats, in repeat order (the compression is linear in the
+ * features, so one front-end adjoint serves all repeats). */
 int sg_feco_kmeans_compress(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
-                            int32_t random_init, uint64_t seed, int64_t index_base, int32_t* assign_dev, float* out_dev,
-                            int32_t* counts_dev, void* stream);
+                            int32_t random_init, uint64_t seed, int64_t index_base, int32_t reps, int32_t* assign_dev,
+                            float* out_dev, int32_t* counts_dev, void* stream);
+int sg_feco_compress_backward_reps(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev, const int32_t* counts_dev,
+                                   int32_t B, int32_t F, int32_t D, int32_t k, int32_t force, int32_t reps,
+                                   float* dfeats_dev, void* stream);
 int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev, const int32_t* counts_dev,
                               int32_t B, int32_t F, int32_t D, int32_t k, int32_t force, float* dfeats_dev, void* stream);
 
@@ -348,9 +356,11 @@ int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, const int32_t*
  * attack/FGSM.py:38-70 attack_batch with the model of model/defended_model.py:46-65 (FeCo at feature level 1:
  * waveform -> log-mel -> FeCo -> AudioNet CNN) and the gradient chained back through the defense by hand.
  * k = int(F * cl_r) is computed by the caller (Python float arithmetic, feature_level.py:184).  random_init != 0: every
- * pass (step it, EOT repeat r) clusters from fresh random frames, key = seed + it * 0x9E3779B97F4A7C15 + r *
- * 0xC2B2AE3D27D4EB4F (sg_feco_kmeans_seeded), params->eot_size passes per step, gradients summed in pass order.
- * random_init == 0: deterministic defense, one pass per step.  Needs B >= 2 (with one utterance the reference drops
+ * gradient step clusters the step's log-mel features params->eot_size times from fresh random frames (repeat r of step
+ * it: key = seed + it * 0x9E3779B97F4A7C15 + r * 0xC2B2AE3D27D4EB4F, sg_feco_kmeans_compress with reps), runs the CNN on
+ * the eot_size x B compressed copies as one batch, sums the repeats' feature-level gradients in repeat order
+ * (sg_feco_compress_backward_reps) and takes the sum through ONE log-mel adjoint: only the defense is random, so the
+ * front-end is not repeated.  random_init == 0: deterministic defense, one pass per step.  Needs B >= 2 (with one utterance the reference drops
  * empty clusters, feature_level.py:209-212: host path).  Outputs as sg_an_pgd_run. */
 typedef struct sg_feco_params {
     int32_t k;

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
 // the reflect padding of torch.stft); d x[t] = d pre[t-1] - 0.97 d pre[t].
 __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __restrict__ dframes, int T, int F,
                                                                 const float* __restrict__ scale_p,
-                                                                const float* accum_in, float* grad_out, float* __restrict__ x_io,
+                                                                float* __restrict__ grad_out, float* __restrict__ x_io,
                                                                 const float* __restrict__ lower,
                                                                 const float* __restrict__ upper, float step, int grad_sign) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -327,7 +327,6 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
     if (t <= Lp - 1) g -= 0.97f * dp[threadIdx.x + 1];
     g *= scale;
     const size_t o = (size_t)b * T + t;
-    if (accum_in) g += accum_in[o];  // gradients of the earlier EOT repeats of this step (may alias grad_out)
     if (grad_out) grad_out[o] = g;
     if (x_io) {
         const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
@@ -500,11 +499,11 @@ hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T,
     else hipLaunchKernelGGL(an_logmel_bwd_kernel<false>, grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes);
     return hipGetLastError();
 }
-hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, const float* accum_in, float* grad_out,
+hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
                                     float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                     hipStream_t s) {
-    hipLaunchKernelGGL(an_frames_to_wave_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, dframes, T, F, scale, accum_in,
-                       grad_out, x_io, lower, upper, step, grad_sign);
+    hipLaunchKernelGGL(an_frames_to_wave_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, dframes, T, F, scale, grad_out,
+                       x_io, lower, upper, step, grad_sign);
     return hipGetLastError();
 }
 hipError_t launch_an_prefilter(const float* in, float* out, int B, int T, const float* w25, float bias, int transpose,

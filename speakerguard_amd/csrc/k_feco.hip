@@ -105,7 +105,11 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
     float* xs = reinterpret_cast<float*>(pj + 1024);             // [F][D] the frames, if x_in_lds
     __shared__ int changed;
     const int tid = threadIdx.x;
+    // blockIdx.y = repeat: the same utterances clustered again from other random frames (EOT over the defense); repeat r
+    // uses key seed + r * 0xC2B2AE3D27D4EB4F and writes slot r * gridDim.x + utterance of every output
     const float* x = feats + (size_t)blockIdx.x * F * D;
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    seed += (uint64_t)blockIdx.y * 0xC2B2AE3D27D4EB4Full;
     for (int i = tid; i < al4(F); i += 1024) ids[i] = -1;  // the pad entries stay -1: no cluster
     if (x_in_lds)
         for (int e = tid; e < F * D; e += 1024) xs[e] = x[e];
@@ -257,14 +261,14 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
     // cnt / cs describe the final ids in both exits: "nothing changed" leaves the previous iteration's lists and means
     // valid, the max_iter exit has just rebuilt them
     if (out) {
-        float* o = out + (size_t)blockIdx.x * k * D;
+        float* o = out + slot * k * D;
         for (int e = tid; e < k * D; e += 1024) {
             const int j = e / D, d = e - j * D;
             o[e] = cnt[j] > 0 ? cs[CS_AT(j, d)] : x[(size_t)j * D + d];  // feature_level.py:213-214 `force` fallback
         }
-        for (int j = tid; j < k; j += 1024) counts[(size_t)blockIdx.x * k + j] = cnt[j];
+        for (int j = tid; j < k; j += 1024) counts[slot * k + j] = cnt[j];
     }
-    for (int i = tid; i < F; i += 1024) assign[(size_t)blockIdx.x * F + i] = ids[i];
+    for (int i = tid; i < F; i += 1024) assign[slot * F + i] = ids[i];
 }
 
 // out[b][j][d] = mean over frames with id j (ascending order) or, for an empty cluster, feats[b][j][d]
@@ -301,13 +305,35 @@ __global__ void feco_compress_bwd_kernel(const float* __restrict__ dout, const i
     dfeats[((size_t)b * F + i) * D + d] = g;
 }
 
+// The same for R repeats of the clustering of the SAME features (EOT over the defense): the compression is linear, so
+// the repeats' gradients wrt the features are summed right here, in repeat order -- one log-mel / MFCC adjoint
+// serves all of them.  dout (R, B, k, D), assign (R, B, F), counts (R, B, k) -> dfeats (B, F, D).
+__global__ void feco_compress_bwd_reps_kernel(const float* __restrict__ dout, const int* __restrict__ assign,
+                                              const int* __restrict__ counts, int B, int F, int D, int k, int force, int R,
+                                              float* __restrict__ dfeats) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= F * D) return;
+    const int i = e / D, d = e - i * D;
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const size_t u = (size_t)r * B + b;
+        const int j = assign[u * F + i];
+        float g = dout[(u * k + j) * D + d] / (float)counts[u * k + j];
+        if (force && i < k && counts[u * k + i] == 0) g = g + dout[(u * k + i) * D + d];
+        acc = r == 0 ? g : acc + g;
+    }
+    dfeats[((size_t)b * F + i) * D + d] = acc;
+}
+
 }  // namespace
 
 static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k, int32_t max_iter,
-                            int seeded, uint64_t seed, int64_t index_base, int32_t* assign_dev, float* out_dev,
+                            int seeded, uint64_t seed, int64_t index_base, int reps, int32_t* assign_dev, float* out_dev,
                             int32_t* counts_dev, void* stream) {
     if (!ctx) return SG_ERR_ARG;
-    if (!feats_dev || !assign_dev || B <= 0 || F <= 0 || D <= 0 || D > kFecoMaxD || k <= 0 || k > F || max_iter <= 0)
+    if (!feats_dev || !assign_dev || B <= 0 || F <= 0 || D <= 0 || D > kFecoMaxD || k <= 0 || k > F || max_iter <= 0 || reps < 1 ||
+        reps > 65535)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: need 0 < k <= F, 0 < D <= %d, max_iter > 0", kFecoMaxD);
     if (hipSetDevice(ctx->device) != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: hipSetDevice failed");
     // LDS holds the centroids (rows padded to 32 / 64 floats), ids, member lists and the chunk minima; the frames stay
@@ -327,10 +353,10 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     if (dpad == 32)
-        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
+        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B, reps), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
                            seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
     else
-        hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
+        hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B, reps), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
                            seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
@@ -339,19 +365,21 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
 
 extern "C" int sg_feco_kmeans(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
                               int32_t max_iter, int32_t* assign_dev, void* stream) {
-    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 0, 0, 0, assign_dev, nullptr, nullptr, stream);
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 0, 0, 0, 1, assign_dev, nullptr, nullptr, stream);
 }
 
 extern "C" int sg_feco_kmeans_seeded(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
                                      int32_t max_iter, uint64_t seed, int64_t index_base, int32_t* assign_dev, void* stream) {
-    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 1, seed, index_base, assign_dev, nullptr, nullptr, stream);
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, 1, seed, index_base, 1, assign_dev, nullptr, nullptr, stream);
 }
 
 extern "C" int sg_feco_kmeans_compress(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, int32_t D, int32_t k,
-                                       int32_t max_iter, int32_t random_init, uint64_t seed, int64_t index_base,
+                                       int32_t max_iter, int32_t random_init, uint64_t seed, int64_t index_base, int32_t reps,
                                        int32_t* assign_dev, float* out_dev, int32_t* counts_dev, void* stream) {
     if (!out_dev || !counts_dev) return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans_compress: out and counts are required");
-    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, random_init != 0, seed, index_base, assign_dev, out_dev,
+    if (reps > 1 && !random_init)
+        return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans_compress: repeats of the evenly started clustering coincide (reps must be 1)");
+    return feco_kmeans_impl(ctx, feats_dev, B, F, D, k, max_iter, random_init != 0, seed, index_base, reps, assign_dev, out_dev,
                             counts_dev, stream);
 }
 
@@ -380,5 +408,20 @@ extern "C" int sg_feco_compress_backward(sg_ctx* ctx, const float* dout_dev, con
                        assign_dev, counts_dev, F, D, k, force, dfeats_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_compress_backward: %s", hipGetErrorString(e));
+    return SG_OK;
+}
+
+extern "C" int sg_feco_compress_backward_reps(sg_ctx* ctx, const float* dout_dev, const int32_t* assign_dev,
+                                              const int32_t* counts_dev, int32_t B, int32_t F, int32_t D, int32_t k,
+                                              int32_t force, int32_t reps, float* dfeats_dev, void* stream) {
+    if (!ctx) return SG_ERR_ARG;
+    if (!dout_dev || !assign_dev || !counts_dev || !dfeats_dev || B <= 0 || F <= 0 || D <= 0 || k <= 0 || k > F || reps < 1)
+        return feco_fail(ctx, SG_ERR_ARG, "sg_feco_compress_backward_reps: bad arguments");
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return feco_fail(ctx, SG_ERR_HIP, "sg_feco_compress_backward_reps: hipSetDevice failed");
+    hipLaunchKernelGGL(feco_compress_bwd_reps_kernel, dim3((F * D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dout_dev,
+                       assign_dev, counts_dev, B, F, D, k, force, reps, dfeats_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_compress_backward_reps: %s", hipGetErrorString(e));
     return SG_OK;
 }

@@ -165,7 +165,9 @@ int an_ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
     rc |= an_alloc(ctx, w.allocs, &w.feco_cnt, b * cf);
     rc |= an_alloc(ctx, w.allocs, &w.feco_out, b * cf * kAnMel);
     rc |= an_alloc(ctx, w.allocs, &w.dfeco, b * cf * kAnMel);
-    rc |= an_alloc(ctx, w.allocs, &w.gsum, b * (size_t)(ct > 0 ? ct : 1));
+    rc |= an_alloc(ctx, w.allocs, &w.y_rep, b);
+    rc |= an_alloc(ctx, w.allocs, &w.trace_l, b);
+    rc |= an_alloc(ctx, w.allocs, &w.trace_d, b);
     for (int l = 0; l < kAnConv; ++l) {
         const size_t n = b * (size_t)(Tout[l] > 0 ? Tout[l] : 1) * kAnCout[l];
         rc |= an_alloc(ctx, w.allocs, &w.act[l], n);
@@ -312,17 +314,14 @@ int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t
     return SG_OK;
 }
 
-// d loss / d log-mel (B, F, 32) -> d loss / d waveform: written to grad_out and / or applied as the fused PGD update;
-// accum_in: gradients of earlier EOT repeats of the step, added before either
-int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const float* dfeats, const float* accum_in,
-                         float* grad_out, float* x_update, const float* lower, const float* upper, float step, int grad_sign,
+// d loss / d log-mel (B, F, 32) -> d loss / d waveform: written to grad_out and / or applied as the fused PGD update
+int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const float* dfeats, float* grad_out, float* x_update, const float* lower, const float* upper, float step, int grad_sign,
                          hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
     AN_HIP(launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, dfeats, w.dframes, s));
-    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, accum_in, grad_out, x_update, lower, upper, step,
-                                    grad_sign, s));
+    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step, grad_sign, s));
     return SG_OK;
 }
 
@@ -331,7 +330,7 @@ int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, floa
     AnWorkspace& w = ctx->an_ws;
     int rc = an_net_backward(ctx, d.B, d.F, flag == 1 ? grad_out : w.dfeats, s);
     if (rc || flag == 1) return rc;
-    return an_frontend_backward(ctx, x, d, w.dfeats, nullptr, grad_out, x_update, lower, upper, step, grad_sign, s);
+    return an_frontend_backward(ctx, x, d, w.dfeats, grad_out, x_update, lower, upper, step, grad_sign, s);
 }
 
 }  // namespace
@@ -436,7 +435,7 @@ int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T,
     if (reuse_forward && w.cache_x == x_dev && w.cache_B == B && w.cache_T == T) tab.mel_cache = w.mel_cache;
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, w.scale, 1, s));
     AN_HIP(launch_an_logmel_bwd(tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, s));
-    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, nullptr, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
+    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
     return SG_OK;
 }
 
@@ -527,53 +526,62 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
                        int32_t B, int32_t T, const sg_pgd_params* p, const sg_feco_params* f, uint8_t* success_dev,
                        int64_t* decisions_dev, float* scores_dev, float* loss_dev, float* loss_trace_dev,
                        int64_t* decision_trace_dev, void* stream) {
-    AnDims d;
-    int rc = an_check(ctx, B, T, 0, &d);
-    if (rc) return rc;
+    if (!ctx) return SG_ERR_ARG;
     if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p || !f) return an_fail(ctx, SG_ERR_ARG, "NULL argument");
     if (p->max_iter < 0) return an_fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
     // defense/feature_level.py:33: with a single utterance the reference DROPS empty clusters (variable frame count);
     // that case stays on the host-chained path (model/defended_model.py)
     if (B < 2) return an_fail(ctx, SG_ERR_ARG, "the fused FeCo loop needs a batch of at least 2 utterances");
+    const int eot_size = p->eot_size > 0 ? p->eot_size : 1, eot_bs = p->eot_batch_size > 0 ? p->eot_batch_size : 1;
+    if (eot_size % eot_bs) return an_fail(ctx, SG_ERR_ARG, "EOT size should be divisible by EOT batch size");
+    // Expectation over the defense's randomness (adaptive_attack/EOT.py:16-54): eot_size clusterings per gradient step,
+    // each started from fresh random frames.  The reference repeats the batch (x_batch.repeat, EOT.py:24) and runs the
+    // whole model on the copies; only the DEFENSE is random here, so the log-mel front-end runs once per step, the R
+    // clusterings and the CNN run as one batch of R x B, and because the compression is linear in the features the
+    // repeats' gradients are summed at the feature level (repeat order) and ONE log-mel adjoint + overlap-add takes the
+    // sum to the waveform: sign(sum) == sign(mean).  (EOT_batch_size only says how the reference cuts the repeats into
+    // model calls.)  The evenly started clustering is a deterministic function of its input: every repeat is the same
+    // computation, one stands for all.  The final pass is a single forward.
+    const int reps = f->random_init ? eot_size : 1;
+    AnDims d;
+    int rc = an_check(ctx, B * reps, T, 0, &d);  // workspace for the batch of R x B rows
+    if (rc) return rc;
+    d.B = B;
     const int k = f->k;
     int Tin[kAnConv], Tout[kAnConv];
     if (k < 1 || k > d.F || f->max_iter < 1 || !an_layer_frames(k, Tin, Tout))
         return an_fail(ctx, SG_ERR_ARG, "FeCo: need 1 <= k <= %d frames, enough of them for the AudioNet stack, max_iter >= 1", d.F);
-    const int eot_size = p->eot_size > 0 ? p->eot_size : 1, eot_bs = p->eot_batch_size > 0 ? p->eot_batch_size : 1;
-    if (eot_size % eot_bs) return an_fail(ctx, SG_ERR_ARG, "EOT size should be divisible by EOT batch size");
-    // Expectation over the defense's randomness (adaptive_attack/EOT.py:16-54): eot_size passes per gradient step, each
-    // clustering started from fresh random frames, data gradients summed in pass order, sign step on the sum
-    // (sign(mean) == sign(sum)).  The evenly-started clustering is a deterministic function of its input: every
-    // repeat is the same computation, one pass stands for all of them.  The final pass is a single forward.
-    const int reps = f->random_init ? eot_size : 1;
     hipStream_t s = (hipStream_t)stream;
     AnWorkspace& w = ctx->an_ws;
     const int L = kAnConv - 1;
+    for (int r = 0; r < reps; ++r)
+        AN_HIP(hipMemcpyAsync(w.y_rep + (size_t)r * B, y_dev, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     for (int it = 0; it <= p->max_iter; ++it) {
         const bool last = it == p->max_iter;
-        const int nrep = last ? 1 : reps;
-        for (int r = 0; r < nrep; ++r) {
-            d.keep_scale = it > 0 || r > 0;  // iterates stay in [-1, 1]
-            if ((rc = an_frontend_forward(ctx, x_adv_dev, d, s))) return rc;
-            const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xC2B2AE3D27D4EB4Full;
-            rc = sg_feco_kmeans_compress(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, f->random_init, key, f->index_base,
-                                         w.feco_ids, w.feco_out, w.feco_cnt, s);
-            if (rc) return rc;
-            if ((rc = an_net_forward(ctx, w.feco_out, B, k, s))) return rc;
-            const bool rec = r == 0;  // per-step records: those of the step's first repeat
-            AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
-                                  nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
-                                  w.dact[L], loss_trace_dev && rec ? loss_trace_dev + (size_t)it * B : nullptr,
-                                  decision_trace_dev && rec ? decision_trace_dev + (size_t)it * B : nullptr,
-                                  last ? success_dev : nullptr, s));
-            if (last) break;
-            if ((rc = an_net_backward(ctx, B, k, w.dfeco, s))) return rc;
-            if ((rc = sg_feco_compress_backward(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, w.dfeats, s))) return rc;
-            const bool final_rep = r == nrep - 1;
-            rc = an_frontend_backward(ctx, x_adv_dev, d, w.dfeats, r > 0 ? w.gsum : nullptr, final_rep ? nullptr : w.gsum,
-                                      final_rep ? x_adv_dev : nullptr, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
-            if (rc) return rc;
+        const int R = last ? 1 : reps, rows = B * R;
+        d.keep_scale = it > 0;  // iterates stay in [-1, 1]
+        if ((rc = an_frontend_forward(ctx, x_adv_dev, d, s))) return rc;
+        const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull;  // repeat r: + r * 0xC2B2AE3D27D4EB4F
+        rc = sg_feco_kmeans_compress(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, f->random_init, key, f->index_base, R,
+                                     w.feco_ids, w.feco_out, w.feco_cnt, s);
+        if (rc) return rc;
+        if ((rc = an_net_forward(ctx, w.feco_out, rows, k, s))) return rc;
+        // per-step records: those of the step's first repeat (rows 0 .. B-1)
+        const bool direct = R == 1;
+        float* ltr = !loss_trace_dev ? nullptr : (direct ? loss_trace_dev + (size_t)it * B : w.trace_l);
+        int64_t* dtr = !decision_trace_dev ? nullptr : (direct ? decision_trace_dev + (size_t)it * B : w.trace_d);
+        AN_HIP(launch_an_tail(w.act[L], rows, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, w.y_rep, p->loss, !last,
+                              nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
+                              w.dact[L], ltr, dtr, last ? success_dev : nullptr, s));
+        if (!direct) {
+            if (ltr) AN_HIP(hipMemcpyAsync(loss_trace_dev + (size_t)it * B, ltr, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (dtr) AN_HIP(hipMemcpyAsync(decision_trace_dev + (size_t)it * B, dtr, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
         }
+        if (last) break;
+        if ((rc = an_net_backward(ctx, rows, k, w.dfeco, s))) return rc;
+        if ((rc = sg_feco_compress_backward_reps(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, R, w.dfeats, s))) return rc;
+        rc = an_frontend_backward(ctx, x_adv_dev, d, w.dfeats, nullptr, x_adv_dev, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
+        if (rc) return rc;
     }
     return SG_OK;
 }

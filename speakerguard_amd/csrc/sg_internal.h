@@ -87,13 +87,14 @@ struct AnWorkspace {
     float* dpre = nullptr;     // (B, F, 32)
     float* dfeats = nullptr;   // (B, F, 32)
     float* dframes = nullptr;  // (B, F, 800)
-    // FeCo inside the fused loop (sg_an_pgd_run_feco): cluster ids / sizes, compressed features and their gradient,
-    // and the data gradient summed over the EOT repeats of a step
+    // FeCo inside the fused loop (sg_an_pgd_run_feco): cluster ids / sizes, compressed features and their gradient
     int* feco_ids = nullptr;     // (B, F)
     int* feco_cnt = nullptr;     // (B, F) (k <= F used)
     float* feco_out = nullptr;   // (B, k, 32)
     float* dfeco = nullptr;      // (B, k, 32)
-    float* gsum = nullptr;       // (B, T)
+    int64_t* y_rep = nullptr;    // (B) labels repeated for the EOT repeats batched into one pass
+    float* trace_l = nullptr;    // (B) per-pass loss / decision records of such a pass (the first repeat's rows are kept)
+    int64_t* trace_d = nullptr;
     float* mel_cache = nullptr;  // (B, F, 32) mel energies of the forward pass, kept for the backward of the same pass
     // which input the mel cache belongs to (sg_an_logmel_backward(reuse_forward) checks pointer and shape, not contents)
     const float* cache_x = nullptr;
@@ -283,7 +284,7 @@ hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T,
                                 hipStream_t s);
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
                                 const float* dfeats, float* dframes, hipStream_t s);
-hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, const float* accum_in, float* grad_out,
+hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
                                     float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                     hipStream_t s);
 hipError_t launch_an_prefilter(const float* in, float* out, int B, int T, const float* w25, float bias, int transpose,

@@ -58,7 +58,7 @@ class FeCoDefense:
         self.calls += 1
         # clustering + cluster means (:204-216) in one launch
         ctx.call("sg_feco_kmeans_compress", N._ptr(feat), B, F, D, k, self.max_iter, int(self.init == 'random'), C.c_uint64(key),
-                 int(self.index_base), N._ptr(ids), N._ptr(out), N._ptr(counts), s)
+                 int(self.index_base), 1, N._ptr(ids), N._ptr(out), N._ptr(counts), s)
         force = B > 1  # :33 force=feat.shape[0] > 1
         keep = None
         if not force and bool((counts == 0).any()):

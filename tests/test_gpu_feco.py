@@ -308,7 +308,8 @@ def test_audionet_feco_gradient_and_pgd_eot():
 def test_audionet_feco_fused_loop(capsys):
     """BASELINE.json configs[3] as ONE device-resident loop (sg_an_pgd_run_feco): (1) with the deterministic defense it
     is the host-chained loop of defended_model bit for bit; (2) with the randomised defense and EOT it equals a replay of
-    its passes through the per-stage entry points with the same generator keys, gradients summed in pass order;
+    its passes through the per-stage entry points with the same generator keys -- the repeats' gradients summed at the
+    feature level in repeat order, one front-end pass and one adjoint per step;
     (3) through the PGD class it is what runs, reproducibly, and the EOT attack raises the loss of the defended model."""
     from speakerguard_amd import synth
     from speakerguard_amd.attack.PGD import PGD
@@ -345,14 +346,15 @@ def test_audionet_feco_fused_loop(capsys):
     replay = FeCoDefense(0.5, init='random', seed=123)  # keys are given explicitly below
     xr = x.clone()
     for it in range(K):
-        gsum = None
+        feats, saved = hip.frontend_forward(xr)  # only the defense is random: one front-end pass per step
+        dsum = None
         for r in range(2):
-            feats, saved = hip.frontend_forward(xr)
             comp, sv = replay.fwd(feats, seed=hip.fused_pass_seed(base_seed, it, r))
             _, _, _, g = hip.loss_grad(comp, y, spec, flag=1)
-            gw = hip.frontend_backward(saved, replay.bwd(sv, g))
-            gsum = gw if gsum is None else gw + gsum
-        hip.pgd_update(xr, gsum.contiguous(), lower.contiguous(), upper.contiguous(), step, 1)
+            df = replay.bwd(sv, g)
+            dsum = df if dsum is None else dsum + df  # feature-level sum in repeat order (the compression is linear)
+        gw = hip.frontend_backward(saved, dsum)
+        hip.pgd_update(xr, gw.contiguous(), lower.contiguous(), upper.contiguous(), step, 1)
     comp, _ = replay.fwd(hip.compute_feat(xr, flag=1), seed=hip.fused_pass_seed(base_seed, K, 0))
     dec_r, sc_r = hip.make_decision(comp, flag=1)
     assert torch.equal(xr, x_adv) and torch.equal(dec_r, dec) and torch.equal(sc_r, scores)
