@@ -16,3 +16,19 @@ with tempfile.TemporaryDirectory() as d:
     print("file-based model, dither", base.dither, "fused", attacker._can_fuse(), "max|dx|", (adver - x).abs().max().item(), "success", success)
     a2, s2 = ShardedAttack(attacker).attack(x, y)
     print("sharded wrapper (world 1):", s2)
+    # adaptive attack on the FeCo-defended AudioNet (BASELINE configs[3]): one device-resident loop
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    ckpt = os.path.join(d, "audionet.ckpt")
+    torch.save({k: torch.as_tensor(v) for k, v in synth.make_audionet_state_dict(seed=0, num_class=251).items()}, ckpt)
+    net = defended_model(audionet_csine(ckpt, device="cuda:0"), defense=[(1, FeCoDefense(0.5, init="random", seed=0))])
+    ya = net.make_decision(x)[0]
+    atk = PGD(net, epsilon=0.002, step_size=0.0004, max_iter=10, batch_size=6, EOT_size=4, EOT_batch_size=4, verbose=0)
+    adver, success = atk.attack(x, ya)
+    print("FeCo(random)-defended AudioNet: device loop", atk._fused_feco(6) is not None, "max|dx|", (adver - x).abs().max().item(), "success", success)
+    # black-box attack with the queries of every model call split over the ranks (one rank here: a pass-through)
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    from speakerguard_amd.shard import QueryShardedModel
+    base0 = xv_plda(p["extractor_file"], p["plda_file"], p["mean_file"], p["transform_mat_file"], model_file=p["model_file"], device="cuda:0", dither=0.0)
+    adver, success = FAKEBOB(QueryShardedModel(base0), task="CSI", epsilon=0.002, max_iter=3, samples_per_draw=10, samples_per_draw_batch_size=10, verbose=0).attack(x[:2], y[:2])
+    print("FAKEBOB over QueryShardedModel (world 1):", success, "max|dx|", (adver - x[:2]).abs().max().item())
