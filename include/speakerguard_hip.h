@@ -89,6 +89,10 @@ int32_t sg_xv_num_frames(int32_t T);
 /* loss selector: attack/utils.py:104-116 resolve_loss */
 #define SG_LOSS_ENTROPY 0 /* SEC4SR_CrossEntropy, attack/utils.py:7-29 */
 #define SG_LOSS_MARGIN 1  /* SEC4SR_MarginLoss,  attack/utils.py:31-102 */
+#define SG_LOSS_LINEAR 2  /* loss[b] = sum_s coef[b][s] * score[b][s]: the vector-Jacobian product of the scores.  What
+                           * autograd hands down at adaptive_attack/EOT.py:35 for ANY loss of the scores: a caller-defined
+                           * loss L passes coef = dL/dscores and gets dL/dx; model/defended_model.py:67-75 ('average' order:
+                           * the loss of the MEAN score of several defended branches) uses it per branch. */
 #define SG_TASK_CSI 0
 #define SG_TASK_SV 1
 #define SG_TASK_OSI 2
@@ -100,6 +104,7 @@ typedef struct sg_loss_spec {
     int32_t clip_max;   /* Margin: max(0, loss) (attack/utils.py:99-100) */
     float confidence;   /* Margin kappa */
     float threshold;    /* SV/OSI threshold used INSIDE the loss */
+    const float* coef_dev; /* SG_LOSS_LINEAR: (B,S) device tensor, else NULL */
 } sg_loss_spec;
 
 /* Input levels, reference model/xv_plda.py:45-47 allowed_flags */
@@ -165,6 +170,12 @@ int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
 /* attack/FGSM.py:65,68: x += step*sign(grad)*grad_sign; x = min(max(x, lower), upper). In place. */
 int sg_pgd_update(sg_ctx* ctx, float* x_dev, const float* grad_dev, const float* lower_dev,
                   const float* upper_dev, int64_t n, float step_size, int32_t grad_sign, void* stream);
+
+/* attack/utils.py:7-102 on given scores (B,S): per-example loss, d loss/d scores and the decision (argmax, -1 unless
+ * max > threshold) -- the tail kernels' loss stage alone.  Used where a loss is taken of scores that no single model
+ * pass produced (model/defended_model.py 'average' order: mean score over the defended branches). */
+int sg_loss_eval(sg_ctx* ctx, const float* scores_dev, const int64_t* y_dev, int32_t B, int32_t S, float threshold,
+                 const sg_loss_spec* loss, int64_t* decisions_dev, float* loss_dev, float* dscores_dev, void* stream);
 
 /* ---- attack-state updates around the model call (config 3: CW2, config 5: FAKEBOB/NES) -------
  * attack/CW2.py:72-82.  One pass over (B,T): if grad1 != NULL, the Adam update (torch.optim.Adam

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeakerguard_hip.so")
 
-SG_LOSS_ENTROPY, SG_LOSS_MARGIN = 0, 1
+SG_LOSS_ENTROPY, SG_LOSS_MARGIN, SG_LOSS_LINEAR = 0, 1, 2
 SG_TASK = {"CSI": 0, "SV": 1, "OSI": 2}
 SG_FLAG_WAV, SG_FLAG_RAW, SG_FLAG_CMVN = 0, 1, 2
 
@@ -18,7 +18,7 @@ SG_FLAG_WAV, SG_FLAG_RAW, SG_FLAG_CMVN = 0, 1, 2
 EXPORTS = (
     "sg_version", "sg_create", "sg_destroy", "sg_last_error", "sg_sync", "sg_xv_load", "sg_xv_set_enroll",
     "sg_xv_num_frames", "sg_input_scale", "sg_xv_mfcc", "sg_xv_cmvn", "sg_xv_forward", "sg_xv_debug_activation",
-    "sg_xv_loss_grad", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
+    "sg_xv_loss_grad", "sg_loss_eval", "sg_pgd_update", "sg_xv_pgd_run", "sg_xv_time_layer",
     "sg_cw2_step", "sg_nes_queries", "sg_nes_grad", "sg_fakebob_step",
     "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
     "sg_an_pgd_run", "sg_an_pgd_run_feco", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
@@ -52,7 +52,7 @@ class AnWeights(C.Structure):
 
 class LossSpec(C.Structure):
     _fields_ = [("loss", C.c_int32), ("task", C.c_int32), ("targeted", C.c_int32), ("clip_max", C.c_int32),
-                ("confidence", C.c_float), ("threshold", C.c_float)]
+                ("confidence", C.c_float), ("threshold", C.c_float), ("coef_dev", C.c_void_p)]
 
 
 class Dither(C.Structure):
@@ -105,6 +105,7 @@ def load():
         "sg_xv_loss_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, C.POINTER(LossSpec), C.POINTER(Dither),
                                       vp, vp, vp, vp, vp]),
         "sg_pgd_update": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, i32, vp]),
+        "sg_loss_eval": (C.c_int, [vp, vp, vp, i32, i32, f32, C.POINTER(LossSpec), vp, vp, vp, vp]),
         "sg_xv_pgd_run": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.POINTER(PgdParams), vp, vp, vp, vp, vp, vp, vp]),
         "sg_cw2_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]),
         "sg_nes_queries": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i64, i32, vp, vp, vp, vp]),

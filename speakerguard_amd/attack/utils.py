@@ -89,6 +89,50 @@ class SEC4SR_MarginLoss(_Loss):
         return loss.float()
 
 
+class ScoreVJP(_Loss):
+    """``loss[b] = sum_s coef[b, s] * scores[b, s]``: the vector-Jacobian product of the scores (SG_LOSS_LINEAR).
+
+    The reference lets a caller put ANY differentiable function of the scores behind ``loss.backward`` (adaptive_attack/
+    EOT.py:33-35); the hand-coded backward knows the two losses of attack/utils.py.  A caller-defined loss L closes the gap
+    with one extra line: compute ``coef = dL/dscores`` (B, S) yourself and ask for ``model.loss_grad(x, y, ScoreVJP(coef))``
+    -- the returned gradient is dL/dx.  ``defended_model`` uses it for the 'average' order, where the loss is taken of
+    the MEAN score of several defended branches."""
+    loss_id = N.SG_LOSS_LINEAR
+
+    def __init__(self, coef):
+        self.coef = coef.to(torch.float32).contiguous()  # kept alive for as long as the native spec may be used
+        if not self.coef.is_cuda or self.coef.dim() != 2:
+            raise N.NativeError("ScoreVJP needs a (B, S) tensor on the HIP device")
+        self.task, self.targeted, self.clip_max, self.confidence, self.threshold = 'CSI', False, False, 0., None
+
+    def native(self):
+        s = super().native()
+        s.coef_dev = self.coef.data_ptr()
+        return s
+
+    def forward(self, scores, label=None):
+        return (self.coef.to(scores.device) * scores).sum(1)
+
+
+def loss_dscores(model, scores, label, loss_spec):
+    """(decisions, loss, d loss / d scores) of `loss_spec` on given scores (B, S): the loss stage of the tail kernels
+    alone (sg_loss_eval), for scores that no single model pass produced."""
+    base = getattr(model, 'base_model', model)
+    scores = scores.to(torch.float32).contiguous()
+    B, S = scores.shape
+    label = label.to(scores.device, torch.int64).contiguous()
+    dec = torch.empty(B, device=scores.device, dtype=torch.int64)
+    loss = torch.empty(B, device=scores.device, dtype=torch.float32)
+    dsc = torch.empty(B, S, device=scores.device, dtype=torch.float32)
+    import ctypes as C
+    import math
+    thr = float(base.threshold) if base.threshold is not None and np.isfinite(base.threshold) else -math.inf
+    spec = loss_spec.native()
+    base.ctx.call("sg_loss_eval", N._ptr(scores), N._ptr(label), B, S, thr, C.byref(spec), N._ptr(dec), N._ptr(loss),
+                  N._ptr(dsc), N.current_stream_ptr(scores.device))
+    return dec, loss, dsc
+
+
 def resolve_loss(loss_name='Entropy', targeted=False, confidence=0., task='CSI', threshold=None, clip_max=True):
     """attack/utils.py:104-116: SV/OSI force the margin loss; grad_sign is -1 for Margin."""
     assert loss_name in ['Entropy', 'Margin']

@@ -3,6 +3,7 @@
 //   nes_queries   adaptive_attack/NES.py:19-25  antithetic Gaussian queries around x
 //   nes_grad      adaptive_attack/NES.py:47-54  loss-weighted noise average (noise regenerated, never stored)
 //   fakebob_step  attack/FAKEBOB.py:93-104      momentum, per-example LR sign step, epsilon-ball clamp
+#include "loss_device.h"
 #include "sg_internal.h"
 
 // These updates mirror torch elementwise expressions (separate multiply and add roundings); keep hipcc
@@ -200,6 +201,29 @@ hipError_t launch_fakebob_step(float* x, float* grad, const float* prev_grad, co
                                hipStream_t s) {
     hipLaunchKernelGGL(fakebob_step_kernel, dim3((T + 255) / 256, n), dim3(256), 0, s, x, grad, prev_grad, lr, lower, upper,
                        T, momentum, one_m_momentum, grad_sign);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- loss stage alone
+// attack/utils.py:7-102 on given scores: one thread per utterance (S is 10 .. 251), global memory as its scratch.
+__global__ __launch_bounds__(64) void loss_eval_kernel(const float* __restrict__ scores, const int64_t* __restrict__ y, int B,
+                                                       int S, float threshold, sg_loss_spec ls, int64_t* __restrict__ dec_out,
+                                                       float* __restrict__ loss_out, float* __restrict__ dsc_out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float* dsc = dsc_out + (size_t)b * S;
+    for (int s = 0; s < S; ++s) dsc[s] = 0.f;
+    int64_t dec = 0;
+    const float loss = loss_and_dscores(scores + (size_t)b * S, dsc, S, threshold, y ? y[b] : 0, y != nullptr, ls, &dec,
+                                        ls.coef_dev ? ls.coef_dev + (size_t)b * S : nullptr);
+    if (dec_out) dec_out[b] = dec;
+    if (loss_out) loss_out[b] = loss;
+}
+
+hipError_t launch_loss_eval(const float* scores, const int64_t* y, int B, int S, float threshold, const sg_loss_spec& ls,
+                            int64_t* dec, float* loss, float* dscores, hipStream_t s) {
+    if (S < 1 || S > kLossMaxS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(loss_eval_kernel, dim3((B + 63) / 64), dim3(64), 0, s, scores, y, B, S, threshold, ls, dec, loss, dscores);
     return hipGetLastError();
 }
 

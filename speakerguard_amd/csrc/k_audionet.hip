@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         __shared__ float ex[kLossMaxS];
         __shared__ float bc[4];
         int64_t dec = 0;
-        const float loss = loss_and_dscores_block(sc, dsc, ex, bc, S, threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, 256);
+        const float loss = loss_and_dscores_block(sc, dsc, ex, bc, S, threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, 256,
+                                                  ls.coef_dev ? ls.coef_dev + (size_t)b * S : nullptr);
         if (tid == 0) {
             if (dec_out) dec_out[b] = dec;
             if (dec_trace) dec_trace[b] = dec;

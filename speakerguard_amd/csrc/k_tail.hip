@@ -202,7 +202,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
     {
         int64_t dec = 0;  // scratch: `part` (kTailParts x kMaxD floats >= kMaxS) and `red` (16 floats), both idle here
-        const float loss = loss_and_dscores_block(sc, dsc, part, red, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, NT);
+        const float loss = loss_and_dscores_block(sc, dsc, part, red, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, NT,
+                                                  ls.coef_dev ? ls.coef_dev + (size_t)b * S : nullptr);
         if (tid == 0) {
             if (dec_out) dec_out[b] = dec;
             if (dec_trace) dec_trace[b] = dec;

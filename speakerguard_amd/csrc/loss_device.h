@@ -14,14 +14,24 @@ namespace sg {
 constexpr int kLossMaxS = 1024;
 
 // sc[S]: scores (LDS or registers); dsc[S]: must be zero on entry, receives d loss / d scores.
+// coef: this utterance's row of ls.coef_dev (SG_LOSS_LINEAR), else unused.
 __device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, int S, float threshold, int64_t yy,
-                                                  bool has_y, const sg_loss_spec& ls, int64_t* dec_out) {
+                                                  bool has_y, const sg_loss_spec& ls, int64_t* dec_out,
+                                                  const float* coef = nullptr) {
     int ja = 0;
     float mx = sc[0];
     for (int s = 1; s < S; ++s)
         if (sc[s] > mx) { mx = sc[s]; ja = s; }
     *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
     float loss = 0.f;
+    if (ls.loss == SG_LOSS_LINEAR) {  // vector-Jacobian product of the scores: the label plays no role
+        if (coef)
+            for (int s = 0; s < S; ++s) {
+                loss += coef[s] * sc[s];
+                dsc[s] = coef[s];
+            }
+        return loss;
+    }
     if (has_y) {
         if (ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI) {
             if (yy >= 0) {
@@ -97,11 +107,11 @@ __device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, i
 // in index order, so the result is bit-identical to loss_and_dscores.  ex: S floats of LDS scratch, bc: 4 floats.
 __device__ __forceinline__ float loss_and_dscores_block(const float* sc, float* dsc, float* ex, float* bc, int S, float threshold,
                                                         int64_t yy, bool has_y, const sg_loss_spec& ls, int64_t* dec_out, int tid,
-                                                        int nt) {
+                                                        int nt, const float* coef = nullptr) {
     const bool ce = has_y && ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI && yy >= 0;  // block-uniform
     if (!ce) {
         float loss = 0.f;
-        if (tid == 0) loss = loss_and_dscores(sc, dsc, S, threshold, yy, has_y, ls, dec_out);
+        if (tid == 0) loss = loss_and_dscores(sc, dsc, S, threshold, yy, has_y, ls, dec_out, coef);
         __syncthreads();
         return loss;
     }

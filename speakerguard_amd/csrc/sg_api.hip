@@ -737,6 +737,15 @@ int sg_pgd_update(sg_ctx* ctx, float* x_dev, const float* grad_dev, const float*
     return SG_OK;
 }
 
+int sg_loss_eval(sg_ctx* ctx, const float* scores_dev, const int64_t* y_dev, int32_t B, int32_t S, float threshold,
+                 const sg_loss_spec* loss, int64_t* decisions_dev, float* loss_dev, float* dscores_dev, void* stream) {
+    if (!ctx || !scores_dev || !loss || !dscores_dev || B < 1 || S < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
+    if (loss->loss == SG_LOSS_LINEAR && !loss->coef_dev) return fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
+    SG_HIP(hipSetDevice(ctx->device));
+    SG_HIP(launch_loss_eval(scores_dev, y_dev, B, S, threshold, *loss, decisions_dev, loss_dev, dscores_dev, (hipStream_t)stream));
+    return SG_OK;
+}
+
 int sg_cw2_step(sg_ctx* ctx, float* modifier_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* x_dev,
                 const float* input_cur_dev, const float* grad1_dev, const float* const_dev, int32_t B, int32_t T, float lr,
                 int32_t step_t, float* input_next_dev, float* loss2_dev, void* stream) {

@@ -280,6 +280,9 @@ hipError_t launch_fakebob_step(float* x, float* grad, const float* prev_grad, co
                                const float* upper, int n, int T, float momentum, float one_m_momentum, int grad_sign,
                                hipStream_t s);
 
+hipError_t launch_loss_eval(const float* scores, const int64_t* y, int B, int S, float threshold, const sg_loss_spec& ls,
+                            int64_t* dec, float* loss, float* dscores, hipStream_t s);
+
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 hipStream_t s);
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,

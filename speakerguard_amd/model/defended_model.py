@@ -109,7 +109,52 @@ class defended_model:
         if not want_grad:
             decisions, scores = self.make_decision(x)
             return decisions, scores, loss_spec(scores, y), None
+        if self.order == average:
+            return self._loss_grad_average(x, y, loss_spec)
         return self._loss_grad_through_defenses(x, y, loss_spec)
+
+    def _loss_grad_average(self, x, y, loss_spec):
+        """'average' order (:67-75 `_average`): the model scores every defended copy d_i(x) on its own and the loss is
+        taken of the MEAN score.  d loss / d x = sum_i J_i^T (g / n) with g = d loss / d mean-score: the loss stage runs
+        once on the mean (sg_loss_eval) and every branch is a vector-Jacobian product of its scores (ScoreVJP) chained
+        back through its defense and the front-end stages below its level by hand."""
+        from ..attack.utils import ScoreVJP, loss_dscores
+        bm = self.base_model
+        branches = [(flag, d) for flag in sorted(self.flag2defense.keys()) for d in self.flag2defense[flag]]
+        if not (hasattr(bm, 'frontend_forward') and all(hasattr(d, 'fwd') and hasattr(d, 'bwd') for _, d in branches)):
+            raise NotImplementedError('gradient through this defense configuration is not built: needs a native base '
+                                      'model and defenses exposing fwd/bwd (FeCoDefense at the feature levels; '
+                                      'adaptive_attack.BPDA.BPDA(f, sub_f) around any input-level transform)')
+        n = len(self.defense)  # :75 divides by len(self.defense)
+        x = x.to(bm.device, torch.float32).contiguous()
+        feats = saved_front = cm = None
+        if any(f >= 1 for f, _ in branches):
+            feats, saved_front = bm.frontend_forward(x)  # one front-end pass serves every feature-level branch
+        if any(f == 2 for f, _ in branches):
+            cm = bm.comput_feat_from_feat(feats, ori_flag=1, des_flag=2)
+        tape, mean = [], None
+        for flag, d in branches:
+            out, sv = d.fwd(x if flag == 0 else (feats if flag == 1 else cm))
+            sc = bm.forward(out, flag=flag)
+            mean = sc if mean is None else mean + sc
+            tape.append((flag, d, out, sv))
+        mean = mean / n
+        decisions, loss, g = loss_dscores(bm, mean, y, loss_spec)
+        vjp = ScoreVJP(g / n)
+        y0 = torch.zeros(x.shape[0], device=bm.device, dtype=torch.int64)
+        grad, dfeat = None, None
+        for flag, d, out, sv in tape:
+            gi = d.bwd(sv, bm.loss_grad(out, y0, vjp, flag=flag, want_grad=True)[3])
+            if flag == 0:
+                grad = gi if grad is None else grad + gi
+            else:
+                if flag == 2:
+                    gi = bm.cmvn_backward(gi)
+                dfeat = gi if dfeat is None else dfeat + gi  # the front-end is linear in its cotangent: one adjoint below
+        if dfeat is not None:
+            gw = bm.frontend_backward(saved_front, dfeat)
+            grad = gw if grad is None else grad + gw
+        return decisions, mean, loss, grad
 
     def _loss_grad_through_defenses(self, x, y, loss_spec):
         """wav -> MFCC -> [flag-1 defenses] -> CMVN -> [flag-2 defenses] -> TDNN ... -> loss, and back.

@@ -34,12 +34,21 @@ def test_version_and_loader():
     assert lib.sg_xv_num_frames(100) == 0
 
 
-def test_struct_layouts_match_header():
-    # sizes the C compiler gives the same structs (x86-64 SysV): catches field-order drift
-    assert ctypes.sizeof(_native.LossSpec) == 24
-    assert ctypes.sizeof(_native.Dither) == 32
-    assert ctypes.sizeof(_native.PgdParams) == 24 + 4 * 5 + 4 + 32
-    assert ctypes.sizeof(_native.XvWeights) == 8 * 28 + 16
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof of every struct that crosses the boundary, as gcc lays out the header's definition (x86-64 SysV), against
+    the ctypes mirror: catches field-order / padding drift."""
+    import subprocess
+    pairs = [("sg_loss_spec", _native.LossSpec), ("sg_dither", _native.Dither), ("sg_pgd_params", _native.PgdParams),
+             ("sg_xv_weights", _native.XvWeights), ("sg_feco_params", _native.FecoParams)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "speakerguard_hip.h"\nint main(void) {\n' +
+                   "".join('    printf("%%zu\\n", sizeof(%s));\n' % c for c, _ in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    for (cname, ctype), size in zip(pairs, sizes):
+        assert ctypes.sizeof(ctype) == size, (cname, ctypes.sizeof(ctype), size)
+    assert ctypes.sizeof(_native.LossSpec) == 32 and ctypes.sizeof(_native.Dither) == 32
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):

@@ -381,3 +381,84 @@ def test_audionet_feco_fused_loop(capsys):
     log("fused PGD + EOT vs FeCo-defended AudioNet: == host-chained loop (deterministic defense), == keyed replay (random "
         "init, EOT 2); PGD-10 EOT 4/2: CE loss %s -> %s, success %s" % (l0.cpu().numpy().round(3), l1.cpu().numpy().round(3), s1))
     assert (l1 >= l0 - 1e-4).all()
+
+
+def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
+    """(1) SG_LOSS_LINEAR: d(sum coef * scores)/d x for an arbitrary coef -- what a caller-defined loss of the scores needs
+    (the reference gets it from autograd, EOT.py:33-35) -- vs the oracle's autograd, x-vector and AudioNet.
+    (2) model/defended_model.py 'average' order: loss of the MEAN score over three defended branches (quantisation at the
+    waveform behind the reference's straight-through BPDA, FeCo at feature levels 1 and 2) vs the oracle's autograd
+    through the same composition with the device's cluster ids."""
+    from oracle import attacks as oatk
+    from oracle import feco
+    from oracle.audionet import AudioNet
+    from speakerguard_amd import synth
+    from speakerguard_amd.adaptive_attack.BPDA import straight_through
+    from speakerguard_amd.attack.utils import ScoreVJP, SEC4SR_CrossEntropy, SEC4SR_MarginLoss, loss_dscores
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    rs = np.random.RandomState(12)
+    x = torch.from_numpy(synth.make_waveforms(3, 32000, seed=75))
+    y0 = torch.zeros(3, dtype=torch.int64, device=DEV)
+
+    def rel(got, want):
+        return float(np.abs(got - want).max() / np.abs(want).max())
+
+    # (1) vector-Jacobian product of the scores
+    coef = torch.from_numpy(rs.randn(3, 10).astype(np.float32))
+    dec, sc, ls, g = hip_model.loss_grad(x.to(DEV), y0, ScoreVJP(coef.to(DEV)))
+    xin = x.clone().requires_grad_(True)
+    osc = oracle_model.make_decision(xin)[1]
+    (coef * osc).sum().backward()
+    e_xv = rel(g.cpu().numpy(), xin.grad.numpy())
+    # bulk tolerance + bound on outliers, as for every x-vector gradient (one ReLU within round-off of 0 flips between the two
+    # fp32 implementations and changes the gradient of its receptive field)
+    bad_xv = float((np.abs(g.cpu().numpy() - xin.grad.numpy()) > 3e-3 * np.abs(xin.grad.numpy()).max()).mean())
+    np.testing.assert_allclose(ls.cpu().numpy(), (coef * osc.detach()).sum(1).numpy(), rtol=2e-4, atol=2e-2)
+    sd = synth.make_audionet_state_dict(seed=0, num_class=251)
+    an, oan = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
+    coef_a = torch.from_numpy(rs.randn(3, 251).astype(np.float32))
+    _, _, _, ga = an.loss_grad(x.to(DEV), y0, ScoreVJP(coef_a.to(DEV)))
+    xin = x.clone().requires_grad_(True)
+    (coef_a * oan.make_decision(xin)[1]).sum().backward()
+    e_an = rel(ga.cpu().numpy(), xin.grad.numpy())
+    assert e_xv < 3e-2 and bad_xv < 5e-3 and e_an < 2e-3, (e_xv, bad_xv, e_an)
+    # the loss stage alone on given scores == the tail kernel's own
+    spec = SEC4SR_MarginLoss(targeted=False, confidence=0.5, task='CSI', threshold=None, clip_max=True)
+    yv = torch.tensor([1, 7, 3], device=DEV)
+    d1, s1, l1, _ = hip_model.loss_grad(x.to(DEV), yv, spec, want_grad=False)
+    d2, l2, ds2 = loss_dscores(hip_model, s1, yv, spec)
+    assert torch.equal(d1, d2) and torch.equal(l1, l2) and ds2.shape == s1.shape
+
+    # (2) 'average' order
+    quant = lambda w: torch.round(w * 512.0) / 512.0
+    f1, f2 = FeCoDefense(0.5), FeCoDefense(0.4)
+    dm = defended_model(hip_model, defense=[(0, straight_through(quant)), (1, f1), (2, f2)], order='average')
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    ce = SEC4SR_CrossEntropy()
+    dec, mean, loss, grad = dm.loss_grad(x.to(DEV), y.to(DEV), ce)
+    assert torch.equal(mean, dm.score(x.to(DEV)))  # the forward-only path of the same wrapper
+    ids1 = f1.fwd(hip_model.compute_feat(x.to(DEV), flag=1))[1][0].cpu().numpy()
+    ids2 = f2.fwd(hip_model.compute_feat(x.to(DEV), flag=2))[1][0].cpu().numpy()
+    xin = x.clone().requires_grad_(True)
+    s0 = oracle_model.make_decision(xin + (quant(xin) - xin).detach())[1]  # straight-through quantisation
+    fe1 = oracle_model.compute_feat(xin, flag=1)
+    k1 = int(fe1.shape[1] * 0.5)
+    s1 = oracle_model.make_decision(torch.stack([feco.compress_from_ids(fe1[b], ids1[b], k1, force=True) for b in range(3)]), flag=1)[1]
+    fe2 = oracle_model.compute_feat(xin, flag=2)
+    k2 = int(fe2.shape[1] * 0.4)
+    s2 = oracle_model.make_decision(torch.stack([feco.compress_from_ids(fe2[b], ids2[b], k2, force=True) for b in range(3)]), flag=2)[1]
+    om = (s0 + s1 + s2) / 3
+    ol = oatk.cross_entropy_loss(om, y)
+    ol.backward(torch.ones(3))
+    want, got = xin.grad.numpy(), grad.cpu().numpy()
+    err = rel(got, want)
+    bad = float((np.abs(got - want) > 3e-3 * np.abs(want).max()).mean())
+    log("score VJP vs oracle autograd: xv %.2e, AudioNet %.2e of max; 'average' order over (BPDA quantise, FeCo@1, FeCo@2): "
+        "mean-score err %.2e, loss err %.2e, wav grad err/max %.2e (outliers %.4f)" % (
+            e_xv, e_an, (mean.cpu() - om.detach()).abs().max().item(), (loss.cpu() - ol.detach()).abs().max().item(), err, bad))
+    assert dec.cpu().tolist() == om.argmax(1).tolist()
+    assert (mean.cpu() - om.detach()).abs().max().item() < 5e-3
+    assert bad < 5e-3 and err < 2e-2, (bad, err)
