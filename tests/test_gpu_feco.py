@@ -338,28 +338,29 @@ def test_audionet_feco_fused_loop(capsys):
     PGD(dm, epsilon=eps, step_size=step, max_iter=1, batch_size=4, verbose=1).attack(x, y)
     assert "iter:1" in capsys.readouterr().out
 
-    # (2) randomised defense + EOT 2: replay of the passes with the same keys
-    feco = FeCoDefense(0.5, init='random', seed=7)
-    x_adv, success, dec, scores, loss, _, _ = hip.pgd_run_feco(x, y, lower, upper, spec, step, K, 1, feco, eot_size=2,
-                                                               eot_batch_size=2)
-    base_seed = hip.last_fused_seed
-    replay = FeCoDefense(0.5, init='random', seed=123)  # keys are given explicitly below
-    xr = x.clone()
-    for it in range(K):
-        feats, saved = hip.frontend_forward(xr)  # only the defense is random: one front-end pass per step
-        dsum = None
-        for r in range(2):
-            comp, sv = replay.fwd(feats, seed=hip.fused_pass_seed(base_seed, it, r))
-            _, _, _, g = hip.loss_grad(comp, y, spec, flag=1)
-            df = replay.bwd(sv, g)
-            dsum = df if dsum is None else dsum + df  # feature-level sum in repeat order (the compression is linear)
-        gw = hip.frontend_backward(saved, dsum)
-        hip.pgd_update(xr, gw.contiguous(), lower.contiguous(), upper.contiguous(), step, 1)
-    comp, _ = replay.fwd(hip.compute_feat(xr, flag=1), seed=hip.fused_pass_seed(base_seed, K, 0))
-    dec_r, sc_r = hip.make_decision(comp, flag=1)
-    assert torch.equal(xr, x_adv) and torch.equal(dec_r, dec) and torch.equal(sc_r, scores)
-    assert success.bool().tolist() == (dec != y).tolist()
-    assert not torch.equal(x_adv, adv_f)  # the random clusterings lead somewhere else than the evenly started one
+    # (2) randomised defense + EOT R: replay of the passes with the same keys (R = 3 after R = 2: odd count, workspace regrown)
+    for R in (2, 3):
+        feco = FeCoDefense(0.5, init='random', seed=7)
+        x_adv, success, dec, scores, loss, _, _ = hip.pgd_run_feco(x, y, lower, upper, spec, step, K, 1, feco, eot_size=R,
+                                                                   eot_batch_size=R)
+        base_seed = hip.last_fused_seed
+        replay = FeCoDefense(0.5, init='random', seed=123)  # keys are given explicitly below
+        xr = x.clone()
+        for it in range(K):
+            feats, saved = hip.frontend_forward(xr)  # only the defense is random: one front-end pass per step
+            dsum = None
+            for r in range(R):
+                comp, sv = replay.fwd(feats, seed=hip.fused_pass_seed(base_seed, it, r))
+                _, _, _, g = hip.loss_grad(comp, y, spec, flag=1)
+                df = replay.bwd(sv, g)
+                dsum = df if dsum is None else dsum + df  # feature-level sum in repeat order (the compression is linear)
+            gw = hip.frontend_backward(saved, dsum)
+            hip.pgd_update(xr, gw.contiguous(), lower.contiguous(), upper.contiguous(), step, 1)
+        comp, _ = replay.fwd(hip.compute_feat(xr, flag=1), seed=hip.fused_pass_seed(base_seed, K, 0))
+        dec_r, sc_r = hip.make_decision(comp, flag=1)
+        assert torch.equal(xr, x_adv) and torch.equal(dec_r, dec) and torch.equal(sc_r, scores), R
+        assert success.bool().tolist() == (dec != y).tolist()
+        assert not torch.equal(x_adv, adv_f)  # the random clusterings lead somewhere else than the evenly started one
 
     # (3) the PGD class against the randomised defense: device loop, reproducible, loss goes up
     def run(seed):
@@ -412,9 +413,17 @@ def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
     osc = oracle_model.make_decision(xin)[1]
     (coef * osc).sum().backward()
     e_xv = rel(g.cpu().numpy(), xin.grad.numpy())
-    # bulk tolerance + bound on outliers, as for every x-vector gradient (one ReLU within round-off of 0 flips between the two
-    # fp32 implementations and changes the gradient of its receptive field)
-    bad_xv = float((np.abs(g.cpu().numpy() - xin.grad.numpy()) > 3e-3 * np.abs(xin.grad.numpy()).max()).mean())
+    # A random +-coef over all ten scores makes the ten score gradients cancel, so the two fp32 implementations sit further
+    # apart (relative to the largest entry) than under a loss; both are judged against the SAME model evaluated in fp64:
+    # the HIP gradient must be about as close to it as the fp32 oracle is (measured 8e-3 vs 6e-3 rms; under the
+    # cross-entropy loss, test_waveform_gradient_matches_oracle_autograd, 2e-4 vs 1e-3).
+    from oracle.xv_plda import XvPlda
+    m64 = XvPlda(synth.make_xv_weights()).double()
+    x64 = x.double().requires_grad_(True)
+    (coef.double() * m64.make_decision(x64)[1]).sum().backward()
+    g64 = x64.grad.numpy()
+    rms = lambda a: float(np.sqrt(((a - g64) ** 2).mean() / (g64 ** 2).mean()))
+    rms_hip, rms_ora = rms(g.cpu().numpy()), rms(xin.grad.numpy())
     np.testing.assert_allclose(ls.cpu().numpy(), (coef * osc.detach()).sum(1).numpy(), rtol=2e-4, atol=2e-2)
     sd = synth.make_audionet_state_dict(seed=0, num_class=251)
     an, oan = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
@@ -423,7 +432,7 @@ def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
     xin = x.clone().requires_grad_(True)
     (coef_a * oan.make_decision(xin)[1]).sum().backward()
     e_an = rel(ga.cpu().numpy(), xin.grad.numpy())
-    assert e_xv < 3e-2 and bad_xv < 5e-3 and e_an < 2e-3, (e_xv, bad_xv, e_an)
+    assert rms_hip <= 2 * rms_ora and rms_hip < 2e-2 and e_xv < 5e-2 and e_an < 2e-3, (rms_hip, rms_ora, e_xv, e_an)
     # the loss stage alone on given scores == the tail kernel's own
     spec = SEC4SR_MarginLoss(targeted=False, confidence=0.5, task='CSI', threshold=None, clip_max=True)
     yv = torch.tensor([1, 7, 3], device=DEV)
@@ -456,9 +465,9 @@ def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
     want, got = xin.grad.numpy(), grad.cpu().numpy()
     err = rel(got, want)
     bad = float((np.abs(got - want) > 3e-3 * np.abs(want).max()).mean())
-    log("score VJP vs oracle autograd: xv %.2e, AudioNet %.2e of max; 'average' order over (BPDA quantise, FeCo@1, FeCo@2): "
+    log("score VJP: xv rms error vs fp64 truth %.2e (fp32 oracle: %.2e), max |hip - oracle| %.2e of max; AudioNet %.2e of max; 'average' order over (BPDA quantise, FeCo@1, FeCo@2): "
         "mean-score err %.2e, loss err %.2e, wav grad err/max %.2e (outliers %.4f)" % (
-            e_xv, e_an, (mean.cpu() - om.detach()).abs().max().item(), (loss.cpu() - ol.detach()).abs().max().item(), err, bad))
+            rms_hip, rms_ora, e_xv, e_an, (mean.cpu() - om.detach()).abs().max().item(), (loss.cpu() - ol.detach()).abs().max().item(), err, bad))
     assert dec.cpu().tolist() == om.argmax(1).tolist()
     assert (mean.cpu() - om.detach()).abs().max().item() < 5e-3
     assert bad < 5e-3 and err < 2e-2, (bad, err)
