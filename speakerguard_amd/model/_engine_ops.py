@@ -36,16 +36,25 @@ class EngineOps:
     _index_base = 0    # global index of the first utterance of the chunk being attacked
     _draw = 0          # passes since begin_batch
     _nes_draw = 0      # NES.forward calls since begin_batch
+    _def_draw = 0      # calls of a randomised defense (FeCoDefense(init='random')) since begin_batch
     _row_base = 0      # position of this call's row 0 inside the full model call it is a slice of (shard.QueryShardedModel)
 
     def begin_attack(self):
         self._noise_epoch += 1
 
     def begin_batch(self, index_base=0, salt=0):
-        self._index_base, self._batch_salt, self._draw, self._nes_draw = int(index_base), int(salt), 0, 0
+        self._index_base, self._batch_salt, self._draw, self._nes_draw, self._def_draw = int(index_base), int(salt), 0, 0, 0
 
     def noise_seed(self, user_seed, draw):
         return mix64(user_seed, self._noise_epoch, self._batch_salt, self._index_base, draw)
+
+    def defense_seed(self, user_seed):
+        """Generator key of the next call of a randomised defense sitting on this model (defended_model): keyed like the
+        dither -- (seed, attack call, restart, chunk base, call number inside the chunk) -- so that the clusterings an
+        utterance sees do not depend on the shard layout either."""
+        key = self.noise_seed(int(user_seed) ^ 0x4665436F, self._def_draw)
+        self._def_draw += 1
+        return key
 
     def _stream(self):
         return N.current_stream_ptr(self.device)

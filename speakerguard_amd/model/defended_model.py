@@ -45,6 +45,16 @@ class defended_model:
     def eval(self):
         return self
 
+    def _fwd(self, d, xx):
+        """``d.fwd(xx)``; a randomised defense (FeCoDefense(init='random')) takes its generator key from the base
+        model's noise bookkeeping (attack call, chunk, call number) instead of its own call counter."""
+        if getattr(d, 'init', None) == 'random' and hasattr(self.base_model, 'defense_seed'):
+            return d.fwd(xx, seed=self.base_model.defense_seed(d.seed))
+        return d.fwd(xx)
+
+    def _apply(self, d, xx):
+        return self._fwd(d, xx)[0] if hasattr(d, 'fwd') else d(xx)
+
     def process_sequential(self, x):
         if self.defense is None:
             return x
@@ -56,7 +66,7 @@ class defended_model:
             else:
                 xx = self.base_model.comput_feat_from_feat(xx, ori_flag=flag - 1, des_flag=flag)
             for d in self.flag2defense[flag]:
-                xx = d(xx)
+                xx = self._apply(d, xx)
         return xx
 
     def _last_flag(self):
@@ -67,7 +77,7 @@ class defended_model:
         for flag in sorted(self.flag2defense.keys()):
             xx = x.clone() if flag == 0 else self.base_model.compute_feat(x, flag=flag)
             for d in self.flag2defense[flag]:
-                out = fn(d(xx), flag)
+                out = fn(self._apply(d, xx), flag)
                 acc = out if acc is None else tuple(a + o for a, o in zip(acc, out))
         return tuple(a / len(self.defense) for a in acc)
 
@@ -134,7 +144,7 @@ class defended_model:
             cm = bm.comput_feat_from_feat(feats, ori_flag=1, des_flag=2)
         tape, mean = [], None
         for flag, d in branches:
-            out, sv = d.fwd(x if flag == 0 else (feats if flag == 1 else cm))
+            out, sv = self._fwd(d, x if flag == 0 else (feats if flag == 1 else cm))
             sc = bm.forward(out, flag=flag)
             mean = sc if mean is None else mean + sc
             tape.append((flag, d, out, sv))
@@ -171,7 +181,7 @@ class defended_model:
         # input-level defenses (flag 0: wav -> wav), e.g. BPDA-wrapped quantisation (defense/time_domain.py:44)
         tape0 = []
         for d in self.flag2defense.get(0, []):
-            x, sv = d.fwd(x)
+            x, sv = self._fwd(d, x)
             tape0.append((d, sv))
         if not self.flag2defense.get(1) and not self.flag2defense.get(2):
             # nothing sits between front-end and network: one native call from the (defended) waveform
@@ -182,12 +192,12 @@ class defended_model:
         feats, saved_front = bm.frontend_forward(x)
         tape1, tape2 = [], []
         for d in self.flag2defense[1]:
-            feats, sv = d.fwd(feats)
+            feats, sv = self._fwd(d, feats)
             tape1.append((d, sv))
         if self.flag2defense.get(2):  # xv_plda only (AudioNet has no level 2, audionet_csine.py:127-129)
             feats = bm.comput_feat_from_feat(feats, ori_flag=1, des_flag=2)
             for d in self.flag2defense[2]:
-                feats, sv = d.fwd(feats)
+                feats, sv = self._fwd(d, feats)
                 tape2.append((d, sv))
             decisions, scores, loss, g = bm.loss_grad(feats, y, loss_spec, flag=2, want_grad=True)
             for d, sv in reversed(tape2):

@@ -471,3 +471,39 @@ def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
     assert dec.cpu().tolist() == om.argmax(1).tolist()
     assert (mean.cpu() - om.detach()).abs().max().item() < 5e-3
     assert bad < 5e-3 and err < 2e-2, (bad, err)
+
+
+def test_randomised_feco_is_shard_invariant():
+    """The random initial frames of the defense are keyed like the dither -- (seed, attack call, restart, GLOBAL index of the
+    chunk's first utterance, call number inside the chunk) + the row inside the chunk -- so the two halves of a batch
+    attacked as two ranks would (attacker.index_offset = shard start) reproduce the unsharded run bit for bit: in the
+    device loop and in the host-chained loop."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    hip = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=DEV)
+    x = torch.from_numpy(synth.make_waveforms(4, 24000, seed=76)).to(DEV)
+    y = hip.make_decision(x)[0]
+    for fused in (True, False):
+        def make():
+            dm = defended_model(hip, defense=[(1, FeCoDefense(0.5, init='random', seed=3))])
+            a = PGD(dm, epsilon=0.002, step_size=0.0005, max_iter=3, batch_size=2, EOT_size=2, EOT_batch_size=2, verbose=0)
+            a.fuse_defended = fused
+            return a
+        hip._noise_epoch = 0
+        full = make().attack(x, y)
+        parts = []
+        for lo, hi in ((0, 2), (2, 4)):
+            hip._noise_epoch = 0
+            a = make()
+            a.index_offset = lo
+            parts.append(a.attack(x[lo:hi], y[lo:hi]))
+        assert torch.equal(full[0], torch.cat([p[0] for p in parts], 0)), fused
+        assert list(full[1]) == sum((list(p[1]) for p in parts), [])
+        hip._noise_epoch = 0
+        shifted = make()
+        shifted.index_offset = 2  # utterances 0, 1 attacked as "global utterances 2, 3" see other clusterings
+        assert not torch.equal(shifted.attack(x[0:2], y[0:2])[0], full[0][0:2])
+    log("randomised FeCo (device loop and host-chained loop): halves == full batch bit for bit")
