@@ -10,8 +10,10 @@ randomly initialised third-party k-means and are not reproducible, so parity wit
 the step after the ids (cluster means + empty-cluster fallback, :204-216).  ``init='even'`` (default) starts from
 evenly spaced frames: one input, one output.  ``init='random'`` starts every call from k distinct random frames like
 the reference's k-means does -- a randomised defense, the case expectation-over-transformation attacks are for --
-with draws that are a function of (seed, call number, global utterance index) only (Philox4x32-10), i.e.
-reproducible and independent of how a batch is cut into shards (``index_base``).
+with draws that are a function of (key, utterance row) only (Philox4x32-10).  Called on its own, the key is (seed, call
+number); inside ``defended_model`` it comes from the base model's noise bookkeeping -- (seed, attack call, restart, GLOBAL
+index of the chunk's first utterance, call number inside the chunk), like the MFCC dither -- so an attack is reproducible
+and independent of how the batch is cut into per-GPU shards.
 'warped_kmeans' and the cosine distance are not built.
 """
 import torch
