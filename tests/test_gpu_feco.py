@@ -341,8 +341,8 @@ def test_audionet_feco_fused_loop(capsys):
     # (2) randomised defense + EOT R: replay of the passes with the same keys (R = 3 after R = 2: odd count, workspace regrown)
     for R in (2, 3):
         feco = FeCoDefense(0.5, init='random', seed=7)
-        x_adv, success, dec, scores, loss, _, _ = hip.pgd_run_feco(x, y, lower, upper, spec, step, K, 1, feco, eot_size=R,
-                                                                   eot_batch_size=R)
+        x_adv, success, dec, scores, loss, ltr, dtr = hip.pgd_run_feco(x, y, lower, upper, spec, step, K, 1, feco, eot_size=R,
+                                                                       eot_batch_size=R, trace=True)
         base_seed = hip.last_fused_seed
         replay = FeCoDefense(0.5, init='random', seed=123)  # keys are given explicitly below
         xr = x.clone()
@@ -351,7 +351,9 @@ def test_audionet_feco_fused_loop(capsys):
             dsum = None
             for r in range(R):
                 comp, sv = replay.fwd(feats, seed=hip.fused_pass_seed(base_seed, it, r))
-                _, _, _, g = hip.loss_grad(comp, y, spec, flag=1)
+                dec_p, _, ls_p, g = hip.loss_grad(comp, y, spec, flag=1)
+                if r == 0:  # the per-step records are those of the step's first repeat
+                    assert torch.equal(ls_p, ltr[it]) and torch.equal(dec_p, dtr[it]), (R, it)
                 df = replay.bwd(sv, g)
                 dsum = df if dsum is None else dsum + df  # feature-level sum in repeat order (the compression is linear)
             gw = hip.frontend_backward(saved, dsum)
@@ -359,6 +361,7 @@ def test_audionet_feco_fused_loop(capsys):
         comp, _ = replay.fwd(hip.compute_feat(xr, flag=1), seed=hip.fused_pass_seed(base_seed, K, 0))
         dec_r, sc_r = hip.make_decision(comp, flag=1)
         assert torch.equal(xr, x_adv) and torch.equal(dec_r, dec) and torch.equal(sc_r, scores), R
+        assert torch.equal(ltr[K], loss) and torch.equal(dtr[K], dec)
         assert success.bool().tolist() == (dec != y).tolist()
         assert not torch.equal(x_adv, adv_f)  # the random clusterings lead somewhere else than the evenly started one
 
