@@ -111,10 +111,13 @@ struct FrameState {
 
 // Raw samples of global frame gf (reflect-padded, snip_edges=False), sample n = lane + 64 i -> raw[i].
 // Issued one frame ahead of use so the ~1 us global latency overlaps the previous frame's FFT.
+// rep_utts > 0: the rows are EOT repeats of rep_utts utterances (row = repeat * rep_utts + utterance): every repeat reads
+// the same waveform row.
 __device__ __forceinline__ void load_frame(const float* __restrict__ x, int T, int F, int gf, int total, int lane,
-                                           float (&raw)[7]) {
+                                           float (&raw)[7], int rep_utts) {
     const int g = gf < total ? gf : total - 1;
-    const int b = g / F, f = g - b * F;
+    const int row = g / F, f = g - row * F;
+    const int b = rep_utts > 0 ? row % rep_utts : row;
     const int base = f * kShift - (kWin / 2 - kShift / 2);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -171,7 +174,12 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         if (active && n < kWin) {
             v = raw[i] * scale;
             if (dz.noise_dev) v += dz.noise_dev[((size_t)b * F + f) * kWin + n];
-            else if (dz.dither != 0.f) v += dither_draw(dz.seed, dz.index_base + b, f, n, dz.dither);
+            else if (dz.dither != 0.f) {
+                // repeat r of the batched EOT passes draws from key seed + r * 0xC2B2AE3D27D4EB4F, like the r-th of the
+                // sequential passes it replaces (sg_xv_pgd_run)
+                const int rep = t.rep_utts > 0 ? b / t.rep_utts : 0, utt = t.rep_utts > 0 ? b - rep * t.rep_utts : b;
+                v += dither_draw(dz.seed + (uint64_t)rep * 0xC2B2AE3D27D4EB4Full, dz.index_base + utt, f, n, dz.dither);
+            }
         }
         st.s[i] = v;
         sum += v;
@@ -263,13 +271,13 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
     const int total = B * F, stride = gridDim.x * kWavesPerBlock;
     float raw[7], nxt[7];
-    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt);
+    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt, t.rep_utts);
     for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
         const bool active = true;
 #pragma unroll
         for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
-        load_frame(x, T, F, gf + stride, total, lane, nxt);
+        load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
         FrameState st;
         float cep;
         frame_forward<0>(t, tb, lc, L, raw, F, b, f, active, scale, dz, lane, st, cep);
@@ -311,13 +319,13 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
     const int total = B * F, stride = gridDim.x * kWavesPerBlock;
     float raw[7], nxt[7];
-    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt);
+    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt, t.rep_utts);
     for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
         const bool active = true;
 #pragma unroll
         for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
-        load_frame(x, T, F, gf + stride, total, lane, nxt);
+        load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
         const int fa = active ? f : 0;
         FrameState st;
         float cep;
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
 // Deterministic overlap-add: sample n of utterance b gathers, in a fixed order, every frame
 // position that maps to it -- directly, or through the reflected edges of _get_strided.
 // Optionally fuses the PGD step (attack/FGSM.py:65,68) so the gradient never round-trips HBM.
-__global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __restrict__ dframes, int B, int T, int F,
+__global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __restrict__ dframes, int B, int T, int F, int R,
                                                              const float* acc_in, float* grad_out, float* __restrict__ x_io,
                                                              const float* __restrict__ lower,
                                                              const float* __restrict__ upper, float step, int grad_sign) {
@@ -402,22 +410,29 @@ __global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __rest
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= T) return;
-    const float* df = dframes + (size_t)b * F * kWin;
     constexpr int kPad = kWin / 2 - kShift / 2;
-    float g = 0.f;
-    auto add_pos = [&](int p) {
-        const int q = p + kPad;  // position in the padded signal, >= 0
-        int fhi = q / kShift;
-        int flo = q > kWin - 1 ? (q - (kWin - 1) + kShift - 1) / kShift : 0;
-        if (fhi > F - 1) fhi = F - 1;
-        for (int f = flo; f <= fhi; ++f) g += df[(size_t)f * kWin + (q - f * kShift)];
-    };
-    add_pos(n);
-    if (n < kPad) add_pos(-n - 1);
-    const int pr = 2 * T - 1 - n;
-    if (pr <= (F - 1) * kShift - kPad + kWin - 1) add_pos(pr);
     const size_t o = (size_t)b * T + n;
-    if (acc_in) g = acc_in[o] + g;
+    const int pr = 2 * T - 1 - n;
+    // dframes (R, B, F, 400): R batched EOT repeats of the B utterances; their gradients are summed in repeat order,
+    // exactly as R sequential passes handing the sum on through acc_in did (EOT.py:41-47)
+    float total = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float* df = dframes + ((size_t)r * B + b) * F * kWin;
+        float g = 0.f;
+        auto add_pos = [&](int p) {
+            const int q = p + kPad;  // position in the padded signal, >= 0
+            int fhi = q / kShift;
+            int flo = q > kWin - 1 ? (q - (kWin - 1) + kShift - 1) / kShift : 0;
+            if (fhi > F - 1) fhi = F - 1;
+            for (int f = flo; f <= fhi; ++f) g += df[(size_t)f * kWin + (q - f * kShift)];
+        };
+        add_pos(n);
+        if (n < kPad) add_pos(-n - 1);
+        if (pr <= (F - 1) * kShift - kPad + kWin - 1) add_pos(pr);
+        if (r == 0) total = acc_in ? acc_in[o] + g : g;
+        else total = total + g;
+    }
+    float g = total;
     if (grad_out) grad_out[o] = g;
     if (x_io) {
         const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
@@ -446,11 +461,11 @@ hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, in
     return hipGetLastError();
 }
 
-hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, const float* acc_in, float* grad_out, float* x_io,
-                                 const float* lower, const float* upper, float step, int grad_sign,
+hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, int R, const float* acc_in, float* grad_out,
+                                 float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                  hipStream_t s) {
     dim3 grid((T + 255) / 256, B);
-    hipLaunchKernelGGL(frames_to_wave_kernel, grid, dim3(256), 0, s, dframes, B, T, F, acc_in, grad_out, x_io, lower, upper,
+    hipLaunchKernelGGL(frames_to_wave_kernel, grid, dim3(256), 0, s, dframes, B, T, F, R, acc_in, grad_out, x_io, lower, upper,
                        step, grad_sign);
     return hipGetLastError();
 }

@@ -119,6 +119,8 @@ struct MfccTables {          // device pointers
     // bins 0..255 of every frame's FFT as float2 (computed in fp64, rounded once) and the 30 mel energies
     float2* spec_cache;      // [B*F][256]
     float* mel_cache;        // [B*F][32]
+    int rep_utts;            // > 0: rows are EOT repeats of rep_utts utterances (row = repeat * rep_utts + utterance):
+                             // repeats share the waveform row, repeat r draws its dither from key seed + r * 0xC2B2AE3D27D4EB4F
 };
 
 struct XvModel {
@@ -174,6 +176,7 @@ struct Workspace {
     float* loss = nullptr;             // [B]
     int64_t* decisions = nullptr;      // [B]
     float* grad = nullptr;             // [B][T]
+    int64_t* y_rep = nullptr;          // [B] labels repeated for EOT repeats batched into one pass
     std::vector<void*> allocs;
 };
 
@@ -251,8 +254,9 @@ hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, in
                            const sg_dither* dz, const float* dfeats, float* dframes, hipStream_t s);
 // overlap-add of dframes into d loss / d x (+ acc_in, the sum over earlier EOT repeats; may alias grad_out);
 // optional fused PGD update of x (in place)
-hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, const float* acc_in, float* grad_out, float* x_io,
-                                 const float* lower, const float* upper, float step, int grad_sign,
+// dframes (R, B, F, 400): R batched EOT repeats, summed in repeat order
+hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, int R, const float* acc_in, float* grad_out,
+                                 float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                  hipStream_t s);
 hipError_t launch_pgd_update(float* x, const float* g, const float* lo, const float* hi, int64_t n,
                              float step, int grad_sign, hipStream_t s);
