@@ -827,7 +827,8 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
         if (!layer_frames(F, Fl)) return fail(ctx, SG_ERR_ARG, "%d frames are too few for the TDNN context", F);
         size_t per_utt = 0;
         for (int l = 0; l < kLayers; ++l) per_utt = std::max(per_utt, (size_t)Fl[l] * kCoutPad[l] * sizeof(float));
-        const long max_rows = (long)(0x7FFFFFFFull / per_utt);
+        long max_rows = (long)(0x7FFFFFFFull / per_utt);
+        if (const char* e = getenv("SG_EOT_MAX_ROWS")) max_rows = std::min<long>(max_rows, atol(e));  // tests: force groups
         G = (int)std::min<long>(reps, std::max<long>(1, max_rows / B));
     }
     PassDims d;

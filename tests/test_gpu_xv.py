@@ -450,7 +450,7 @@ def test_fused_loop_equals_stepwise_calls(hip_model, dev):
     assert success.bool().tolist() == (dec != y).tolist()
 
 
-def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev):
+def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev, monkeypatch):
     """The reference's default front-end is random (dither = 1.0, xv_plda.py:119) and EOT averages its gradient over
     fresh draws (EOT.py:16-54).  The fused loop runs those repeats on the device; replaying its per-pass generator
     keys through the per-step API (loss_grad with an explicit key, gradients summed in pass order by torch, then
@@ -479,6 +479,18 @@ def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev):
     assert torch.equal(xa, xb)
     assert torch.equal(dec, d2) and torch.equal(scores, s2) and torch.equal(loss, l2)
     assert success.bool().tolist() == (dec != y).tolist()
+    # the device loop runs the 4 repeats as one batch of 12 rows; when a pass cannot hold them all they go in groups with
+    # the sum handed on (here forced: 2 + 2 repeats, then 1 + 1 + 1 + 1) -- same bits, and the per-step records are those
+    # of the step's first repeat either way
+    m._draw = 100  # same generator key for the three runs
+    ref_tr = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
+    for cap in (6, 3):
+        monkeypatch.setenv("SG_EOT_MAX_ROWS", str(cap))
+        m._draw = 100
+        got = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
+        for a, b in zip(got, ref_tr):
+            assert torch.equal(a, b), cap
+    monkeypatch.delenv("SG_EOT_MAX_ROWS")
     # the repeats really are different draws, and EOT changes the trajectory
     assert not torch.equal(grads[0], grads[1])
     x1 = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=1)[0]
