@@ -219,7 +219,9 @@ typedef struct sg_pgd_params {
     int32_t grad_sign;       /* attack/utils.py:114 */
     int32_t eot_size;        /* EOT.py:16-54: passes per gradient step, each with fresh dither (key = dither.seed +
                               * step * 0x9E3779B97F4A7C15 + repeat * 0xC2B2AE3D27D4EB4F); their data gradients are summed
-                              * in pass order before the sign step.  With dither == 0 all repeats coincide: one pass. */
+                              * in pass order before the sign step.  The repeats of a step are rows of ONE batch
+                              * (eot_size x B rows, as many as fit one pass), with the bits of separate passes.
+                              * With dither == 0 all repeats coincide: one pass. */
     int32_t eot_batch_size;  /* how the reference groups the repeats into model calls; must divide eot_size */
     sg_dither dither;
 } sg_pgd_params;
