@@ -29,6 +29,16 @@ def timed(fn):
     return out, time.perf_counter() - t0
 
 
+# ---- configs[0]: FGSM 1-step on AudioNet CSI-NE, a single 3 s utterance (the reference's CPU-runnable plumbing case)
+from speakerguard_amd.attack.FGSM import FGSM
+an0 = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)
+x0 = torch.from_numpy(synth.make_waveforms(1, 48000, seed=1)).to(dev)
+y0 = an0.make_decision(x0)[0]
+fgsm = FGSM(an0, task="CSI", epsilon=0.002, batch_size=1, verbose=0)
+fgsm.attack(x0, y0)
+(_, succ0), dt = timed(lambda: [fgsm.attack(x0, y0) for _ in range(20)][-1])
+print("configs[0] FGSM (1 step + final pass) on AudioNet, ONE 3 s utterance: %.2f ms per attack, success %s" % (1e3 * dt / 20, succ0))
+
 # ---- configs[2]: CW2, SV (one enrolled speaker, finite threshold), batch 32
 w1 = dict(w); w1["enroll"] = w["enroll"][:1]
 sv = xv_plda.from_weights(w1, threshold=-10.0, device=dev, dither=0.0)
