@@ -5,6 +5,8 @@ evaluates together with d loss / d scores); calling one on a (scores, label) pai
 same formula with torch ops on whatever device the scores live on, for callers that only need
 values (no autograd graph is produced anywhere in this package).
 """
+import ctypes as C
+import math
 import warnings
 from collections import Counter
 
@@ -110,6 +112,11 @@ class ScoreVJP(_Loss):
         s.coef_dev = self.coef.data_ptr()
         return s
 
+    def check(self, B, S):
+        """Called by the models before the native pass reads coef as a (B, S) table."""
+        if tuple(self.coef.shape) != (B, S):
+            raise ValueError("ScoreVJP: coef is %s, the pass scores %d rows against %d speakers" % (tuple(self.coef.shape), B, S))
+
     def forward(self, scores, label=None):
         return (self.coef.to(scores.device) * scores).sum(1)
 
@@ -124,8 +131,6 @@ def loss_dscores(model, scores, label, loss_spec):
     dec = torch.empty(B, device=scores.device, dtype=torch.int64)
     loss = torch.empty(B, device=scores.device, dtype=torch.float32)
     dsc = torch.empty(B, S, device=scores.device, dtype=torch.float32)
-    import ctypes as C
-    import math
     thr = float(base.threshold) if base.threshold is not None and np.isfinite(base.threshold) else -math.inf
     spec = loss_spec.native()
     base.ctx.call("sg_loss_eval", N._ptr(scores), N._ptr(label), B, S, thr, C.byref(spec), N._ptr(dec), N._ptr(loss),

@@ -16,6 +16,8 @@ index of the chunk's first utterance, call number inside the chunk), like the MF
 and independent of how the batch is cut into per-GPU shards.
 'warped_kmeans' and the cosine distance are not built.
 """
+import ctypes as C
+
 import torch
 
 from .. import _native as N
@@ -53,7 +55,6 @@ class FeCoDefense:
         ids = torch.empty(B, F, device=feat.device, dtype=torch.int32)
         out = torch.empty(B, k, D, device=feat.device, dtype=torch.float32)
         counts = torch.empty(B, k, device=feat.device, dtype=torch.int32)
-        import ctypes as C
         key = 0
         if self.init == 'random':
             key = self.call_seed(self.calls) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF

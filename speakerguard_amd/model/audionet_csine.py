@@ -156,6 +156,8 @@ class audionet_csine(EngineOps):
         scores = torch.empty(B, self.num_spks, device=self.device, dtype=torch.float32)
         loss = torch.empty(B, device=self.device, dtype=torch.float32)
         grad = torch.empty_like(x) if want_grad else None
+        if hasattr(loss_spec, 'check'):
+            loss_spec.check(B, self.num_spks)
         spec = loss_spec.native()
         self.ctx.call("sg_an_loss_grad", N._ptr(x), N._ptr(y), B, TF, flag, C.byref(spec), N._ptr(dec), N._ptr(scores),
                       N._ptr(loss), N._ptr(grad), self._stream())

@@ -329,6 +329,8 @@ class xv_plda(EngineOps):
         loss = torch.empty(B, device=self.device, dtype=torch.float32)
         grad = torch.empty_like(x) if want_grad else None
         dz = self._dither(dither_noise, dither_seed)
+        if hasattr(loss_spec, 'check'):
+            loss_spec.check(B, self.num_spks)
         spec = loss_spec.native()
         self.ctx.call("sg_xv_loss_grad", N._ptr(x), N._ptr(y), B, TF, flag, C.byref(spec), C.byref(dz), N._ptr(dec),
                       N._ptr(scores), N._ptr(loss), N._ptr(grad), self._stream())

@@ -151,6 +151,8 @@ class QueryShardedModel:
         self.group = group
 
     def __getattr__(self, name):  # threshold, make_decision, nes_queries, fakebob_step, ...: the wrapped model's
+        if name in ('model', 'base_model', 'group'):  # not set yet (copy / unpickle): no recursion through self.model
+            raise AttributeError(name)
         return getattr(self.model, name)
 
     def eval(self):

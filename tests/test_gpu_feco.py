@@ -436,6 +436,8 @@ def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
     (coef_a * oan.make_decision(xin)[1]).sum().backward()
     e_an = rel(ga.cpu().numpy(), xin.grad.numpy())
     assert rms_hip <= 2 * rms_ora and rms_hip < 2e-2 and e_xv < 5e-2 and e_an < 2e-3, (rms_hip, rms_ora, e_xv, e_an)
+    with pytest.raises(ValueError, match="ScoreVJP"):  # a (B, S) table of the wrong shape is refused before the pass reads it
+        hip_model.loss_grad(x.to(DEV), y0, ScoreVJP(coef[:2].to(DEV)))
     # the loss stage alone on given scores == the tail kernel's own
     spec = SEC4SR_MarginLoss(targeted=False, confidence=0.5, task='CSI', threshold=None, clip_max=True)
     yv = torch.tensor([1, 7, 3], device=DEV)
