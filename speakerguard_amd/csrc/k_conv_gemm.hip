@@ -963,6 +963,155 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Nearly empty chip (batch 1-4: the reference's default batch_size is 1 and real utterances differ in length, so one
+// utterance per call is the common drop-in case): a 32 x 128 tile keeps ONE CU busy for the whole k range -- 114 k
+// matrix-pipe cycles for tdnn3, 48 us, while 36 tiles leave 220 CUs idle.  Smaller tiles need a smaller MFMA:
+// v_mfma_f32_16x16x4_f32 -- and tools/native/mfma_order.hip shows that both f32 MFMA shapes ARE a sequential fmaf chain
+// over k (bit for bit, 20480 outputs, K up to 3584), so a 16 x 16 block fed the k values in the order the 32x32x2 kernels
+// consume them -- per k-group of 8: (0, 4, 1, 5) then (2, 6, 3, 7) -- gives the same bits with a quarter of the
+// per-tile work: 544 independent waves at batch 1 instead of 144.
+// A block is four waves = 32 x 32 outputs.  Per chunk of 32 k the block stages 32 rows x 32 k of A and 32 k x 32 columns
+// of the k4-packed W in LDS (one 16-byte load of each per thread, coalesced; the same images and the same XOR swizzle
+// as the quad-fed kernels), through a register ring D chunks deep -- a chunk is only ~300 cycles of MFMA chain, so the
+// loads run ~2000 cycles ahead -- and three LDS stages, so that a wave fetches the NEXT chunk's operands from
+// LDS while the MFMA chain of the current one runs.  Lane (row l % 16, k-half h = (l / 16) & 1, element pair
+// e = l / 32) reads the 16 bytes A[row][8 kg + 4 h ..] and W[2 kg + h][col l % 16][..] of a k-group and feeds elements
+// e and 2 + e of each to the k-group's two MFMAs.  (A first version without LDS, every lane loading its operands
+// straight from L2, was slower than the 32-row tiles: 16 rows x 2 halves = 32 cache lines per load instruction keep
+// the CU's texture path busier than the MFMA chain.)  Out-of-range tap rows come back as zeros from the buffer bounds
+// check, as everywhere.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int EPI, int D>
+__global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int ntile32) {
+    static_assert(D % 3 == 0, "the LDS stage of a chunk is taken from its ring slot");
+    constexpr int A_STAGE = 32 * 32, STAGE = A_STAGE + 8 * 32 * 4;  // floats: A 4 KB + W 4 KB
+    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int bm0 = ((int)blockIdx.x / ntile32) * 32, bn0 = ((int)blockIdx.x % ntile32) * 32;
+    constexpr unsigned kOob = 0x80000000u;
+    // ---- staging role of this thread: A float4 (row tid / 8, slot tid % 8), W float4 (k4-group tid / 32, column tid % 32)
+    const int srow = bm0 + (tid >> 3), c4 = tid & 7;
+    const bool srow_ok = srow < p.M;
+    const int sb = srow_ok ? srow / p.Tc : 0;
+    const int st = srow_ok ? srow - sb * p.Tc : 0;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
+    const unsigned a_base = ((unsigned)(sb * p.Ta + st) * (unsigned)p.lda + (unsigned)(4 * c4)) * 4u;
+    const unsigned w_voff = (unsigned)(((tid >> 5) * p.ldw + bn0 + (tid & 31)) * 16);
+    auto tap_voff = [&](int j) {
+        const int off = p.tap_base + j * p.tap_step;
+        const bool ok = srow_ok && (unsigned)(st + off) < (unsigned)p.Ta;
+        return ok ? a_base + (unsigned)(off * p.lda * 4) : kOob;
+    };
+    float* st_a = smem + (tid >> 3) * 32 + ((c4 ^ ((tid >> 4) & 7)) << 2);  // stage 0; row r slot c at c ^ ((r >> 1) & 7)
+    float* st_w = smem + A_STAGE + tid * 4;
+    const int C = p.total_chunks;
+    int ld_j = 0, ld_k = 0;  // load cursor: tap, k inside the tap
+    unsigned a_voff = tap_voff(0), w_v = w_voff;
+    if (p.ablate & 1) a_voff = w_v = kOob;  // timing experiment: no memory traffic (results become wrong)
+    i32x4 ra[D], rw[D];
+    // Loads, LDS stores and operand reads are issued UNCONDITIONALLY (past the last chunk they carry out-of-range
+    // offsets: the bounds check returns zeros without touching memory): a load behind a branch makes hipcc lose count of
+    // what is in flight and wait vmcnt(0) before every LDS store -- the whole L2 latency once per chunk, measured 50 us
+    // for tdnn3 at batch 1 against 78 us for the 32-row tiles and ~17 us of MFMA chain.  Only the MFMAs are guarded.
+    auto issue = [&](i32x4& a, i32x4& w) {
+        a = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff, ld_k * 4, 0);
+        w = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_v, ((ld_j * p.Kc + ld_k) >> 2) * p.ldw * 16, 0);
+        ld_k += BK;
+        if (ld_k == p.Kc) {
+            ld_k = 0;
+            ++ld_j;
+            const bool more = ld_j < p.taps;
+            a_voff = (more && !(p.ablate & 1)) ? tap_voff(ld_j) : kOob;
+            w_v = (more && !(p.ablate & 1)) ? w_voff : kOob;
+        }
+    };
+    auto store = [&](const i32x4& a, const i32x4& w, int stage) {
+        *reinterpret_cast<i32x4*>(st_a + stage * STAGE) = a;
+        *reinterpret_cast<i32x4*>(st_w + stage * STAGE) = w;
+    };
+    // ---- compute role: wave (wm, wn) owns rows 16 wm .., columns 16 wn .. of the block
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l16 = lane & 15, g = lane >> 4, h = g & 1, e = g >> 1;
+    const int arow = 16 * wm + l16;
+    const int sw = (arow >> 1) & 7;
+    const float* rd_a = smem + arow * 32;
+    const float* rd_w = smem + A_STAGE + (h * 32 + 16 * wn + l16) * 4;
+    float4 ca[4], cw[4], na[4], nw[4];  // operands of the chunk being multiplied / of the next one
+    auto read_ops = [&](float4 (&a)[4], float4 (&w)[4], int stage) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            a[kg] = *reinterpret_cast<const float4*>(rd_a + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
+            w[kg] = *reinterpret_cast<const float4*>(rd_w + stage * STAGE + kg * 2 * 32 * 4);
+        }
+    };
+    // prologue: D chunks in flight, chunks 0 and 1 staged, operands of chunk 0 in registers
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(ra[j], rw[j]);
+    store(ra[0], rw[0], 0);
+    issue(ra[0], rw[0]);
+    store(ra[1], rw[1], 1);
+    issue(ra[1], rw[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    read_ops(ca, cw, 0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int c = c0 + j;  // c % 3 == j % 3 and c % D == j: c0 is a multiple of D, D of 3
+            // chunk c + 2 -> the stage chunk c - 1 was read from (its reads were issued during iteration c - 2 and are long
+            // complete); its ring slot is refilled with chunk c + 2 + D
+            store(ra[(j + 2) % D], rw[(j + 2) % D], (j + 2) % 3);
+            issue(ra[(j + 2) % D], rw[(j + 2) % D]);
+            // operands of chunk c + 1 (staged during iteration c - 1, published by the barrier that ended it): their LDS
+            // latency runs under the MFMA chain of chunk c
+            read_ops(na, nw, (j + 1) % 3);
+            if (c < C && !(p.ablate & 16)) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[kg].y : ca[kg].x, e ? cw[kg].y : cw[kg].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[kg].w : ca[kg].z, e ? cw[kg].w : cw[kg].z, acc, 0, 0, 0);
+                }
+            }
+            // LDS-only barrier (__syncthreads() would also wait for every global load in flight)
+            if (!(p.ablate & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                ca[kg] = na[kg];
+                cw[kg] = nw[kg];
+            }
+        }
+    }
+    const int m0 = bm0 + 16 * wm, col = bn0 + 16 * wn + l16;
+    float bias = 0.f;
+    if (EPI == EPI_BIAS_RELU) bias = p.bias[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ro = m0 + 4 * g + r;
+        if (ro < p.M) {
+            float v = acc[r];
+            if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+            if (EPI == EPI_RELU_MASK) v = p.mask[(size_t)ro * p.ldc + col] > 0.f ? v : 0.f;
+            p.C[(size_t)ro * p.ldc + col] = v;
+        }
+    }
+}
+
+static hipError_t launch_s16(const ConvGemmArgs& a, int epi, hipStream_t s) {
+    constexpr int R = 6;  // chunks in flight per thread (multiple of 3)
+    const int ntile32 = a.N / 32;
+    dim3 grid(((a.M + 31) / 32) * ntile32);
+    switch (epi) {
+        case EPI_NONE: hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI_NONE, R>), grid, dim3(256), 0, s, a, ntile32); break;
+        case EPI_BIAS_RELU: hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI_BIAS_RELU, R>), grid, dim3(256), 0, s, a, ntile32); break;
+        case EPI_RELU_MASK: hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI_RELU_MASK, R>), grid, dim3(256), 0, s, a, ntile32); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int MI>
 static hipError_t launch_tile_q_mi(const ConvGemmArgs& a, int epi, hipStream_t s) {
     const int mtiles = (a.M + 32 * MI - 1) / (32 * MI), ntiles = a.N / 128;
@@ -1175,6 +1324,14 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     if (a_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) return hipErrorInvalidValue;
     a.a_bytes = (unsigned)a_bytes;
     a.w_bytes = (unsigned)w_bytes;
+    // batch 1-4: so few 16 x 16 output blocks that every one can have a SIMD (almost) to itself
+    static const long s16_max = [] {
+        const char* e = getenv("SG_S16_MAX_BLOCKS");  // 0 = never (tuning aid)
+        return e ? atol(e) : 2304L;
+    }();
+    if ((tile == 0 || tile == 2) && splits == 1 && a.Wq && (a.N % 32) == 0 &&
+        (a.force == 5 || (a.force == 0 && a.total_chunks >= 4 && (long)((a.M + 15) / 16) * (a.N / 16) <= s16_max)))
+        return launch_s16(a, epi, s);
     switch (tile) {
         case 0: {
             if (a.N % 128) return hipErrorInvalidValue;

@@ -64,7 +64,7 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     B, Ta, Tc, Kc, n, taps, step, base = shape
     a, w = _case(7, B, Ta, Tc, Kc, n, taps)
     want = conv1d_rows(a, w, B, Ta, Tc, taps, step, base)
-    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2, 3, 4)]
+    outs = [_run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k) for k in (0, 1, 2, 3, 4, 5)]
     scale = np.abs(want).max()
     for k, o in enumerate(outs):
         assert np.isfinite(o).all(), "kernel %d left rows unwritten" % k
@@ -74,6 +74,8 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     assert np.array_equal(outs[2], outs[1]), "b32-fed stream-K differs from the tile launch"
     assert np.array_equal(outs[3], outs[1]), "8-wave quad-fed stream-K differs from the tile launch"
     assert np.array_equal(outs[4], outs[1]), "quad-fed tile launch differs from the b32-fed tile launch"
+    # v_mfma_f32_16x16x4_f32 fed the k values in the order the 32x32x2 kernels consume them: the same fmaf chain
+    assert np.array_equal(outs[5], outs[1]), "16 x 16 blocks (small-batch kernel) differ from the tile launch"
 
 
 def test_conv_rows_epilogues(ctx):
