@@ -8,7 +8,15 @@ OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS))
 LIB   := speakerguard_amd/libspeakerguard_hip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 
-all: $(LIB)
+ORACLE_SO := oracle/libconv_chain.so
+
+all: $(LIB) $(ORACLE_SO)
+
+# the CPU checker's C part (test infrastructure: never linked into the product library)
+$(ORACLE_SO): oracle/conv_chain.c
+	gcc -O2 -mfma -fopenmp -ffp-contract=off -shared -fPIC $< -o $@ -lm
+
+oracle: $(ORACLE_SO)
 
 $(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h $(CSRC)/fft512.h $(CSRC)/loss_device.h include/speakerguard_hip.h
 	@mkdir -p $(OBJ)
@@ -18,6 +26,6 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(ORACLE_SO)
 
-.PHONY: all clean
+.PHONY: all clean oracle

@@ -76,6 +76,11 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     assert np.array_equal(outs[4], outs[1]), "quad-fed tile launch differs from the b32-fed tile launch"
     # v_mfma_f32_16x16x4_f32 fed the k values in the order the 32x32x2 kernels consume them: the same fmaf chain
     assert np.array_equal(outs[5], outs[1]), "16 x 16 blocks (small-batch kernel) differ from the tile launch"
+    # and all of them ARE the documented arithmetic: one float32 fmaf chain per output in the kernels' k order, restated
+    # in C on the CPU (oracle/conv_chain.c) -- bit for bit, signs of zeros included
+    from oracle.conv_chain import conv_chain
+    chain = conv_chain(a, w, B, Ta, Tc, taps, step, base)
+    assert np.array_equal(outs[1].view(np.uint32), chain.view(np.uint32)), "device result is not the restated fmaf chain"
 
 
 def test_conv_rows_epilogues(ctx):
@@ -91,6 +96,10 @@ def test_conv_rows_epilogues(ctx):
         o4 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 4, **kw)
         assert np.abs(o0 - want).max() / np.abs(want).max() < 2e-5
         assert np.array_equal(o0, o1) and np.array_equal(o4, o1)
+        o5 = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, epi, 5, **kw)
+        from oracle.conv_chain import conv_chain
+        chain = conv_chain(a, w, B, Ta, Tc, taps, step, 0, **kw)
+        assert np.array_equal(o5, o1) and np.array_equal(o1.view(np.uint32), chain.view(np.uint32))
 
 
 def test_conv_rows_is_torch_conv1d(ctx):
