@@ -1009,7 +1009,6 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     const int C = p.total_chunks;
     int ld_j = 0, ld_k = 0;  // load cursor: tap, k inside the tap
     unsigned a_voff = tap_voff(0), w_v = w_voff;
-    if (p.ablate & 1) a_voff = w_v = kOob;  // timing experiment: no memory traffic (results become wrong)
     i32x4 ra[D], rw[D];
     // Loads, LDS stores and operand reads are issued UNCONDITIONALLY (past the last chunk they carry out-of-range
     // offsets: the bounds check returns zeros without touching memory): a load behind a branch makes hipcc lose count of
@@ -1023,8 +1022,8 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
             ld_k = 0;
             ++ld_j;
             const bool more = ld_j < p.taps;
-            a_voff = (more && !(p.ablate & 1)) ? tap_voff(ld_j) : kOob;
-            w_v = (more && !(p.ablate & 1)) ? w_voff : kOob;
+            a_voff = more ? tap_voff(ld_j) : kOob;
+            w_v = more ? w_voff : kOob;
         }
     };
     auto store = [&](const i32x4& a, const i32x4& w, int stage) {
@@ -1067,7 +1066,7 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
             // operands of chunk c + 1 (staged during iteration c - 1, published by the barrier that ended it): their LDS
             // latency runs under the MFMA chain of chunk c
             read_ops(na, nw, (j + 1) % 3);
-            if (c < C && !(p.ablate & 16)) {
+            if (c < C) {
 #pragma unroll
                 for (int kg = 0; kg < 4; ++kg) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[kg].y : ca[kg].x, e ? cw[kg].y : cw[kg].x, acc, 0, 0, 0);
@@ -1075,8 +1074,7 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
                 }
             }
             // LDS-only barrier (__syncthreads() would also wait for every global load in flight)
-            if (!(p.ablate & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
                 ca[kg] = na[kg];

@@ -232,7 +232,7 @@ struct ConvGemmArgs {
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
     int force;          // 0 auto, 1 one b32-fed block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave,
                         // 4 one quad-fed block per tile, 5 one 16 x 16 block per wave (parity tests)
-    int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier, 16 no MFMAs (s16 kernel);
+    int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier;
                         // 8 = fault injection: stream-K hand-off flags are never published (health-word test)
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags

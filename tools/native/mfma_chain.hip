@@ -46,8 +46,15 @@ int main() {
     {
         float* d; long long* c; (void)hipMalloc(&d, 64); (void)hipMalloc(&c, 64);
         long long h[4];
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int blocks : {1, 136, 272}) {
-            hipLaunchKernelGGL(chain16_block, dim3(blocks), dim3(256), 0, 0, d, c, 20000, 0.5f, 0.25f); (void)hipDeviceSynchronize();
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(chain16_block, dim3(blocks), dim3(256), 0, 0, d, c, 20000, 0.5f, 0.25f);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("  (kernel %.3f ms by HIP events: with the cycle count below the shader clock of this short launch is ~%.2f GHz)\n", ms,
+                   20000.0 * (blocks > 256 ? 64.0 : 44.0) / (ms * 1e6));
+            (void)hipDeviceSynchronize();
             (void)hipMemcpy(h, c, 32, hipMemcpyDeviceToHost);
             printf("4 waves per block, %3d blocks: %.1f %.1f %.1f %.1f cycles per dependent 16x16x4 MFMA (waves 0..3 of the last block to write)\n",
                    blocks, h[0] / 20000.0, h[1] / 20000.0, h[2] / 20000.0, h[3] / 20000.0);
