@@ -1055,24 +1055,35 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     read_ops(ca, cw, 0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto read_one = [&](float4& a, float4& w, int kg, int stage) {
+        a = *reinterpret_cast<const float4*>(rd_a + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
+        w = *reinterpret_cast<const float4*>(rd_w + stage * STAGE + kg * 2 * 32 * 4);
+    };
+    // The loop runs to the next multiple of D and is free of branches: past the last chunk the staged operands are the
+    // zeros of the out-of-range loads, and fmaf(0, 0, acc) == acc exactly (an accumulator that starts at +0 never becomes
+    // -0: x + (-x) rounds to +0), so the surplus MFMAs change nothing.  One basic block lets hipcc keep exact counts of the
+    // loads in flight AND lets every other instruction be placed behind an MFMA of the dependent chain (44 cycles each,
+    // 32 of them busy), where it issues for free.
     for (int c0 = 0; c0 < C; c0 += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            const int c = c0 + j;  // c % 3 == j % 3 and c % D == j: c0 is a multiple of D, D of 3
-            // chunk c + 2 -> the stage chunk c - 1 was read from (its reads were issued during iteration c - 2 and are long
-            // complete); its ring slot is refilled with chunk c + 2 + D
+            // chunk c = c0 + j (c % 3 == j % 3, c % D == j): its operands are in ca / cw.  Chunk c + 2 goes from its ring slot
+            // to the LDS stage chunk c - 1 was read from, the slot is refilled with chunk c + 2 + D, and the operands of chunk
+            // c + 1 (staged during iteration c - 1, published by the barrier that ended it) are fetched from LDS.
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[0].y : ca[0].x, e ? cw[0].y : cw[0].x, acc, 0, 0, 0);
             store(ra[(j + 2) % D], rw[(j + 2) % D], (j + 2) % 3);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[0].w : ca[0].z, e ? cw[0].w : cw[0].z, acc, 0, 0, 0);
             issue(ra[(j + 2) % D], rw[(j + 2) % D]);
-            // operands of chunk c + 1 (staged during iteration c - 1, published by the barrier that ended it): their LDS
-            // latency runs under the MFMA chain of chunk c
-            read_ops(na, nw, (j + 1) % 3);
-            if (c < C) {
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[kg].y : ca[kg].x, e ? cw[kg].y : cw[kg].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[kg].w : ca[kg].z, e ? cw[kg].w : cw[kg].z, acc, 0, 0, 0);
-                }
-            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[1].y : ca[1].x, e ? cw[1].y : cw[1].x, acc, 0, 0, 0);
+            read_one(na[0], nw[0], 0, (j + 1) % 3);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[1].w : ca[1].z, e ? cw[1].w : cw[1].z, acc, 0, 0, 0);
+            read_one(na[1], nw[1], 1, (j + 1) % 3);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[2].y : ca[2].x, e ? cw[2].y : cw[2].x, acc, 0, 0, 0);
+            read_one(na[2], nw[2], 2, (j + 1) % 3);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[2].w : ca[2].z, e ? cw[2].w : cw[2].z, acc, 0, 0, 0);
+            read_one(na[3], nw[3], 3, (j + 1) % 3);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[3].y : ca[3].x, e ? cw[3].y : cw[3].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[3].w : ca[3].z, e ? cw[3].w : cw[3].z, acc, 0, 0, 0);
             // LDS-only barrier (__syncthreads() would also wait for every global load in flight)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
