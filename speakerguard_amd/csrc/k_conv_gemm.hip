@@ -1026,9 +1026,13 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
             w_v = more ? w_voff : kOob;
         }
     };
+    // A lane needs elements e and 2 + e of a 16-byte group (k = 4 h + e and 4 h + 2 + e).  The groups are staged with their
+    // middle elements swapped -- (k0, k2, k1, k3) -- so that the pair is one aligned 8-byte read: half the LDS bytes of a
+    // 16-byte read (the four waves of a block hit the LDS together after every barrier: with 16-byte reads it was busy
+    // 320 of a chunk's ~770 cycles and the MFMA chain waited behind it) and no select instructions in front of the MFMAs.
     auto store = [&](const i32x4& a, const i32x4& w, int stage) {
-        *reinterpret_cast<i32x4*>(st_a + stage * STAGE) = a;
-        *reinterpret_cast<i32x4*>(st_w + stage * STAGE) = w;
+        *reinterpret_cast<i32x4*>(st_a + stage * STAGE) = i32x4{a.x, a.z, a.y, a.w};
+        *reinterpret_cast<i32x4*>(st_w + stage * STAGE) = i32x4{w.x, w.z, w.y, w.w};
     };
     // ---- compute role: wave (wm, wn) owns rows 16 wm .., columns 16 wn .. of the block
     const int wm = wid >> 1, wn = wid & 1;
@@ -1037,12 +1041,15 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     const int sw = (arow >> 1) & 7;
     const float* rd_a = smem + arow * 32;
     const float* rd_w = smem + A_STAGE + (h * 32 + 16 * wn + l16) * 4;
-    float4 ca[4], cw[4], na[4], nw[4];  // operands of the chunk being multiplied / of the next one
-    auto read_ops = [&](float4 (&a)[4], float4 (&w)[4], int stage) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 ca[4], cw[4], na[4], nw[4];  // operands of the chunk being multiplied / of the next one: (k = 4 h + e, 4 h + 2 + e)
+    const float* rd_ae = rd_a + 2 * e;
+    const float* rd_we = rd_w + 2 * e;
+    auto read_ops = [&](f32x2 (&a)[4], f32x2 (&w)[4], int stage) {
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
-            a[kg] = *reinterpret_cast<const float4*>(rd_a + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
-            w[kg] = *reinterpret_cast<const float4*>(rd_w + stage * STAGE + kg * 2 * 32 * 4);
+            a[kg] = *reinterpret_cast<const f32x2*>(rd_ae + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
+            w[kg] = *reinterpret_cast<const f32x2*>(rd_we + stage * STAGE + kg * 2 * 32 * 4);
         }
     };
     // prologue: D chunks in flight, chunks 0 and 1 staged, operands of chunk 0 in registers
@@ -1055,9 +1062,9 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     read_ops(ca, cw, 0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    auto read_one = [&](float4& a, float4& w, int kg, int stage) {
-        a = *reinterpret_cast<const float4*>(rd_a + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
-        w = *reinterpret_cast<const float4*>(rd_w + stage * STAGE + kg * 2 * 32 * 4);
+    auto read_one = [&](f32x2& a, f32x2& w, int kg, int stage) {
+        a = *reinterpret_cast<const f32x2*>(rd_ae + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
+        w = *reinterpret_cast<const f32x2*>(rd_we + stage * STAGE + kg * 2 * 32 * 4);
     };
     // The loop runs to the next multiple of D and is free of branches: past the last chunk the staged operands are the
     // zeros of the out-of-range loads, and fmaf(0, 0, acc) == acc exactly (an accumulator that starts at +0 never becomes
@@ -1070,20 +1077,20 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
             // chunk c = c0 + j (c % 3 == j % 3, c % D == j): its operands are in ca / cw.  Chunk c + 2 goes from its ring slot
             // to the LDS stage chunk c - 1 was read from, the slot is refilled with chunk c + 2 + D, and the operands of chunk
             // c + 1 (staged during iteration c - 1, published by the barrier that ended it) are fetched from LDS.
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[0].y : ca[0].x, e ? cw[0].y : cw[0].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0].x, cw[0].x, acc, 0, 0, 0);
             store(ra[(j + 2) % D], rw[(j + 2) % D], (j + 2) % 3);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[0].w : ca[0].z, e ? cw[0].w : cw[0].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0].y, cw[0].y, acc, 0, 0, 0);
             issue(ra[(j + 2) % D], rw[(j + 2) % D]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[1].y : ca[1].x, e ? cw[1].y : cw[1].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[1].x, cw[1].x, acc, 0, 0, 0);
             read_one(na[0], nw[0], 0, (j + 1) % 3);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[1].w : ca[1].z, e ? cw[1].w : cw[1].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[1].y, cw[1].y, acc, 0, 0, 0);
             read_one(na[1], nw[1], 1, (j + 1) % 3);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[2].y : ca[2].x, e ? cw[2].y : cw[2].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[2].x, cw[2].x, acc, 0, 0, 0);
             read_one(na[2], nw[2], 2, (j + 1) % 3);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[2].w : ca[2].z, e ? cw[2].w : cw[2].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[2].y, cw[2].y, acc, 0, 0, 0);
             read_one(na[3], nw[3], 3, (j + 1) % 3);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[3].y : ca[3].x, e ? cw[3].y : cw[3].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? ca[3].w : ca[3].z, e ? cw[3].w : cw[3].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[3].x, cw[3].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[3].y, cw[3].y, acc, 0, 0, 0);
             // LDS-only barrier (__syncthreads() would also wait for every global load in flight)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
