@@ -306,7 +306,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
  * rows outside [0, Ta) of an utterance contribute zero.  A: (B*Ta, Kc) floats, W: (taps*Kc, N), C: (B*Tc, N);
  * Kc % 32 == 0, N % 128 == 0.  epi: 0 none, 1 relu(acc + bias[n]), 2 acc where mask[row][n] > 0 else 0
  * (mask shaped like C).  kernel: 0 = what the TDNN layers get (stream-K with 16-wave 256x128 quad-fed blocks when
- * the shape qualifies, one 16x16 block per wave on the 16x16x4 MFMA when there are at most 2304 such blocks, else one
+ * the shape qualifies, one 16x16 block per wave on the 16x16x4 MFMA when there are at most 2800 such blocks, else one
  * quad-fed 64x128 block per tile), 1 = one b32-fed 64x128 block per tile, 2 = stream-K with the b32-fed 8-wave kernel,
  * 3 = stream-K with 8-wave 128x128 quad-fed blocks, 4 = one quad-fed 64x128 block per tile, 5 = one 16x16 block per
  * wave.  All choices give bit-identical results: the float32 fmaf chain restated in oracle/conv_chain.c. */

@@ -1343,7 +1343,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     // batch 1-4: so few 16 x 16 output blocks that every one can have a SIMD (almost) to itself
     static const long s16_max = [] {
         const char* e = getenv("SG_S16_MAX_BLOCKS");  // 0 = never (tuning aid)
-        return e ? atol(e) : 2304L;
+        return e ? atol(e) : 2800L;
     }();
     if ((tile == 0 || tile == 2) && splits == 1 && a.Wq && (a.N % 32) == 0 &&
         (a.force == 5 || (a.force == 0 && a.total_chunks >= 4 && (long)((a.M + 15) / 16) * (a.N / 16) <= s16_max)))
