@@ -34,7 +34,7 @@ EPS, STEP = 0.002, 0.0004
 FLOP_PER_UTT_STEP = 4.70e9
 
 
-def cpu_baseline(weights, budget_utts=16, steps=3, gpu_model=None):
+def cpu_baseline(weights, budget_utts=32, steps=3, gpu_model=None):
     """Reference-equivalent CPU path = the oracle in its structure-faithful form (per-utterance
     MFCC/TDNN loops, Python CMVN loop, autograd with parameters requiring grad), timed on this
     host's cores on a bounded sample of the same workload."""
