@@ -982,7 +982,7 @@ static hipError_t launch_tile(const ConvGemmArgs& a, int epi, int splits, hipStr
 // the CU's texture path busier than the MFMA chain.)  Out-of-range tap rows come back as zeros from the buffer bounds
 // check, as everywhere.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int EPI, int D>
+template <int EPI, int D, bool TRACE>
 __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int ntile32) {
     static_assert(D % 3 == 0, "the LDS stage of a chunk is taken from its ring slot");
     constexpr int A_STAGE = 32 * 32, STAGE = A_STAGE + 8 * 32 * 4;  // floats: A 4 KB + W 4 KB
@@ -1042,15 +1042,14 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     const float* rd_a = smem + arow * 32;
     const float* rd_w = smem + A_STAGE + (h * 32 + 16 * wn + l16) * 4;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 ca[4], cw[4], na[4], nw[4];  // operands of the chunk being multiplied / of the next one: (k = 4 h + e, 4 h + 2 + e)
+    // operands (k = 4 h + e, 4 h + 2 + e) of the chunk being multiplied and of the next one: two register sets that swap
+    // roles every chunk (the set is a compile-time function of the unrolled ring slot: no copies)
+    f32x2 oa[2][4], ow[2][4];
     const float* rd_ae = rd_a + 2 * e;
     const float* rd_we = rd_w + 2 * e;
-    auto read_ops = [&](f32x2 (&a)[4], f32x2 (&w)[4], int stage) {
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            a[kg] = *reinterpret_cast<const f32x2*>(rd_ae + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
-            w[kg] = *reinterpret_cast<const f32x2*>(rd_we + stage * STAGE + kg * 2 * 32 * 4);
-        }
+    auto read_one = [&](f32x2& a, f32x2& w, int kg, int stage) {
+        a = *reinterpret_cast<const f32x2*>(rd_ae + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
+        w = *reinterpret_cast<const f32x2*>(rd_we + stage * STAGE + kg * 2 * 32 * 4);
     };
     // prologue: D chunks in flight, chunks 0 and 1 staged, operands of chunk 0 in registers
 #pragma unroll
@@ -1060,23 +1059,31 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     store(ra[1], rw[1], 1);
     issue(ra[1], rw[1]);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    read_ops(ca, cw, 0);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) read_one(oa[0][kg], ow[0][kg], kg, 0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    auto read_one = [&](f32x2& a, f32x2& w, int kg, int stage) {
-        a = *reinterpret_cast<const f32x2*>(rd_ae + stage * STAGE + (((2 * kg + h) ^ sw) << 2));
-        w = *reinterpret_cast<const f32x2*>(rd_we + stage * STAGE + kg * 2 * 32 * 4);
-    };
+    long long t_chain = 0, t_bar = 0, t_all0 = 0;  // SG_S16_TRACE (tuning aid): cycles of block 0, wave 0
+    const bool tracing = TRACE && p.trace != nullptr && blockIdx.x == 0 && tid == 0;
+    if (tracing) t_all0 = __builtin_readcyclecounter();
     // The loop runs to the next multiple of D and is free of branches: past the last chunk the staged operands are the
     // zeros of the out-of-range loads, and fmaf(0, 0, acc) == acc exactly (an accumulator that starts at +0 never becomes
     // -0: x + (-x) rounds to +0), so the surplus MFMAs change nothing.  One basic block lets hipcc keep exact counts of the
     // loads in flight AND lets every other instruction be placed behind an MFMA of the dependent chain (44 cycles each,
-    // 32 of them busy), where it issues for free.
+    // 32 of them busy), where it issues for free: the hand-over of chunk c + 2 from its ring slot to LDS and the slot's
+    // refill first, then the LDS reads of the next chunk's operands (reading first made the four waves of a block collide in
+    // the LDS right after the barrier and stretched the chain from 460 to 610 cycles).
+    static_assert(D % 2 == 0, "the operand register set of a chunk is taken from its ring slot");
     for (int c0 = 0; c0 < C; c0 += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            // chunk c = c0 + j (c % 3 == j % 3, c % D == j): its operands are in ca / cw.  Chunk c + 2 goes from its ring slot
-            // to the LDS stage chunk c - 1 was read from, the slot is refilled with chunk c + 2 + D, and the operands of chunk
-            // c + 1 (staged during iteration c - 1, published by the barrier that ended it) are fetched from LDS.
+            // chunk c = c0 + j (c % 3 == j % 3, c % 2 == j % 2, c % D == j): its operands are in set j % 2.  The operands of
+            // chunk c + 1 (staged during iteration c - 1, published by the barrier that ended it) go to the other set; chunk
+            // c + 2 goes from its ring slot to the LDS stage chunk c - 1 was read from; the slot is refilled with chunk c + 2 + D.
+            f32x2 (&ca)[4] = oa[j & 1];
+            f32x2 (&cw)[4] = ow[j & 1];
+            f32x2 (&na)[4] = oa[(j + 1) & 1];
+            f32x2 (&nw)[4] = ow[(j + 1) & 1];
+            const long long s0 = TRACE ? __builtin_readcyclecounter() : 0;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0].x, cw[0].x, acc, 0, 0, 0);
             store(ra[(j + 2) % D], rw[(j + 2) % D], (j + 2) % 3);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0].y, cw[0].y, acc, 0, 0, 0);
@@ -1091,14 +1098,23 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
             read_one(na[3], nw[3], 3, (j + 1) % 3);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[3].x, cw[3].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[3].y, cw[3].y, acc, 0, 0, 0);
-            // LDS-only barrier (__syncthreads() would also wait for every global load in flight)
+            const long long s1 = TRACE ? __builtin_readcyclecounter() : 0;
+            // LDS-only barrier (__syncthreads() would also wait for every global load in flight).  Waiting only for the two
+            // LDS writes (lgkmcnt(8): "the eight reads may still fly") is NOT safe: hipcc merges pairs of the reads into
+            // ds_read2st64_b64, so fewer than eight instructions follow the writes and the count would pass too early.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                ca[kg] = na[kg];
-                cw[kg] = nw[kg];
+            if (TRACE) {
+                const long long s2 = __builtin_readcyclecounter();
+                t_chain += s1 - s0;
+                t_bar += s2 - s1;
             }
         }
+    }
+    if (tracing) {
+        p.trace[0] = (unsigned long long)(__builtin_readcyclecounter() - t_all0);
+        p.trace[1] = (unsigned long long)t_chain;
+        p.trace[2] = (unsigned long long)t_bar;
+        p.trace[3] = (unsigned long long)C;
     }
     const int m0 = bm0 + 16 * wm, col = bn0 + 16 * wn + l16;
     float bias = 0.f;
@@ -1115,15 +1131,31 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
     }
 }
 
-static hipError_t launch_s16(const ConvGemmArgs& a, int epi, hipStream_t s) {
+static hipError_t launch_s16(const ConvGemmArgs& a_in, int epi, hipStream_t s) {
     constexpr int R = 6;  // chunks in flight per thread (multiple of 3)
+    ConvGemmArgs a = a_in;
+    static const bool tr_on = getenv("SG_S16_TRACE") != nullptr;  // tuning aid: cycle split of block 0 (synchronises)
+    static unsigned long long* tr_dev = nullptr;
+    if (tr_on && !tr_dev) (void)hipMalloc(reinterpret_cast<void**>(&tr_dev), 64);
+    a.trace = tr_on ? tr_dev : nullptr;
     const int ntile32 = a.N / 32;
     dim3 grid(((a.M + 31) / 32) * ntile32);
+#define SG_S16(EPI) \
+    if (tr_on) hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI, R, true>), grid, dim3(256), 0, s, a, ntile32); \
+    else hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI, R, false>), grid, dim3(256), 0, s, a, ntile32);
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI_NONE, R>), grid, dim3(256), 0, s, a, ntile32); break;
-        case EPI_BIAS_RELU: hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI_BIAS_RELU, R>), grid, dim3(256), 0, s, a, ntile32); break;
-        case EPI_RELU_MASK: hipLaunchKernelGGL((conv_gemm_s16_kernel<EPI_RELU_MASK, R>), grid, dim3(256), 0, s, a, ntile32); break;
+        case EPI_NONE: SG_S16(EPI_NONE) break;
+        case EPI_BIAS_RELU: SG_S16(EPI_BIAS_RELU) break;
+        case EPI_RELU_MASK: SG_S16(EPI_RELU_MASK) break;
         default: return hipErrorInvalidValue;
+    }
+#undef SG_S16
+    if (tr_on && tr_dev && hipStreamSynchronize(s) == hipSuccess) {
+        unsigned long long h[4];
+        if (hipMemcpy(h, tr_dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3])
+            fprintf(stderr, "s16 M=%d N=%d chunks %llu: %llu cycles in all, per chunk %.0f = chain section %.0f + wait/barrier %.0f + rest %.0f\n",
+                    a.M, a.N, h[3], h[0], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3],
+                    ((double)h[0] - h[1] - h[2]) / h[3]);
     }
     return hipGetLastError();
 }
