@@ -43,25 +43,33 @@ class FeCoDefense:
         return mix64(self.seed ^ 0x4665436F, call)
 
     # ---- forward with saved state ------------------------------------------------------------------
-    def fwd(self, feat, seed=None):
+    def fwd(self, feat, seed=None, ids=None):
         """feat (B,F,D) -> (compressed (B,k,D) [or (1,k',D) with empty clusters dropped when B == 1], saved).
-        `seed`: explicit generator key for this call of the randomised defense (tests replay the fused loop's keys)."""
+        `seed`: explicit generator key for this call of the randomised defense (tests replay the fused loop's keys).
+        `ids` (B,F) int32: cluster ids from elsewhere -- only the reference's step after the clustering runs
+        (feature_level.py:204-216; tests/golden/feco_ref.npz pins it against the reference's own code)."""
         feat = feat.to(torch.float32).contiguous()
         if not feat.is_cuda:
             raise N.NativeError("FeCo runs on the HIP device only")
         B, F, D = feat.shape
         k = int(F * self.param)  # :184
         ctx, s = _context(feat.device), N.current_stream_ptr(feat.device)
-        ids = torch.empty(B, F, device=feat.device, dtype=torch.int32)
         out = torch.empty(B, k, D, device=feat.device, dtype=torch.float32)
         counts = torch.empty(B, k, device=feat.device, dtype=torch.int32)
-        key = 0
-        if self.init == 'random':
-            key = self.call_seed(self.calls) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
-        self.calls += 1
-        # clustering + cluster means (:204-216) in one launch
-        ctx.call("sg_feco_kmeans_compress", N._ptr(feat), B, F, D, k, self.max_iter, int(self.init == 'random'), C.c_uint64(key),
-                 int(self.index_base), 1, N._ptr(ids), N._ptr(out), N._ptr(counts), s)
+        if ids is not None:
+            ids = ids.to(device=feat.device, dtype=torch.int32).contiguous()
+            if tuple(ids.shape) != (B, F):
+                raise ValueError("ids must have shape (B, F)")
+            ctx.call("sg_feco_compress", N._ptr(feat), N._ptr(ids), B, F, D, k, N._ptr(out), N._ptr(counts), s)
+        else:
+            ids = torch.empty(B, F, device=feat.device, dtype=torch.int32)
+            key = 0
+            if self.init == 'random':
+                key = self.call_seed(self.calls) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+            self.calls += 1
+            # clustering + cluster means (:204-216) in one launch
+            ctx.call("sg_feco_kmeans_compress", N._ptr(feat), B, F, D, k, self.max_iter, int(self.init == 'random'),
+                     C.c_uint64(key), int(self.index_base), 1, N._ptr(ids), N._ptr(out), N._ptr(counts), s)
         force = B > 1  # :33 force=feat.shape[0] > 1
         keep = None
         if not force and bool((counts == 0).any()):

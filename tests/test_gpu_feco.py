@@ -137,6 +137,33 @@ def test_compress_forward_backward_match_reference_step():
     assert int(counts[0, 3]) == 0 and torch.equal(out[0, 3].cpu(), feat[0, 3])  # fallback row = frame i
 
 
+def test_compress_given_ids_matches_the_reference_run():
+    """The HIP step after the clustering against tests/golden/feco_ref.npz: the reference's OWN FEATURE_COMPRESSION / kmeans
+    code (feature_level.py:21-50,168-217) on given ids -- per-cluster means, the empty-cluster fallback of a batch
+    (force), the DROP of empty clusters for a single utterance, and autograd's gradient of each.  Tolerance: the device
+    sums a cluster's members in ascending frame order, torch.mean reduces pairwise: <= 2 ulp of the largest member sum."""
+    import os
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feco_ref.npz"))
+    worst = {}
+    for tag in ("mfcc_b3", "logmel_b2", "single_drop", "single_full"):
+        feat = torch.from_numpy(z[tag + "_feat"]).to(DEV)
+        ids = torch.from_numpy(z[tag + "_ids"]).to(DEV)
+        d = FeCoDefense(float(z[tag + "_ratio"]))
+        out, saved = d.fwd(feat, ids=ids)
+        want = torch.from_numpy(z[tag + "_out"])
+        assert tuple(out.shape) == tuple(want.shape), (tag, out.shape, want.shape)  # incl. (1, k - 3, D) for the drop case
+        e_out = (out.cpu() - want).abs().max().item()
+        got = d.bwd(saved, torch.from_numpy(z[tag + "_cot"]).to(DEV))
+        e_grad = (got.cpu() - torch.from_numpy(z[tag + "_dfeat"])).abs().max().item()
+        worst[tag] = (e_out, e_grad)
+        assert e_out < 2e-6 and e_grad < 1e-6, (tag, e_out, e_grad)
+    # a fallback row is a copy of frame i, a singleton cluster a copy of its member: exact
+    out, _ = FeCoDefense(0.5).fwd(torch.from_numpy(z["mfcc_b3_feat"]).to(DEV), ids=torch.from_numpy(z["mfcc_b3_ids"]).to(DEV))
+    assert torch.equal(out[1, 3].cpu(), torch.from_numpy(z["mfcc_b3_feat"][1, 3]))
+    log("FeCo given ids vs the reference run (max abs err out, grad): %s" % worst)
+
+
 def test_single_utterance_drops_empty_clusters():
     from oracle import feco
     from speakerguard_amd.defense.feature_level import FeCoDefense
@@ -262,7 +289,8 @@ def test_pgd_against_feco_defended_model(hip_model):
 def test_audionet_feco_gradient_and_pgd_eot():
     """PGD + EOT against a FeCo-defended AudioNet (BASELINE.json configs[3], small batch): the chained gradient
     wav -> log-mel -> FeCo -> CNN vs the oracle's autograd with the device's cluster ids, then the attack itself.
-    AudioNet's oracle is unpinned, so this is agreement with this repo's restatement."""
+    The AudioNet oracle is pinned by a run of the reference's own class (tests/golden/an_ref.npz) and the
+    step after the clustering by tests/golden/feco_ref.npz; the cluster ids themselves are this repository's contract."""
     from oracle import attacks as oatk
     from oracle import feco
     from oracle.audionet import AudioNet

@@ -28,3 +28,37 @@ def test_compress_from_ids_branches():
     assert dropped.shape == (2, 4) and torch.equal(dropped[1], forced[2])
     y = feco.feco(torch.randn(2, 40, 5), param=0.5)
     assert y.shape == (2, 20, 5)
+
+
+FECO_CASES = ("mfcc_b3", "logmel_b2", "single_drop", "single_full")
+
+
+def _feco_ref():
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feco_ref.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+def test_compress_from_ids_reproduces_the_reference_run():
+    """tests/golden/feco_ref.npz = the reference's own FEATURE_COMPRESSION / kmeans code (feature_level.py:21-50,168-217)
+    run on given ids (its third-party k-means replaced by a placeholder that returns them): outputs incl. the
+    empty-cluster fallback (batch) and drop (single utterance) branches, and autograd's gradient.  The restatement must
+    reproduce them exactly -- same torch ops in the same order."""
+    z, meta = _feco_ref()
+    assert "placeholder" in meta["accommodation"] and len(meta["kmeans_calls"]) == 7
+    for tag in FECO_CASES:
+        feat = torch.from_numpy(z[tag + "_feat"]).clone().requires_grad_(True)
+        ids, k = z[tag + "_ids"], int(z[tag + "_k"])
+        B = feat.shape[0]
+        assert k == int(feat.shape[1] * float(z[tag + "_ratio"]))  # :186
+        y = torch.cat([feco.compress_from_ids(feat[b], ids[b], k, force=B > 1).unsqueeze(0) for b in range(B)], dim=0)
+        want = torch.from_numpy(z[tag + "_out"])
+        assert y.shape == want.shape, (tag, y.shape, want.shape)
+        assert torch.equal(y.detach(), want), tag
+        (y * torch.from_numpy(z[tag + "_cot"])).sum().backward()
+        assert torch.equal(feat.grad, torch.from_numpy(z[tag + "_dfeat"])), tag
+    # the branches the fixture was built to reach
+    assert z["single_drop_out"].shape[1] == int(z["single_drop_k"]) - 3
+    ids = z["mfcc_b3_ids"]
+    assert not (ids[1] == 3).any() and np.array_equal(z["mfcc_b3_out"][1, 3], z["mfcc_b3_feat"][1, 3])  # fallback = frame i
