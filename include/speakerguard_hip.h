@@ -296,6 +296,28 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
 int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters,
                      float* ms_per_launch, double* flops, int32_t* tile_rows, void* stream);
 
+/* Stage trace of the x-vector pass sequences (what rocprofv3 --kernel-trace shows, from inside the process).  The
+ * reference has no counterpart: its only timing is a time.time() per training batch (adver_train.py:185,237); this
+ * is the measurement hook SURVEY.md section 5 asks for "around the C-ABI step call".
+ * Between sg_trace_begin and sg_trace_end every launch of sg_xv_forward / sg_xv_loss_grad / sg_xv_pgd_run is bracketed
+ * by a pair of HIP events on the launch stream, up to max_records launches (further launches are not recorded).
+ * sg_trace_end waits for the last recorded event, writes tag and elapsed milliseconds of each record in launch order
+ * (at most `capacity`), the number of records to *n_out, and switches the trace off.  Tags: +l / -l = forward /
+ * data-gradient contraction of TDNN layer l (1..5), others below.  Event records cost a few microseconds between
+ * launches: trace a run of its own, not the run that is timed. */
+#define SG_STAGE_MFCC_FWD 10
+#define SG_STAGE_CMVN_FWD 11
+#define SG_STAGE_POOL_FWD 12
+#define SG_STAGE_FC1_FWD 13
+#define SG_STAGE_TAIL 14
+#define SG_STAGE_FC1_BWD 15
+#define SG_STAGE_POOL_BWD 16
+#define SG_STAGE_CMVN_BWD 17
+#define SG_STAGE_MFCC_BWD 18
+#define SG_STAGE_OVERLAP_ADD 19
+int sg_trace_begin(sg_ctx* ctx, int32_t max_records);
+int sg_trace_end(sg_ctx* ctx, int32_t* tags_out, float* ms_out, int32_t capacity, int32_t* n_out);
+
 /* ---- the convolution primitive on caller buffers ------------------------------------------------
  * Dilated 1-D convolution / its data gradient on channel-last rows, the contraction behind
  * torch.nn.functional.conv1d in model/_xv_plda/xvecTDNN.py:16-33,49-53 and behind autograd's conv
@@ -308,6 +330,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
  * (mask shaped like C).  kernel: 0 = what the TDNN layers get (stream-K with 16-wave 256x128 quad-fed blocks when
  * the shape qualifies, one 16x16 block per wave on the 16x16x4 MFMA when there are at most 2800 such blocks, else one
  * quad-fed 64x128 block per tile), 1 = one b32-fed 64x128 block per tile, 2 = stream-K with the b32-fed 8-wave kernel,
+ * (6 / 7 / 8 = stream-K on the deep pipeline with 128- / 64- / 32-row tiles, an error when the shape does not qualify),
  * 3 = stream-K with 8-wave 128x128 quad-fed blocks, 4 = one quad-fed 64x128 block per tile, 5 = one 16x16 block per
  * wave.  All choices give bit-identical results: the float32 fmaf chain restated in oracle/conv_chain.c. */
 int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c_dev, const float* bias_dev,

@@ -654,6 +654,175 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
     if (c < c_end) chunk(c, std::integral_constant<int, 0>{});
 }
 
+// ------------------------------------------------------------------------------------------
+// Quad-fed segment for the ONE-BLOCK-PER-CU stream-K kinds (8 ... 32 utterances per GPU: the shards of a batch of 64
+// cut over 8 / 4 / 2 GPUs), where a SIMD holds one wave (two at 32) and nothing hides that wave's own issue gaps.
+// What round 3 measured on the two-stage kernels above at these sizes (rocprofv3 per-layer times, SG_ABLATE sweeps,
+// tools/native/mfma_chain_chip.hip):
+//   * a dependent chain of v_mfma_f32_32x32x2_f32 runs at 64-67 cycles per instruction on all 1024 SIMDs at once, one
+//     wave each (150 TFLOP/s) -- but ONLY when the MFMAs follow each other directly.  Any other instruction between two
+//     MFMAs of a chain costs ~43 cycles for the first and ~6 for each further one (MI355X_MICROARCH.md, "one EXTRA issue
+//     slot between two MFMAs on the SAME accumulator": a cliff, not a slope).  The loops above put operand reads in front
+//     of every group of four (or eight) MFMAs and the staging into the middle of the chunk: five gaps per chunk, 110
+//     cycles per MFMA at 8 utterances -- with global loads, LDS stores and the barrier ablated as well: the issue
+//     pattern alone, not memory, set the pace (L2 hit rate 88 %, 68 MB of fabric traffic per tdnn3 launch);
+//   * the LDS stores of chunk c+1 waited for loads issued one chunk earlier (0.43 us of compute at 32 rows against
+//     ~0.7 us of round trip).
+// Here a chunk is ONE burst of everything that is not an MFMA -- barrier, the 16-byte operand reads of the WHOLE next
+// chunk into a second register set, the LDS stores of chunk c+2 from a two-deep register ring, the buffer loads of chunk
+// c+4 -- followed by its 16 (MI = 1) or 32 (MI = 2) MFMAs back to back.  Operands leave LDS a whole chunk early, so two
+// LDS stages suffice; a load has two chunk times to land.  Staging is uniform (no roles): every thread copies LA
+// float4 of the A chunk and LW float4 of the W chunk.  Same LDS images, same operand values, same k order as
+// gemm_segment_q / gemm_segment_q1: bit-identical results.  WM waves along M x 4 along N; a wave computes (32 MI) x 32.
+// Loads past the segment's last chunk carry out-of-range offsets (the bounds check returns zeros without touching
+// memory), so the loop body has no conditional loads (a load behind a branch makes hipcc drain vmcnt at the join).
+template <int WM, int MI>
+__device__ __forceinline__ void gemm_segment_deep(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+                                                  int c_end, f32x16 (&acc)[MI][1]) {
+    constexpr int BM = 32 * MI * WM, BN = 128, NT = 256 * WM;
+    constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;  // floats; stage s = [A | W] at s * STAGE
+    constexpr int LA = BM * 8 / NT, LW = 1024 / NT, APASS = NT / 8;                 // float4 per thread and chunk; A rows per pass
+    static_assert(LA >= 1 && LW >= 1 && APASS % 16 == 0, "staging map");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr unsigned kOob = 0x80000000u;
+    const int kchunks = p.Kc / BK;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
+    // ---- staging map
+    const int c4 = tid & 7, r0 = tid >> 3;
+    unsigned a_row[LA], a_voff[LA], w_voff[LW];
+    int a_t[LA];
+    {
+        int b = (m0 + r0) / p.Tc;
+        int t = (m0 + r0) - b * p.Tc;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int r = m0 + r0 + APASS * i;
+            a_row[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
+            a_t[i] = r < p.M ? t : -(1 << 28);
+            t += APASS;
+            while (t >= p.Tc) {
+                t -= p.Tc;
+                ++b;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LW; ++i) {
+            const int f = tid + i * NT;  // float4 index in the [8 k4-groups][128 columns] chunk image
+            w_voff[i] = (unsigned)(((f >> 7) * p.ldw + n0 + (f & 127)) * 16);
+        }
+    }
+    float* st_a = smem + r0 * 32 + ((c4 ^ ((r0 >> 1) & 7)) << 2);  // + i * APASS * 32: rows 16 apart keep the swizzle
+    float* st_w = smem + A_STAGE + tid * 4;                          // + i * NT * 4
+    int ld_j = c_begin / kchunks;
+    int ld_kc = (c_begin - ld_j * kchunks) * BK;
+    int ld_left = c_end - c_begin;
+    auto set_tap = [&](int j) __attribute__((always_inline)) {
+        const int off = p.tap_base + j * p.tap_step;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const bool okv = (unsigned)(a_t[i] + off) < (unsigned)p.Ta;
+            a_voff[i] = okv ? a_row[i] + (unsigned)(off * p.lda * 4) : kOob;
+        }
+    };
+    set_tap(ld_j);
+    i32x4 ra[2][LA], rw[2][LW];  // ring: slot = chunk % 2 (indices are compile-time everywhere below)
+    auto issue = [&](i32x4 (&a)[LA], i32x4 (&w)[LW]) __attribute__((always_inline)) {
+        const int soff_a = ld_kc * 4, soff_w = (ld_j * p.Kc + ld_kc) * p.ldw * 4;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], soff_a, 0);
+#pragma unroll
+        for (int i = 0; i < LW; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], soff_w, 0);
+        ld_kc += BK;
+        --ld_left;
+        if (ld_left <= 0) {  // the segment's chunks are all requested: further loads return zeros
+#pragma unroll
+            for (int i = 0; i < LA; ++i) a_voff[i] = kOob;
+#pragma unroll
+            for (int i = 0; i < LW; ++i) w_voff[i] = kOob;
+            ld_kc = 0;
+        } else if (ld_kc == p.Kc) {
+            ld_kc = 0;
+            ++ld_j;
+            set_tap(ld_j);
+        }
+    };
+    auto store = [&](const i32x4 (&a)[LA], const i32x4 (&w)[LW], int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<i32x4*>(st_a + stage_off + i * APASS * 32) = a[i];
+#pragma unroll
+        for (int i = 0; i < LW; ++i) *reinterpret_cast<i32x4*>(st_w + stage_off + i * NT * 4) = w[i];
+    };
+    // per-lane operand addresses: A row, slot of k-group kg XOR-swizzled; W column
+    const int sw = (l31 >> 1) & 7;
+    const float* a_base = smem + (wm * 32 * MI + l31) * 32;
+    const float* a_kg[4] = {a_base + (((0 * 2 + lhi) ^ sw) << 2), a_base + (((1 * 2 + lhi) ^ sw) << 2),
+                            a_base + (((2 * 2 + lhi) ^ sw) << 2), a_base + (((3 * 2 + lhi) ^ sw) << 2)};
+    const float* b_base = smem + A_STAGE + (lhi * BN + wn * 32 + l31) * 4;
+    float4 oa[2][MI][4], ob[2][4];  // operand sets: [set][row fragment][k-group]
+    auto read_set = [&](float4 (&a)[MI][4], float4 (&b)[4], int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi][kg] = *reinterpret_cast<const float4*>(a_kg[kg] + stage_off + mi * 32 * 32);
+            b[kg] = *reinterpret_cast<const float4*>(b_base + stage_off + kg * 2 * BN * 4);
+        }
+    };
+    // prologue: four chunks requested; chunks 0 and 1 staged; operands of chunk 0 in registers
+    issue(ra[0], rw[0]);
+    issue(ra[1], rw[1]);
+    store(ra[0], rw[0], 0);
+    issue(ra[0], rw[0]);
+    store(ra[1], rw[1], STAGE);
+    issue(ra[1], rw[1]);
+    __syncthreads();
+    read_set(oa[0], ob[0], 0);
+    // always_inline: left to the inliner's size threshold the 64-row variants became real calls, and everything the
+    // closure refers to (the accumulators, the kernel arguments, the ring) then lived in scratch memory: 5x slower
+    auto chunk = [&](auto ptag) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;  // parity of the chunk: its operand set, LDS stage and ring slot
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the burst.  The barrier publishes stage 1 - P (chunk c + 1, written in the previous burst) and tells that
+        // every wave has the operands of chunk c (stage P, read in the previous burst) in registers.
+        // (No SG_ABLATE switches in here: a conditional barrier or load makes hipcc put s_waitcnt between the MFMAs.)
+        __syncthreads();
+        read_set(oa[1 - P], ob[1 - P], (1 - P) * STAGE);
+        store(ra[P], rw[P], P * STAGE);   // chunk c + 2
+        issue(ra[P], rw[P]);              // chunk c + 4
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the MFMAs of chunk c, back to back.  k order: step s of k-group kg takes k = 8 kg + 4 (lane / 32) + s.
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const float4 b = ob[P][kg];
+            const float4 x0 = oa[P][0][kg], x1 = oa[P][MI - 1][kg];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, b.x, acc[0][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, b.x, acc[MI - 1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, b.y, acc[0][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, b.y, acc[MI - 1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, b.z, acc[0][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, b.z, acc[MI - 1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, b.w, acc[0][0], 0, 0, 0);
+            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, b.w, acc[MI - 1][0], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // Whole pairs in a loop with ONE back edge and no exits inside the body, the odd last chunk after it: with `break`s
+    // between the chunks the structurizer leaves never-taken edges from inside the body back to the loop header, and the
+    // waitcnt insertion then merges "the ring slot was refilled one chunk ago" into the LDS stores (s_waitcnt vmcnt(0)).
+    const int n = c_end - c_begin;
+    const int pairs = n >> 1;
+    for (int q = 0; q < pairs; ++q) {
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+    }
+    if (n & 1) chunk(std::integral_constant<int, 0>{});
+    __syncthreads();  // the next segment's prologue overwrites both stages
+}
+
 // Walk the accumulator fragments of a tile.  C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5).  fn(mi, ni, row0, col) handles one 16-value fragment.
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -798,13 +967,21 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
 // KIND 0: 8 waves, b32-fed 128x128 (no packed weights); 1: 8 waves, quad-fed 128x128; 2: 16 waves, quad-fed 256x128;
 // 3: 4 waves, quad-fed 64x128 (small batches: one block per CU); 4: 4 waves, quad-fed 32x128 (batch 8).
+// 5 / 6 / 7: the shapes of 1 / 3 / 4 on gemm_segment_deep (one burst of staging per chunk, then its MFMAs back to back;
+// two chunks of loads in flight) -- what the one-block-per-CU launches of 8 ... 32 utterances per GPU use (round 3).
+constexpr bool sk_deep(int kind) { return kind >= 5; }
+constexpr int sk_wm(int kind) { return kind == 2 ? 4 : (kind == 3 || kind == 4 || kind == 6 || kind == 7) ? 1 : 2; }
+constexpr int sk_bm(int kind) { return (kind == 4 || kind == 7) ? 32 : 64 * sk_wm(kind); }
+constexpr int sk_threads(int kind) { return 256 * sk_wm(kind); }
+constexpr int sk_min_waves(int kind) { return sk_wm(kind) == 1 ? 1 : kind == 5 ? 2 : 4; }  // per SIMD: sets the VGPR budget
+constexpr size_t sk_lds_bytes(int kind) { return (size_t)2 * BK * (sk_bm(kind) + 128) * sizeof(float); }
 template <int EPI, int KIND>
-__global__ __launch_bounds__(KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, KIND >= 3 ? 1 : 4) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
+__global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                                       int iters_per_worker, float* slabs,
                                                                                       unsigned* flags, unsigned epoch) {
-    constexpr int WM = KIND == 2 ? 4 : KIND >= 3 ? 1 : 2, WN = 4;
-    constexpr int BM = KIND == 4 ? 32 : 64 * WM, BN = 128;
-    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 fragments per wave
+    constexpr int WM = sk_wm(KIND), WN = 4;
+    constexpr int BM = sk_bm(KIND), BN = 128;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 (or 1x1) fragments per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BK * (BM + BN) floats
     const int C = p.total_chunks;
     const long total = (long)tiles * C;
@@ -824,8 +1001,9 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, KIND >= 3
     if (it_begin >= it_end) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     f32x16 acc[MI][NI];
-    auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) {
+    auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) __attribute__((always_inline)) {
         if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (sk_deep(KIND)) gemm_segment_deep<WM, MI>(p, smem, m0, n0, c0, c1, acc);
         else if constexpr (KIND == 3) gemm_segment_q1<2>(p, smem, m0, n0, c0, c1, acc);
         else if constexpr (KIND == 4) gemm_segment_q1<1>(p, smem, m0, n0, c0, c1, acc);
         else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc, tr);
@@ -883,6 +1061,9 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, KIND >= 3
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), slab_rsrc, piece_off(w, mi, ni, q), 0, 16);
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores ...
+        // A/B knob (SG_ABLATE bit 16): additionally the classic agent-scope release fence (writes back the XCD's dirty L2
+        // lines); the default relies on the sc1 write-through semantics alone, see DESIGN.md section 4
+        if (p.ablate & 16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();                                   // ... before ONE lane publishes the flag
         if (threadIdx.x == 0) {
             // (ablate bit 8 = fault injection for tests/test_gpu_conv.py: the flag is never published)
@@ -920,6 +1101,7 @@ __global__ __launch_bounds__(KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, KIND >= 3
                 }
             }
         }
+        if (p.ablate & 16) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
         SG_STAMP(9)
         // the slab was stored write-through (sc1) before the flag; sc1 loads bypass this CU's L1, so no acquire fence
@@ -1194,9 +1376,8 @@ static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
 template <int EPI, int KIND>
 static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, int tiles, int ipw, float* slabs,
                                 unsigned* flags, unsigned epoch, hipStream_t s) {
-    constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : KIND == 4 ? 32 : 128;
-    constexpr int threads = KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512;
-    constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
+    constexpr int threads = sk_threads(KIND);
+    constexpr size_t lds = sk_lds_bytes(KIND);
     // per device: remember for which devices the > 64 KB dynamic-LDS opt-in has been made (a process may hold one
     // sg_ctx per GPU)
     static std::atomic<unsigned long long> done_mask{0};
@@ -1217,13 +1398,12 @@ static void launch_streamk_kind(const ConvGemmArgs& a, int workers, int ntiles, 
 template <int KIND>
 static int streamk_blocks_per_cu() {
     static const int n = [] {
-        constexpr int bm = KIND == 2 ? 256 : KIND == 3 ? 64 : KIND == 4 ? 32 : 128;
-        constexpr size_t lds = (size_t)2 * BK * (bm + 128) * sizeof(float);
+        constexpr size_t lds = sk_lds_bytes(KIND);
         const void* fn = reinterpret_cast<const void*>(conv_gemm_streamk_kernel<EPI_NONE, KIND>);
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_streamk_kernel<EPI_NONE, KIND>,
-                                                         KIND == 2 ? 1024 : KIND >= 3 ? 256 : 512, lds) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_streamk_kernel<EPI_NONE, KIND>, sk_threads(KIND), lds) !=
+            hipSuccess)
             nb = 0;
         return nb;
     }();
@@ -1248,21 +1428,31 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 1;
     }();
     if (mid && kind == 2 && a.force == 0 && ((a.M + 255) / 256) * (a.N / 128) < cus) {
+        // deep = 1 (default): the three-stage / three-chunk pipeline of gemm_segment_deep (kinds 5 / 6 / 7); 0: kinds 1 / 3 / 4
+        static const int deep = [] {
+            const char* e = getenv("SG_STREAMK_DEEP");
+            return e ? atoi(e) : 1;
+        }();
         if (((a.M + 127) / 128) * (a.N / 128) >= cus) {
-            kind = 1;
+            kind = deep ? 5 : 1;
             bm = 128;
             workers = cus;
         } else if (((a.M + 63) / 64) * (a.N / 128) >= cus) {
             // small batches (B = 16): 4-wave 64x128 blocks, one per CU -- balances the 272 tiles a one-block-per-tile
             // launch would spread as 240 x 1 + 16 x 2
-            kind = 3;
+            kind = deep ? 6 : 3;
             bm = 64;
             workers = cus;
         } else if (((a.M + 31) / 32) * (a.N / 128) >= cus) {
-            kind = 4;  // batch 8: 32-row tiles, half the k chain per tile, balanced over the CUs
+            kind = deep ? 7 : 4;  // batch 8: 32-row tiles, half the k chain per tile, balanced over the CUs
             bm = 32;
             workers = cus;
         }
+    }
+    if (a.force >= 6 && a.force <= 8 && a.Wq) {  // parity tests: the deep kinds on any shape that qualifies
+        kind = a.force - 1;
+        bm = kind == 5 ? 128 : kind == 6 ? 64 : 32;
+        workers = cus;
     }
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
     const int tiles = mtiles * ntiles;
@@ -1278,7 +1468,9 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
     // every worker has to be resident at once; if the runtime would admit fewer blocks than that, use the tile launch
     const int per_cu = kind == 2 ? streamk_blocks_per_cu<2>() : kind == 1 ? streamk_blocks_per_cu<1>()
-                     : kind == 3 ? streamk_blocks_per_cu<3>() : kind == 4 ? streamk_blocks_per_cu<4>() : streamk_blocks_per_cu<0>();
+                     : kind == 3 ? streamk_blocks_per_cu<3>() : kind == 4 ? streamk_blocks_per_cu<4>()
+                     : kind == 5 ? streamk_blocks_per_cu<5>() : kind == 6 ? streamk_blocks_per_cu<6>()
+                     : kind == 7 ? streamk_blocks_per_cu<7>() : streamk_blocks_per_cu<0>();
     if ((long)per_cu * cus < workers) return hipErrorNotSupported;
     if ((size_t)workers * bm * 128 > (size_t)512 * 128 * 128) return hipErrorNotSupported;  // slab capacity (sg_api.hip)
     static std::atomic<unsigned> launch_counter{0};
@@ -1292,7 +1484,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     dim3 grid(workers);
 #define a at
 #define SG_SK(EPI)                                                                                          \
-    if (kind == 4) launch_streamk_kind<EPI, 4>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    if (kind == 7) launch_streamk_kind<EPI, 7>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    else if (kind == 6) launch_streamk_kind<EPI, 6>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
+    else if (kind == 5) launch_streamk_kind<EPI, 5>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
+    else if (kind == 4) launch_streamk_kind<EPI, 4>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 3) launch_streamk_kind<EPI, 3>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 2) launch_streamk_kind<EPI, 2>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 1) launch_streamk_kind<EPI, 1>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
@@ -1386,6 +1581,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
             if (splits == 1 && use_streamk && a.force != 1 && a.force != 4) {
                 const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
                 if (e != hipErrorNotSupported) return e;
+                if (a.force >= 6) return hipErrorInvalidValue;  // a forced deep kind never silently becomes a tile launch
             }
             if (a.Wq && splits == 1 && a.force != 1) return launch_tile_q(a, epi, s);
             return launch_tile<64, 128, 2, 2>(a, epi, splits, s);

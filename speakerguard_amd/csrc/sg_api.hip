@@ -29,6 +29,26 @@ int fail(sg_ctx* ctx, int code, const char* fmt, ...) {
                                           hipGetErrorString(e_), __FILE__, __LINE__);                  \
     } while (0)
 
+// stage trace: event pair around one launch (no-op unless sg_trace_begin switched it on and records are left)
+inline void trace_mark(sg_ctx* ctx, int tag, hipStream_t s, int after) {
+    if (!ctx->trace_on) return;
+    if (!after) {
+        if (ctx->trace_used >= (int)ctx->trace_tag.size()) return;
+        ctx->trace_tag[ctx->trace_used] = tag;
+        (void)hipEventRecord(ctx->trace_ev[2 * ctx->trace_used], s);
+    } else {
+        if (ctx->trace_used >= (int)ctx->trace_tag.size() || ctx->trace_tag[ctx->trace_used] != tag) return;
+        (void)hipEventRecord(ctx->trace_ev[2 * ctx->trace_used + 1], s);
+        ++ctx->trace_used;
+    }
+}
+#define SG_STAGE(tag, expr)          \
+    do {                             \
+        trace_mark(ctx, (tag), s, 0); \
+        SG_HIP(expr);                \
+        trace_mark(ctx, (tag), s, 1); \
+    } while (0)
+
 template <typename T>
 int dev_alloc(sg_ctx* ctx, std::vector<void*>& pool, T** out, size_t count) {
     void* p = nullptr;
@@ -245,8 +265,8 @@ int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const
         tab.spec_cache = w.spec_cache;  // the backward of this pass starts from the stored spectrum
         tab.mel_cache = w.mel_cache;
         tab.rep_utts = d.Bu;
-        SG_HIP(launch_mfcc_fwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
-        SG_HIP(launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
+        SG_STAGE(SG_STAGE_MFCC_FWD, launch_mfcc_fwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
+        SG_STAGE(SG_STAGE_CMVN_FWD, launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else if (flag == SG_FLAG_RAW) {
         SG_HIP(launch_cmvn_fwd(x, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else {
@@ -288,9 +308,9 @@ int run_tdnn_forward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
     Workspace& w = ctx->ws;
     for (int l = 0; l < kLayers; ++l) {
         ConvGemmArgs a = fwd_layer_args(ctx, l, d.B, d.F);
-        SG_HIP(launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));
+        SG_STAGE(l + 1, launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));
     }
-    SG_HIP(launch_pool_fwd(w.act[4], d.B, w.Fl[4], w.stats, s));
+    SG_STAGE(SG_STAGE_POOL_FWD, launch_pool_fwd(w.act[4], d.B, w.Fl[4], w.stats, s));
     // fc1 as a split-K contraction: (B x 3072) x (3072 x 512) -> kFc1SplitK partial slabs
     ConvGemmArgs a{};
     a.A = w.stats; a.W = ctx->xv.fc1_w; a.C = w.fc1_part; a.bias = nullptr; a.mask = nullptr;
@@ -298,7 +318,7 @@ int run_tdnn_forward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
     a.taps = 1; a.tap_step = 0; a.total_chunks = kStats / 32;
     a.chunks_per_split = a.total_chunks / kFc1SplitK;
     a.split_stride = (long long)d.B * kEmb;
-    SG_HIP(launch_conv_gemm(a, 2, EPI_NONE, kFc1SplitK, s));
+    SG_STAGE(SG_STAGE_FC1_FWD, launch_conv_gemm(a, 2, EPI_NONE, kFc1SplitK, s));
     return SG_OK;
 }
 
@@ -312,9 +332,9 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.taps = 1; a.tap_step = 0; a.total_chunks = kEmb / 32;
         a.chunks_per_split = a.total_chunks / kFc1BwdSplitK;
         a.split_stride = (long long)d.B * kStats;
-        SG_HIP(launch_conv_gemm(a, 2, EPI_NONE, kFc1BwdSplitK, s));
+        SG_STAGE(SG_STAGE_FC1_BWD, launch_conv_gemm(a, 2, EPI_NONE, kFc1BwdSplitK, s));
     }
-    SG_HIP(launch_pool_bwd(w.act[4], w.stats, w.dstats_part, kFc1BwdSplitK, d.B, w.Fl[4], w.dact[4], s));
+    SG_STAGE(SG_STAGE_POOL_BWD, launch_pool_bwd(w.act[4], w.stats, w.dstats_part, kFc1BwdSplitK, d.B, w.Fl[4], w.dact[4], s));
     for (int l = kLayers - 1; l >= 0; --l) {
         ConvGemmArgs a{};
         a.A = w.dact[l];
@@ -346,7 +366,7 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
             a.chunks_per_split = a.total_chunks / kL1BwdSplitK;
             a.split_stride = (long long)d.B * d.F * kFeatPad;
         }
-        SG_HIP(launch_conv_gemm(a, l == 0 ? 1 : 0, l == 0 ? EPI_NONE : EPI_RELU_MASK, splits, s));
+        SG_STAGE(-(l + 1), launch_conv_gemm(a, l == 0 ? 1 : 0, l == 0 ? EPI_NONE : EPI_RELU_MASK, splits, s));
     }
     return SG_OK;
 }
@@ -404,8 +424,8 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
         SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep, d.B,
                                d.F, s));
     } else {
-        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, w.dfeats_raw, kCep,
-                               d.B, d.F, s));
+        SG_STAGE(SG_STAGE_CMVN_BWD, launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad,
+                                                    w.dfeats_raw, kCep, d.B, d.F, s));
         MfccTables tab = ctx->tab;
         static const bool use_cache = [] {
             const char* e = getenv("SG_MFCC_CACHE");  // 0 = recompute the forward in the backward kernel
@@ -417,9 +437,9 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
         }
         tab.rep_utts = d.Bu;
         const int utts = d.Bu > 0 ? d.Bu : d.B;
-        SG_HIP(launch_mfcc_bwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
-        SG_HIP(launch_frames_to_wave(w.dframes, utts, d.T, d.F, d.B / utts, grad_acc_in, grad_out, x_update, lower, upper, step,
-                                     grad_sign, s));
+        SG_STAGE(SG_STAGE_MFCC_BWD, launch_mfcc_bwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.dfeats_raw, w.dframes, s));
+        SG_STAGE(SG_STAGE_OVERLAP_ADD, launch_frames_to_wave(w.dframes, utts, d.T, d.F, d.B / utts, grad_acc_in, grad_out, x_update,
+                                                             lower, upper, step, grad_sign, s));
     }
     return SG_OK;
 }
@@ -468,6 +488,7 @@ void sg_destroy(sg_ctx* ctx) {
     if (ctx->err_host) (void)hipHostFree(ctx->err_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->trace_ev) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -695,7 +716,7 @@ int sg_xv_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, in
     TailArgs t{};
     t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = nullptr; t.want_grad = 0;
     t.tdnn_emb = tdnn_emb_dev; t.emb = emb_dev; t.scores = scores_dev; t.decisions = decisions_dev;
-    SG_HIP(launch_tail(t, s));
+    SG_STAGE(SG_STAGE_TAIL, launch_tail(t, s));
     return SG_OK;
 }
 
@@ -729,7 +750,7 @@ int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = B; t.m = &ctx->xv; t.y = y_dev; t.loss = *loss;
     t.want_grad = grad_dev != nullptr;
     t.scores = scores_dev; t.decisions = decisions_dev; t.loss_out = loss_dev; t.demb = w.demb;
-    SG_HIP(launch_tail(t, s));
+    SG_STAGE(SG_STAGE_TAIL, launch_tail(t, s));
     if (grad_dev) {
         rc = run_backward_to_input(ctx, x_dev, d, flag, dither, grad_dev, nullptr, nullptr, nullptr, 0.f, 0, s);
         if (rc) return rc;
@@ -863,7 +884,7 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
             const bool rec = g0 == 0, direct = Gi == 1;
             t.loss_trace = loss_trace_dev && rec ? (direct ? loss_trace_dev + (size_t)it * B : w.loss) : nullptr;
             t.decision_trace = decision_trace_dev && rec ? (direct ? decision_trace_dev + (size_t)it * B : w.decisions) : nullptr;
-            SG_HIP(launch_tail(t, s));
+            SG_STAGE(SG_STAGE_TAIL, launch_tail(t, s));
             if (rec && !direct) {
                 if (loss_trace_dev)
                     SG_HIP(hipMemcpyAsync(loss_trace_dev + (size_t)it * B, w.loss, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -883,13 +904,44 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     return SG_OK;
 }
 
+int sg_trace_begin(sg_ctx* ctx, int32_t max_records) {
+    if (!ctx) return SG_ERR_ARG;
+    if (max_records < 1 || max_records > (1 << 20)) return fail(ctx, SG_ERR_ARG, "max_records must be 1 .. 2^20");
+    SG_HIP(hipSetDevice(ctx->device));
+    while ((int)ctx->trace_ev.size() < 2 * max_records) {
+        hipEvent_t e = nullptr;
+        SG_HIP(hipEventCreate(&e));
+        ctx->trace_ev.push_back(e);
+    }
+    ctx->trace_tag.assign((size_t)max_records, 0);
+    ctx->trace_used = 0;
+    ctx->trace_on = true;
+    return SG_OK;
+}
+
+int sg_trace_end(sg_ctx* ctx, int32_t* tags_out, float* ms_out, int32_t capacity, int32_t* n_out) {
+    if (!ctx || !n_out) return SG_ERR_ARG;
+    if (!ctx->trace_on) return fail(ctx, SG_ERR_STATE, "sg_trace_end without sg_trace_begin");
+    ctx->trace_on = false;
+    const int n = ctx->trace_used;
+    *n_out = n;
+    if (n > 0) SG_HIP(hipEventSynchronize(ctx->trace_ev[2 * (n - 1) + 1]));
+    for (int i = 0; i < n && i < capacity; ++i) {
+        float ms = 0.f;
+        SG_HIP(hipEventElapsedTime(&ms, ctx->trace_ev[2 * i], ctx->trace_ev[2 * i + 1]));
+        if (tags_out) tags_out[i] = ctx->trace_tag[i];
+        if (ms_out) ms_out[i] = ms;
+    }
+    return SG_OK;
+}
+
 int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c_dev, const float* bias_dev,
                    const float* mask_dev, int32_t B, int32_t Ta, int32_t Tc, int32_t Kc, int32_t N, int32_t taps,
                    int32_t tap_step, int32_t tap_base, int32_t epi, int32_t kernel, void* stream) {
     if (!ctx) return SG_ERR_ARG;
     if (!a_dev || !w_dev || !c_dev || B <= 0 || Ta <= 0 || Tc <= 0 || taps <= 0 || Kc <= 0 || Kc % 32 || N <= 0 || N % 128)
         return fail(ctx, SG_ERR_ARG, "sg_conv1d_rows: need Kc %% 32 == 0 and N %% 128 == 0 (got Kc=%d N=%d)", Kc, N);
-    if (epi < 0 || epi > 2 || (epi == 1 && !bias_dev) || (epi == 2 && !mask_dev) || kernel < 0 || kernel > 5)
+    if (epi < 0 || epi > 2 || (epi == 1 && !bias_dev) || (epi == 2 && !mask_dev) || kernel < 0 || kernel > 8)
         return fail(ctx, SG_ERR_ARG, "sg_conv1d_rows: bad epi/kernel");
     if (build_tables(ctx) != SG_OK) return SG_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;

@@ -204,6 +204,12 @@ struct sg_ctx {
     sg::AnWorkspace an_ws;
     std::vector<void*> model_allocs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Stage trace (sg_trace_begin / sg_trace_end): while on, every launch of the x-vector pass sequences is bracketed by a
+    // pair of HIP events on the launch stream; a record = (stage tag, event before, event after).
+    bool trace_on = false;
+    int trace_used = 0;
+    std::vector<hipEvent_t> trace_ev;  // 2 per record
+    std::vector<int> trace_tag;
 };
 
 namespace sg {
@@ -231,9 +237,11 @@ struct ConvGemmArgs {
     int num_cus;        // stream-K: persistent blocks = resident slots of THIS device (0: assume 256)
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
     int force;          // 0 auto, 1 one b32-fed block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave,
-                        // 4 one quad-fed block per tile, 5 one 16 x 16 block per wave (parity tests)
+                        // 4 one quad-fed block per tile, 5 one 16 x 16 block per wave, 6 / 7 / 8 stream-K on the deep pipeline
+                        // with 128- / 64- / 32-row tiles (parity tests)
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier;
-                        // 8 = fault injection: stream-K hand-off flags are never published (health-word test)
+                        // 8 = fault injection: stream-K hand-off flags are never published (health-word test);
+                        // 16 = A/B: agent-scope release / acquire fences around the stream-K hand-off (results stay right)
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags
     unsigned* err_word; // stream-K: device-visible health word (bit 0 = a hand-off wait timed out), may be null

@@ -76,11 +76,51 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     assert np.array_equal(outs[4], outs[1]), "quad-fed tile launch differs from the b32-fed tile launch"
     # v_mfma_f32_16x16x4_f32 fed the k values in the order the 32x32x2 kernels consume them: the same fmaf chain
     assert np.array_equal(outs[5], outs[1]), "16 x 16 blocks (small-batch kernel) differ from the tile launch"
+    # round 3: the deep pipeline (three LDS stages, three chunks of loads in flight) of the one-block-per-CU stream-K
+    # launches, forced on every shape that qualifies for it (enough tiles for 256 workers, a range >= one tile's chunks)
+    chunks = taps * (Kc // 32)
+    for k, rows in ((6, 128), (7, 64), (8, 32)):
+        tiles = -(-(B * Tc) // rows) * (n // 128)
+        if chunks >= 16 and tiles >= 256 and -(-tiles * chunks // 256) >= chunks:
+            o = _run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k)
+            assert np.array_equal(o, outs[1]), "deep stream-K with %d-row tiles differs from the tile launch" % rows
     # and all of them ARE the documented arithmetic: one float32 fmaf chain per output in the kernels' k order, restated
     # in C on the CPU (oracle/conv_chain.c) -- bit for bit, signs of zeros included
     from oracle.conv_chain import conv_chain
     chain = conv_chain(a, w, B, Ta, Tc, taps, step, base)
     assert np.array_equal(outs[1].view(np.uint32), chain.view(np.uint32)), "device result is not the restated fmaf chain"
+
+
+@pytest.mark.parametrize("B", [8, 16, 32, 64])
+@pytest.mark.parametrize("direction", ["fwd", "dgrad"])
+def test_real_tdnn3_shape_is_the_restated_fmaf_chain(ctx, B, direction):
+    """The contraction of the real tdnn3 layer (xvecTDNN.py:24-26: 512 -> 512 channels, 7 taps, dilation 3: K = 3584, 112
+    chunks) at the per-GPU shard sizes of a batch of 64 over 8 / 4 / 2 / 1 GPUs, through the launcher's own choice of
+    kernel (deep stream-K with 32- / 64- / 128-row tiles, 16-wave stream-K at 64): bit for bit the C restatement
+    oracle/conv_chain.c, forward and data gradient (hardware-zero-filled taps at the utterance edges)."""
+    from oracle.conv_chain import conv_chain
+    Kc, n, taps = 512, 512, 7
+    Ta, Tc, step = (288, 270, 3) if direction == "fwd" else (270, 288, -3)
+    base = 0  # dgrad: output row t (an input frame) collects the d(out) rows t - 3 j that exist, as run_tdnn_backward does
+    a, w = _case(100 + B, B, Ta, Tc, Kc, n, taps)
+    got = _run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, 0)
+    chain = conv_chain(a, w, B, Ta, Tc, taps, step, base)
+    assert np.array_equal(got.view(np.uint32), chain.view(np.uint32))
+
+
+def test_streamk_slabs_reused_back_to_back(ctx):
+    """the stream-K hand-off parks accumulators in slabs that every launch of a context reuses, published by
+    write-through (sc1) stores and a relaxed flag -- a stale line would not raise the health word.  Many launches in a
+    row on the same context, a different input every time and the kinds interleaved (16-wave, 8-wave, deep 128 / 64 /
+    32 rows: all park into the same slab addresses): every result must equal the one-block-per-tile launch."""
+    B, Ta, Tc, Kc, n, taps, step = 64, 270, 266, 192, 512, 3, 2
+    rng = np.random.RandomState(17)
+    w = (rng.standard_normal((taps * Kc, n)) / 24).astype(np.float32)
+    for it in range(12):
+        a = rng.standard_normal((B * Ta, Kc)).astype(np.float32)
+        ref = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, 0, 4)
+        for k in (0, 3, 6, 7, 8, 0):
+            assert np.array_equal(_run(ctx, a, w, B, Ta, Tc, taps, step, 0, 0, k), ref), (it, k)
 
 
 def test_conv_rows_epilogues(ctx):
