@@ -655,172 +655,218 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
 }
 
 // ------------------------------------------------------------------------------------------
-// Quad-fed segment for the ONE-BLOCK-PER-CU stream-K kinds (8 ... 32 utterances per GPU: the shards of a batch of 64
-// cut over 8 / 4 / 2 GPUs), where a SIMD holds one wave (two at 32) and nothing hides that wave's own issue gaps.
-// What round 3 measured on the two-stage kernels above at these sizes (rocprofv3 per-layer times, SG_ABLATE sweeps,
-// tools/native/mfma_chain_chip.hip):
+// Wave-specialised quad-fed segment for the ONE-BLOCK-PER-CU stream-K kinds (8 ... 32 utterances per GPU: the shards of
+// a batch of 64 cut over 8 / 4 / 2 GPUs), where a SIMD holds one computing wave (two at 32) and nothing hides that
+// wave's own issue gaps.  What round 3 measured on the two-stage kernels above at these sizes (rocprofv3 per-layer times,
+// PMC passes, tools/native/mfma_chain_chip.hip, tools/native/mfma_burst.hip):
+//   * memory is not the limit: L2 hit rate 88 %, 68 MB of fabric traffic per tdnn3 launch at 8 utterances, and a
+//     register ring three chunks deep changed nothing;
 //   * a dependent chain of v_mfma_f32_32x32x2_f32 runs at 64-67 cycles per instruction on all 1024 SIMDs at once, one
-//     wave each (150 TFLOP/s) -- but ONLY when the MFMAs follow each other directly.  Any other instruction between two
-//     MFMAs of a chain costs ~43 cycles for the first and ~6 for each further one (MI355X_MICROARCH.md, "one EXTRA issue
-//     slot between two MFMAs on the SAME accumulator": a cliff, not a slope).  The loops above put operand reads in front
-//     of every group of four (or eight) MFMAs and the staging into the middle of the chunk: five gaps per chunk, 110
-//     cycles per MFMA at 8 utterances -- with global loads, LDS stores and the barrier ablated as well: the issue
-//     pattern alone, not memory, set the pace (L2 hit rate 88 %, 68 MB of fabric traffic per tdnn3 launch);
-//   * the LDS stores of chunk c+1 waited for loads issued one chunk earlier (0.43 us of compute at 32 rows against
-//     ~0.7 us of round trip).
-// Here a chunk is ONE burst of everything that is not an MFMA -- barrier, the 16-byte operand reads of the WHOLE next
-// chunk into a second register set, the LDS stores of chunk c+2 from a two-deep register ring, the buffer loads of chunk
-// c+4 -- followed by its 16 (MI = 1) or 32 (MI = 2) MFMAs back to back.  Operands leave LDS a whole chunk early, so two
-// LDS stages suffice; a load has two chunk times to land.  Staging is uniform (no roles): every thread copies LA
-// float4 of the A chunk and LW float4 of the W chunk.  Same LDS images, same operand values, same k order as
-// gemm_segment_q / gemm_segment_q1: bit-identical results.  WM waves along M x 4 along N; a wave computes (32 MI) x 32.
+//     wave each (150 TFLOP/s), and 8 ds_read_b128 + one s_barrier per 16 MFMAs cost < 4 %;
+//   * but the STAGING issued by the same wave -- 5 buffer loads, the wait for them, 5 ds_write_b128 per chunk -- stretches
+//     a 1024-cycle chunk to 1550 (micro-benchmark) ... 1800 cycles (the kernel): 57 % of peak at 8 utterances, 66 % at 16.
+// So the roles are split between waves: the first 4 WM waves of a block (one or two per SIMD) only fetch operands from LDS
+// and multiply -- per chunk: one barrier, the 16-byte operand reads of the WHOLE next chunk into a second register
+// set, then 16 (MI = 1) or 32 (MI = 2) MFMAs back to back -- and four more waves (one per SIMD) only stage: per chunk
+// the LDS stores of chunk c+2 from a two-deep register ring, the buffer loads of chunk c+4, one barrier.  Three LDS
+// stages.  The micro-benchmark of this split: 1320 cycles per chunk (77 %) against 1550 (66 %) for one wave doing both.
+// Same LDS images, same operand values, same k order as gemm_segment_q / gemm_segment_q1: bit-identical results.
+// WM computing waves along M x 4 along N; a computing wave owns (32 MI) x 32 of the (32 MI WM) x 128 tile.
 // Loads past the segment's last chunk carry out-of-range offsets (the bounds check returns zeros without touching
-// memory), so the loop body has no conditional loads (a load behind a branch makes hipcc drain vmcnt at the join).
+// memory), so the staging loop has no conditional loads (a load behind a branch makes hipcc drain vmcnt at the join).
+// Every wave of the block executes the same number of barriers: one after the prologue, one per chunk.
 template <int WM, int MI>
-__device__ __forceinline__ void gemm_segment_deep(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
-                                                  int c_end, f32x16 (&acc)[MI][1]) {
-    constexpr int BM = 32 * MI * WM, BN = 128, NT = 256 * WM;
+__device__ __forceinline__ void gemm_segment_ws(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
+                                                int c_end, f32x16 (&acc)[MI][1]) {
+    constexpr int BM = 32 * MI * WM, BN = 128, NC = 256 * WM;                       // NC computing threads, then 256 staging threads
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;  // floats; stage s = [A | W] at s * STAGE
-    constexpr int LA = BM * 8 / NT, LW = 1024 / NT, APASS = NT / 8;                 // float4 per thread and chunk; A rows per pass
-    static_assert(LA >= 1 && LW >= 1 && APASS % 16 == 0, "staging map");
+    const int n = c_end - c_begin;
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) >= 4 * WM) {
+        // ============================================================ staging waves
+        constexpr int LA = BM * 8 / 256, LW = 1024 / 256, APASS = 32;  // float4 per thread and chunk; A rows per pass
+        const int tid = (int)threadIdx.x - NC;
+        constexpr unsigned kOob = 0x80000000u;
+        const int kchunks = p.Kc / BK;
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
+        const int c4 = tid & 7, r0 = tid >> 3;
+        unsigned a_row[LA], a_voff[LA], w_voff[LW];
+        int a_t[LA];
+        {
+            int b = (m0 + r0) / p.Tc;
+            int t = (m0 + r0) - b * p.Tc;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const int r = m0 + r0 + APASS * i;
+                a_row[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
+                a_t[i] = r < p.M ? t : -(1 << 28);
+                t += APASS;
+                while (t >= p.Tc) {
+                    t -= p.Tc;
+                    ++b;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < LW; ++i) {
+                const int f = tid + i * 256;  // float4 index in the [8 k4-groups][128 columns] chunk image
+                w_voff[i] = (unsigned)(((f >> 7) * p.ldw + n0 + (f & 127)) * 16);
+            }
+        }
+        float* st_a = smem + r0 * 32 + ((c4 ^ ((r0 >> 1) & 7)) << 2);  // + i * APASS * 32: rows 16 apart keep the swizzle
+        float* st_w = smem + A_STAGE + tid * 4;                          // + i * 1024
+        int ld_j = c_begin / kchunks;
+        int ld_kc = (c_begin - ld_j * kchunks) * BK;
+        int ld_left = n;
+        auto set_tap = [&](int j) __attribute__((always_inline)) {
+            const int off = p.tap_base + j * p.tap_step;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const bool okv = (unsigned)(a_t[i] + off) < (unsigned)p.Ta;
+                a_voff[i] = okv ? a_row[i] + (unsigned)(off * p.lda * 4) : kOob;
+            }
+        };
+        set_tap(ld_j);
+        // Register ring: slot = chunk % D, D chunks of loads in flight.  With two (round 3, first version) a load had two
+        // chunk times to land -- 0.85 us at 32-row tiles while all 256 CUs pull ~7 TB/s out of the L2s: the staging waves were
+        // latency-bound again (0.66 us per chunk).  The staging waves hold no accumulators or operands, so the ring is cheap.
+        constexpr int D = WM == 1 ? 6 : 2;  // 128-row tiles: a chunk is 1.7 us of compute, and three waves per SIMD leave 168 registers
+        i32x4 ra[D][LA], rw[D][LW];
+        auto issue = [&](i32x4 (&a)[LA], i32x4 (&w)[LW]) __attribute__((always_inline)) {
+            const int soff_a = ld_kc * 4, soff_w = (ld_j * p.Kc + ld_kc) * p.ldw * 4;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], soff_a, 0);
+#pragma unroll
+            for (int i = 0; i < LW; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], soff_w, 0);
+            ld_kc += BK;
+            --ld_left;
+            if (ld_left <= 0) {  // the segment's chunks are all requested: further loads return zeros
+#pragma unroll
+                for (int i = 0; i < LA; ++i) a_voff[i] = kOob;
+#pragma unroll
+                for (int i = 0; i < LW; ++i) w_voff[i] = kOob;
+                ld_kc = 0;
+            } else if (ld_kc == p.Kc) {
+                ld_kc = 0;
+                ++ld_j;
+                set_tap(ld_j);
+            }
+        };
+        auto store = [&](const i32x4 (&a)[LA], const i32x4 (&w)[LW], int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) *reinterpret_cast<i32x4*>(st_a + stage_off + i * APASS * 32) = a[i];
+#pragma unroll
+            for (int i = 0; i < LW; ++i) *reinterpret_cast<i32x4*>(st_w + stage_off + i * 1024) = w[i];
+        };
+        // prologue: D + 2 chunks requested, chunks 0 and 1 staged
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(ra[d], rw[d]);
+        store(ra[0], rw[0], 0);
+        issue(ra[0], rw[0]);
+        store(ra[1], rw[1], STAGE);
+        issue(ra[1], rw[1]);
+        __syncthreads();  // barrier 0
+        // iteration i: chunk i + 2 goes from ring slot (i + 2) % D to stage (i + 2) % 3 (last read two barriers ago), the slot
+        // is refilled with chunk i + 2 + D.  Six iterations per trip: slot and stage are compile-time; one back edge, no exits
+        // inside (never-taken structurizer edges would make the waitcnt insertion wait for the loads issued one iteration ago).
+        auto step = [&](auto jtag) __attribute__((always_inline)) {
+            constexpr int J = decltype(jtag)::value;
+            store(ra[(J + 2) % D], rw[(J + 2) % D], ((J + 2) % 3) * STAGE);
+            issue(ra[(J + 2) % D], rw[(J + 2) % D]);
+            __syncthreads();
+        };
+        const int trips = n / 6;
+        for (int q = 0; q < trips; ++q) {
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});
+            step(std::integral_constant<int, 5>{});
+        }
+        const int rest = n - 6 * trips;
+        if (rest >= 1) step(std::integral_constant<int, 0>{});
+        if (rest >= 2) step(std::integral_constant<int, 1>{});
+        if (rest >= 3) step(std::integral_constant<int, 2>{});
+        if (rest >= 4) step(std::integral_constant<int, 3>{});
+        if (rest >= 5) step(std::integral_constant<int, 4>{});
+        return;
+    }
+    // ================================================================ computing waves
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int l31 = lane & 31, lhi = lane >> 5;
-    constexpr unsigned kOob = 0x80000000u;
-    const int kchunks = p.Kc / BK;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
-    // ---- staging map
-    const int c4 = tid & 7, r0 = tid >> 3;
-    unsigned a_row[LA], a_voff[LA], w_voff[LW];
-    int a_t[LA];
-    {
-        int b = (m0 + r0) / p.Tc;
-        int t = (m0 + r0) - b * p.Tc;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int r = m0 + r0 + APASS * i;
-            a_row[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
-            a_t[i] = r < p.M ? t : -(1 << 28);
-            t += APASS;
-            while (t >= p.Tc) {
-                t -= p.Tc;
-                ++b;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < LW; ++i) {
-            const int f = tid + i * NT;  // float4 index in the [8 k4-groups][128 columns] chunk image
-            w_voff[i] = (unsigned)(((f >> 7) * p.ldw + n0 + (f & 127)) * 16);
-        }
-    }
-    float* st_a = smem + r0 * 32 + ((c4 ^ ((r0 >> 1) & 7)) << 2);  // + i * APASS * 32: rows 16 apart keep the swizzle
-    float* st_w = smem + A_STAGE + tid * 4;                          // + i * NT * 4
-    int ld_j = c_begin / kchunks;
-    int ld_kc = (c_begin - ld_j * kchunks) * BK;
-    int ld_left = c_end - c_begin;
-    auto set_tap = [&](int j) __attribute__((always_inline)) {
-        const int off = p.tap_base + j * p.tap_step;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const bool okv = (unsigned)(a_t[i] + off) < (unsigned)p.Ta;
-            a_voff[i] = okv ? a_row[i] + (unsigned)(off * p.lda * 4) : kOob;
-        }
-    };
-    set_tap(ld_j);
-    i32x4 ra[2][LA], rw[2][LW];  // ring: slot = chunk % 2 (indices are compile-time everywhere below)
-    auto issue = [&](i32x4 (&a)[LA], i32x4 (&w)[LW]) __attribute__((always_inline)) {
-        const int soff_a = ld_kc * 4, soff_w = (ld_j * p.Kc + ld_kc) * p.ldw * 4;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], soff_a, 0);
-#pragma unroll
-        for (int i = 0; i < LW; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], soff_w, 0);
-        ld_kc += BK;
-        --ld_left;
-        if (ld_left <= 0) {  // the segment's chunks are all requested: further loads return zeros
-#pragma unroll
-            for (int i = 0; i < LA; ++i) a_voff[i] = kOob;
-#pragma unroll
-            for (int i = 0; i < LW; ++i) w_voff[i] = kOob;
-            ld_kc = 0;
-        } else if (ld_kc == p.Kc) {
-            ld_kc = 0;
-            ++ld_j;
-            set_tap(ld_j);
-        }
-    };
-    auto store = [&](const i32x4 (&a)[LA], const i32x4 (&w)[LW], int stage_off) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<i32x4*>(st_a + stage_off + i * APASS * 32) = a[i];
-#pragma unroll
-        for (int i = 0; i < LW; ++i) *reinterpret_cast<i32x4*>(st_w + stage_off + i * NT * 4) = w[i];
-    };
     // per-lane operand addresses: A row, slot of k-group kg XOR-swizzled; W column
     const int sw = (l31 >> 1) & 7;
     const float* a_base = smem + (wm * 32 * MI + l31) * 32;
     const float* a_kg[4] = {a_base + (((0 * 2 + lhi) ^ sw) << 2), a_base + (((1 * 2 + lhi) ^ sw) << 2),
                             a_base + (((2 * 2 + lhi) ^ sw) << 2), a_base + (((3 * 2 + lhi) ^ sw) << 2)};
     const float* b_base = smem + A_STAGE + (lhi * BN + wn * 32 + l31) * 4;
-    float4 oa[2][MI][4], ob[2][4];  // operand sets: [set][row fragment][k-group]
-    auto read_set = [&](float4 (&a)[MI][4], float4 (&b)[4], int stage_off) __attribute__((always_inline)) {
+    // Operand sets: the 16-byte pieces of KGS k-groups -- a whole chunk for MI = 1, half a chunk for MI = 2 (a whole chunk of
+    // 64 x 32 operands in two sets is 96 registers; with three waves per SIMD at 128-row tiles the budget is 168).
+    constexpr int PARTS = MI == 2 ? 2 : 1, KGS = 4 / PARTS;
+    float4 oa[2][MI][KGS], ob[2][KGS];  // [set][row fragment][k-group of the part]
+    auto read_set = [&](float4 (&a)[MI][KGS], float4 (&b)[KGS], int stage_off, int kg0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
+        for (int g = 0; g < KGS; ++g) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi][kg] = *reinterpret_cast<const float4*>(a_kg[kg] + stage_off + mi * 32 * 32);
-            b[kg] = *reinterpret_cast<const float4*>(b_base + stage_off + kg * 2 * BN * 4);
+            for (int mi = 0; mi < MI; ++mi) a[mi][g] = *reinterpret_cast<const float4*>(a_kg[kg0 + g] + stage_off + mi * 32 * 32);
+            b[g] = *reinterpret_cast<const float4*>(b_base + stage_off + (kg0 + g) * 2 * BN * 4);
         }
     };
-    // prologue: four chunks requested; chunks 0 and 1 staged; operands of chunk 0 in registers
-    issue(ra[0], rw[0]);
-    issue(ra[1], rw[1]);
-    store(ra[0], rw[0], 0);
-    issue(ra[0], rw[0]);
-    store(ra[1], rw[1], STAGE);
-    issue(ra[1], rw[1]);
-    __syncthreads();
-    read_set(oa[0], ob[0], 0);
-    // always_inline: left to the inliner's size threshold the 64-row variants became real calls, and everything the
-    // closure refers to (the accumulators, the kernel arguments, the ring) then lived in scratch memory: 5x slower
-    auto chunk = [&](auto ptag) __attribute__((always_inline)) {
-        constexpr int P = decltype(ptag)::value;  // parity of the chunk: its operand set, LDS stage and ring slot
+    __syncthreads();  // barrier 0: chunks 0 and 1 are staged
+    read_set(oa[0], ob[0], 0, 0);
+    // iteration i, part h: the MFMAs of the part, and half way through them the operand reads of the NEXT part (of this
+    // chunk, or the first of chunk i + 1 in stage (i + 1) % 3, complete since the previous barrier) into the other register
+    // set; after the last part the barrier.  k order: step s of k-group kg takes k = 8 kg + 4 (lane / 32) + s.
+    auto chunk = [&](auto jtag) __attribute__((always_inline)) {
+        constexpr int J = decltype(jtag)::value;
+#pragma unroll
+        for (int h = 0; h < PARTS; ++h) {
+            const int cur = PARTS == 1 ? J % 2 : h % 2;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < KGS; ++g) {
+                if (g == KGS / 2) {
+                    // the reads sit in the MIDDLE of the part's MFMA chain: straight after a barrier release every
+                    // non-MFMA instruction costs ~22 cycles (MI355X_MICROARCH.md) and the staging waves issue their own
+                    // burst there; tools/native/mfma_burst.hip: 1170 cycles per chunk against 1330 with the reads first
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (h + 1 < PARTS) read_set(oa[1 - cur], ob[1 - cur], (J % 3) * STAGE, KGS * (h + 1));
+                    else read_set(oa[1 - cur], ob[1 - cur], ((J + 1) % 3) * STAGE, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float4 b = ob[cur][g];
+                const float4 x0 = oa[cur][0][g], x1 = oa[cur][MI - 1][g];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, b.x, acc[0][0], 0, 0, 0);
+                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, b.x, acc[MI - 1][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, b.y, acc[0][0], 0, 0, 0);
+                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, b.y, acc[MI - 1][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, b.z, acc[0][0], 0, 0, 0);
+                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, b.z, acc[MI - 1][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, b.w, acc[0][0], 0, 0, 0);
+                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, b.w, acc[MI - 1][0], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- the burst.  The barrier publishes stage 1 - P (chunk c + 1, written in the previous burst) and tells that
-        // every wave has the operands of chunk c (stage P, read in the previous burst) in registers.
-        // (No SG_ABLATE switches in here: a conditional barrier or load makes hipcc put s_waitcnt between the MFMAs.)
         __syncthreads();
-        read_set(oa[1 - P], ob[1 - P], (1 - P) * STAGE);
-        store(ra[P], rw[P], P * STAGE);   // chunk c + 2
-        issue(ra[P], rw[P]);              // chunk c + 4
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- the MFMAs of chunk c, back to back.  k order: step s of k-group kg takes k = 8 kg + 4 (lane / 32) + s.
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const float4 b = ob[P][kg];
-            const float4 x0 = oa[P][0][kg], x1 = oa[P][MI - 1][kg];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, b.x, acc[0][0], 0, 0, 0);
-            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, b.x, acc[MI - 1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, b.y, acc[0][0], 0, 0, 0);
-            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, b.y, acc[MI - 1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, b.z, acc[0][0], 0, 0, 0);
-            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, b.z, acc[MI - 1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, b.w, acc[0][0], 0, 0, 0);
-            if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, b.w, acc[MI - 1][0], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     };
-    // Whole pairs in a loop with ONE back edge and no exits inside the body, the odd last chunk after it: with `break`s
-    // between the chunks the structurizer leaves never-taken edges from inside the body back to the loop header, and the
-    // waitcnt insertion then merges "the ring slot was refilled one chunk ago" into the LDS stores (s_waitcnt vmcnt(0)).
-    const int n = c_end - c_begin;
-    const int pairs = n >> 1;
-    for (int q = 0; q < pairs; ++q) {
+    const int trips = n / 6;
+    for (int q = 0; q < trips; ++q) {
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        chunk(std::integral_constant<int, 4>{});
+        chunk(std::integral_constant<int, 5>{});
     }
-    if (n & 1) chunk(std::integral_constant<int, 0>{});
-    __syncthreads();  // the next segment's prologue overwrites both stages
+    const int rest = n - 6 * trips;
+    if (rest >= 1) chunk(std::integral_constant<int, 0>{});
+    if (rest >= 2) chunk(std::integral_constant<int, 1>{});
+    if (rest >= 3) chunk(std::integral_constant<int, 2>{});
+    if (rest >= 4) chunk(std::integral_constant<int, 3>{});
+    if (rest >= 5) chunk(std::integral_constant<int, 4>{});
 }
 
 // Walk the accumulator fragments of a tile.  C/D layout of the 32x32 MFMA: col = lane & 31,
@@ -967,14 +1013,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int
 // launch counter passed as a kernel argument), so nothing has to be cleared between launches.
 // KIND 0: 8 waves, b32-fed 128x128 (no packed weights); 1: 8 waves, quad-fed 128x128; 2: 16 waves, quad-fed 256x128;
 // 3: 4 waves, quad-fed 64x128 (small batches: one block per CU); 4: 4 waves, quad-fed 32x128 (batch 8).
-// 5 / 6 / 7: the shapes of 1 / 3 / 4 on gemm_segment_deep (one burst of staging per chunk, then its MFMAs back to back;
-// two chunks of loads in flight) -- what the one-block-per-CU launches of 8 ... 32 utterances per GPU use (round 3).
+// 5 / 6 / 7: the shapes of 1 / 3 / 4 with the roles split between waves (gemm_segment_ws: the tile's waves only multiply,
+// four more waves only stage; three LDS stages) -- what the one-block-per-CU launches of 8 ... 32 utterances per GPU use.
 constexpr bool sk_deep(int kind) { return kind >= 5; }
 constexpr int sk_wm(int kind) { return kind == 2 ? 4 : (kind == 3 || kind == 4 || kind == 6 || kind == 7) ? 1 : 2; }
 constexpr int sk_bm(int kind) { return (kind == 4 || kind == 7) ? 32 : 64 * sk_wm(kind); }
-constexpr int sk_threads(int kind) { return 256 * sk_wm(kind); }
-constexpr int sk_min_waves(int kind) { return sk_wm(kind) == 1 ? 1 : kind == 5 ? 2 : 4; }  // per SIMD: sets the VGPR budget
-constexpr size_t sk_lds_bytes(int kind) { return (size_t)2 * BK * (sk_bm(kind) + 128) * sizeof(float); }
+constexpr int sk_threads(int kind) { return 256 * sk_wm(kind) + (sk_deep(kind) ? 256 : 0); }  // deep: + 4 staging waves
+constexpr int sk_min_waves(int kind) { return kind == 5 ? 3 : sk_deep(kind) ? 2 : sk_wm(kind) == 1 ? 1 : 4; }  // per SIMD: sets the VGPR budget
+constexpr size_t sk_lds_bytes(int kind) { return (size_t)(sk_deep(kind) ? 3 : 2) * BK * (sk_bm(kind) + 128) * sizeof(float); }
 template <int EPI, int KIND>
 __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                                       int iters_per_worker, float* slabs,
@@ -1000,10 +1046,13 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
     const long it_end = min(total, it_begin + iters_per_worker);
     if (it_begin >= it_end) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // deep kinds: the waves past the tile's 4 WM only stage operands (gemm_segment_ws); they hold no accumulators and take
+    // part in the hand-off and the epilogue through the barriers alone
+    const bool computing = !sk_deep(KIND) || __builtin_amdgcn_readfirstlane(wid) < 4 * WM;
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) __attribute__((always_inline)) {
         if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
-        else if constexpr (sk_deep(KIND)) gemm_segment_deep<WM, MI>(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (sk_deep(KIND)) gemm_segment_ws<WM, MI>(p, smem, m0, n0, c0, c1, acc);
         else if constexpr (KIND == 3) gemm_segment_q1<2>(p, smem, m0, n0, c0, c1, acc);
         else if constexpr (KIND == 4) gemm_segment_q1<1>(p, smem, m0, n0, c0, c1, acc);
         else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc, tr);
@@ -1051,15 +1100,17 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
         acc_zero(acc);
         segment(m0, n0, 0, last_c1);
         SG_STAMP(1)
+        if (computing) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), slab_rsrc, piece_off(w, mi, ni, q), 0, 16);
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), slab_rsrc, piece_off(w, mi, ni, q), 0, 16);
+                    }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores ...
         // A/B knob (SG_ABLATE bit 16): additionally the classic agent-scope release fence (writes back the XCD's dirty L2
         // lines); the default relies on the sc1 write-through semantics alone, see DESIGN.md section 4
@@ -1080,7 +1131,7 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
         acc_zero(acc);
         segment(m0, n0, 0, C);
         SG_STAMP(3 + 2 * min(tile - whole_begin, 2))
-        tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
+        if (computing) tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
         SG_STAMP(4 + 2 * min(tile - whole_begin, 2))
     }
     // 3. the tail piece of my first tile (chunks [first_c0, C)): RESUME from the accumulators worker
@@ -1105,20 +1156,22 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
         __syncthreads();
         SG_STAMP(9)
         // the slab was stored write-through (sc1) before the flag; sc1 loads bypass this CU's L1, so no acquire fence
+        if (computing) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, piece_off(w - 1, mi, ni, q), 0, 16));
-                    acc[mi][ni][4 * q] = v.x; acc[mi][ni][4 * q + 1] = v.y; acc[mi][ni][4 * q + 2] = v.z; acc[mi][ni][4 * q + 3] = v.w;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, piece_off(w - 1, mi, ni, q), 0, 16));
+                        acc[mi][ni][4 * q] = v.x; acc[mi][ni][4 * q + 1] = v.y; acc[mi][ni][4 * q + 2] = v.z; acc[mi][ni][4 * q + 3] = v.w;
+                    }
+        }
         const int c1 = first_tile == last_tile ? last_c1 : C;  // (host guarantees == C, see launcher)
         SG_STAMP(10)
         segment(m0, n0, first_c0, c1, p.trace ? p.trace + (size_t)w * 16 : nullptr);
         SG_STAMP(11)
-        tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
+        if (computing) tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
         SG_STAMP(12)
     }
 #undef SG_STAMP

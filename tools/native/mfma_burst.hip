@@ -87,7 +87,7 @@ static void run(const char* name, K kern, float* d, float* src) {
 
 // Wave-specialised block of 8 waves: waves 0-3 (one per SIMD) only read operands and multiply, waves 4-7 (the second wave of
 // each SIMD) only stage: 5 buffer loads + 5 ds_write_b128 per thread and chunk.  One s_barrier per chunk for all.
-template <int PRIO>
+template <int PRIO, int MID>
 __global__ __launch_bounds__(512, 2) void ks(float* out, const float* src, int iters) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -129,11 +129,19 @@ __global__ __launch_bounds__(512, 2) void ks(float* out, const float* src, int i
         constexpr int P = decltype(ptag)::value;
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (!MID) {
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) { a[1 - P][kg] = *(const float4*)(ap + AOFF(kg) + (1 - P) * 1024); b[1 - P][kg] = *(const float4*)(bp + kg * 1024 + (1 - P) * 16); }
+            for (int kg = 0; kg < 4; ++kg) { a[1 - P][kg] = *(const float4*)(ap + AOFF(kg) + (1 - P) * 1024); b[1 - P][kg] = *(const float4*)(bp + kg * 1024 + (1 - P) * 16); }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
+            if (MID && kg == MID) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { a[1 - P][g] = *(const float4*)(ap + AOFF(g) + (1 - P) * 1024); b[1 - P][g] = *(const float4*)(bp + g * 1024 + (1 - P) * 16); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const float4 x = a[P][kg], y = b[P][kg];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc, 0, 0, 0);
@@ -180,7 +188,10 @@ int main() {
     run("14 barrier+writes+loads", k<14>, d, src); run("15 all", k<15>, d, src);
     run("19 reads + barrier after 8 MFMAs", k<19>, d, src); run("23 reads+writes + barrier after 8 MFMAs", k<23>, d, src);
     run("31 all, barrier after 8 MFMAs", k<31>, d, src);
-    run512("wave-specialised: 4 MFMA waves + 4 staging waves", ks<0>, d, src);
-    run512("  same, s_setprio 3 on the MFMA waves", ks<1>, d, src);
+    run512("wave-specialised: 4 MFMA waves + 4 staging waves", ks<0, 0>, d, src);
+    run512("  same, s_setprio 3 on the MFMA waves", ks<1, 0>, d, src);
+    run512("  operand reads after 4 of the 16 MFMAs", ks<0, 1>, d, src);
+    run512("  operand reads after 8 of the 16 MFMAs", ks<0, 2>, d, src);
+    run512("  operand reads after 12 of the 16 MFMAs", ks<0, 3>, d, src);
     return 0;
 }
