@@ -1,23 +1,31 @@
 """Headline benchmark: PGD attack steps/s on the x-vector/PLDA system (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--scaling weak|strong] [--batch-per-gpu B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload per GPU: PGD, L-inf eps 0.002, step 0.0004, cross-entropy, untargeted, EOT 1/1, CSI-E,
-batch 64 x 3 s @ 16 kHz synthetic utterances, synthetic seeded weights (D=200, 10 enrolled
-speakers), dither off.  One "step" = forward + hand-coded backward to d loss/d waveform + fused
-sign/project/clamp update for the whole batch of 64.  The timed region is ONE ``sg_xv_pgd_run``
-call with max_iter = K, i.e. K steps plus the attack's final forward-only evaluation pass
-(reference attack/FGSM.py:44-47) -- the pass is part of every real attack, so it is charged to
-the K steps rather than hidden.  Inputs are resident in HBM before the clock starts.
+Workload: PGD, L-inf eps 0.002, step 0.0004, cross-entropy, untargeted, EOT 1/1, CSI-E, 3 s @ 16 kHz synthetic
+utterances, synthetic seeded weights (D=200, 10 enrolled speakers), dither off.  One "step" = forward + hand-coded
+backward to d loss/d waveform + fused sign/project/clamp update for a whole batch of 64.  A timed region is ONE
+``sg_xv_pgd_run`` call with max_iter = K, i.e. exactly K steps plus the attack's final forward-only evaluation pass
+(reference attack/FGSM.py:44-47) -- the pass is part of every real attack, so it is charged to the K steps rather
+than hidden.  Inputs are resident in HBM before the clock starts.
 
-N > 1: weak scaling, every rank attacks its own batch of 64 (no data-path collective); the only
-exchange is one RCCL all-gather of the per-utterance success flags at the end of the attack,
-inside the timed region.
+Protocol: W untimed warm-up steps, then R timed attacks of exactly K steps, each bracketed by
+barrier + device synchronise on both sides and timed as the MAX over ranks; `value` is computed from the MEDIAN attack,
+all samples are in the line.
+
+N > 1, two partitions of the work, both measured in the same run:
+  * ``--scaling weak`` (default, the line's `value`): every rank attacks its own batch of 64; no data-path collective,
+    one RCCL all-gather of the per-utterance success flags at the end of the attack, inside the timed region;
+  * ``strong`` (the line's ``strong_scaling`` object; `value` with ``--scaling strong``): ONE batch of 64 cut into
+    contiguous shards of 64/N utterances (reference attack/PGD.py:62-73 chunks one batch; BASELINE.md section 3 "batch 64
+    sharded B/G per GPU"), same exchange.  On one GPU the shard sizes 32 / 16 / 8 are timed as well (``shard_points``):
+    what a rank of a 2 / 4 / 8-GPU strong-scaling run does.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,42 +36,61 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-B_PER_GPU, T_SAMPLES = 64, 48000
+GLOBAL_BATCH, T_SAMPLES = 64, 48000
 EPS, STEP = 0.002, 0.0004
-# algorithmic MACs per utterance of the TDNN contractions, forward (SURVEY.md §8d); data-gradient = same
+# algorithmic MACs per utterance of the TDNN contractions, forward (SURVEY.md section 8d); data-gradient = same
 FLOP_PER_UTT_STEP = 4.70e9
+LAYER_MACS = {1: 22732800, 2: 377487360, 3: 495452160, 4: 70778880, 5: 207360000}  # per utterance, one direction
+STREAMK_STAGES = ["tdnn%d_fwd" % l for l in (2, 3, 4, 5)] + ["tdnn%d_dgrad" % l for l in (5, 4, 3, 2)]
 
 
-def cpu_baseline(weights, budget_utts=32, steps=3, gpu_model=None):
-    """Reference-equivalent CPU path = the oracle in its structure-faithful form (per-utterance
-    MFCC/TDNN loops, Python CMVN loop, autograd with parameters requiring grad), timed on this
-    host's cores on a bounded sample of the same workload."""
+def _timed(fn):
+    t0 = time.perf_counter()
+    out = fn()
+    return out, time.perf_counter() - t0
+
+
+def cpu_baseline(weights, budget_utts=32, steps=5, gpu_model=None):
+    """Reference-equivalent CPU path = the oracle in its structure-faithful form (per-utterance MFCC/TDNN loops, Python
+    CMVN loop, autograd with parameters requiring grad), timed on this host's cores on a bounded sample of the same
+    workload: thread count picked by a quick sweep, one warm-up, median of three."""
     from oracle import attacks as oatk
     from oracle.xv_plda import XvPlda
     from speakerguard_amd import synth
-    cores = torch.get_num_threads()
-    model = XvPlda(weights, faithful=True, freeze=False)
+    avail = os.cpu_count() or 1
     x = torch.from_numpy(synth.make_waveforms(budget_utts, T_SAMPLES, seed=1234))
     y = torch.arange(budget_utts) % 10
-    atk = oatk.PGD(model, task="CSI", epsilon=EPS, step_size=STEP, max_iter=steps, batch_size=budget_utts)
-    t0 = time.perf_counter()
-    oadv, osucc = atk.attack(x, y)
-    dt = time.perf_counter() - t0
-    utt_steps = budget_utts * steps  # (+ one forward-only pass, charged like on the GPU side)
-    # second row SURVEY.md section 8(d) asks for: the same oracle vectorised (batched, closed-form CMVN, parameters
-    # frozen) -- fairer to the CPU, still not the optimisation target
+    model = XvPlda(weights, faithful=True, freeze=False)
     vmodel = XvPlda(weights, faithful=False, freeze=True)
-    vatk = oatk.PGD(vmodel, task="CSI", epsilon=EPS, step_size=STEP, max_iter=steps, batch_size=budget_utts)
-    t1 = time.perf_counter()
-    vatk.attack(x, y)
-    dtv = time.perf_counter() - t1
+    kw = dict(task="CSI", epsilon=EPS, step_size=STEP)
+
+    # thread sweep on a tiny piece of the workload (batch-1 convolutions oversubscribe easily)
+    sweep = {}
+    for nt in sorted({n for n in (8, 16, 32, 64, 128) if n <= avail} | {min(avail, 8)}):
+        torch.set_num_threads(nt)
+        atk = oatk.PGD(model, max_iter=1, batch_size=4, **kw)
+        atk.attack(x[:2], y[:2])  # touch
+        _, dt = _timed(lambda: atk.attack(x[:4], y[:4]))
+        sweep[nt] = dt
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+
+    def run(m):
+        atk = oatk.PGD(m, max_iter=steps, batch_size=budget_utts, **kw)
+        atk.attack(x, y)  # warm-up
+        outs = [_timed(lambda: atk.attack(x, y)) for _ in range(3)]
+        return outs[-1][0], [dt for _, dt in outs]
+
+    (oadv, osucc), dts = run(model)
+    _, vdts = run(vmodel)
+    dt, dtv = statistics.median(dts), statistics.median(vdts)
+    utt_steps = budget_utts * steps  # (+ one forward-only pass, charged like on the GPU side)
     parity = None
     if gpu_model is not None:
-        # the checker role of the oracle: the same PGD-%d on the same utterances through the HIP path
+        # the checker role of the oracle: the same PGD on the same utterances through the HIP path
         from speakerguard_amd.attack.PGD import PGD
         dev = gpu_model.device
-        adv, succ = PGD(gpu_model, task="CSI", epsilon=EPS, step_size=STEP, max_iter=steps, batch_size=budget_utts,
-                        verbose=0).attack(x.to(dev), y.to(dev))
+        adv, succ = PGD(gpu_model, max_iter=steps, batch_size=budget_utts, verbose=0, **kw).attack(x.to(dev), y.to(dev))
         diff = (adv.cpu() - oadv).abs()
         with torch.no_grad():
             odec = model.make_decision(oadv)[0]
@@ -73,16 +100,20 @@ def cpu_baseline(weights, budget_utts=32, steps=3, gpu_model=None):
                   "perturbation_samples_differing": float((diff > 1e-7).float().mean()),
                   "perturbation_max_abs_diff": float(diff.max())}
     return {
-        "parity_vs_oracle": parity,
-        "vectorised_value": utt_steps / dtv / B_PER_GPU,
-        "vectorised_sample": "same sample, batched oracle with frozen parameters: %.1f s" % dtv,
-        "value": utt_steps / dt / B_PER_GPU,
+        "value": utt_steps / dt / GLOBAL_BATCH,
         "unit": "steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": "oracle faithful path (per-utterance loops, autograd incl. weight grads), PGD-%d on %d of the 64 "
-                  "utterances = %d utterance-steps in %.1f s; scaled to batch-64 steps" % (steps, budget_utts, utt_steps, dt),
+        "sample": "oracle faithful path (per-utterance loops, autograd incl. weight grads), PGD-%d on %d of the 64 utterances = "
+                  "%d utterance-steps, one warm-up + median of 3 runs (%s s), %d threads picked by a sweep; scaled to batch-64 steps"
+                  % (steps, budget_utts, utt_steps, ", ".join("%.1f" % d for d in dts), cores),
         "utt_steps_per_s": utt_steps / dt,
+        "samples_s": dts,
+        "thread_sweep_s": {str(k): v for k, v in sweep.items()},
+        "host_cores": avail,
+        "vectorised_value": utt_steps / dtv / GLOBAL_BATCH,
+        "vectorised_sample": "same sample, batched oracle with frozen parameters: median of 3 runs (%s s)" % ", ".join("%.1f" % d for d in vdts),
+        "parity_vs_oracle": parity,
     }
 
 
@@ -119,12 +150,52 @@ def timed_region(attack, steps, warmup, dist, sync, dev):
     return result, dt
 
 
+def timed_reps(attack, steps, warmup, reps, dist, sync, dev):
+    """`reps` timed regions of exactly `steps` steps (the warm-up before the first only); returns (last result, [seconds])."""
+    result, samples = None, []
+    for r in range(max(1, reps)):
+        result, dt = timed_region(attack, steps, warmup if r == 0 else 0, dist, sync, dev)
+        samples.append(dt)
+    return result, samples
+
+
+def summarise(samples, steps):
+    ms = sorted(1e3 * s / steps for s in samples)
+    return {"ms_per_step": statistics.median(ms), "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1],
+            "ms_per_step_samples": [1e3 * s / steps for s in samples]}
+
+
+def stage_roofline(model, run_attack, B, steps):
+    """In-loop per-launch times from HIP-event pairs on the launch stream (sg_trace_begin / sg_trace_end) over one traced
+    attack of the timed workload: flop-weighted fraction of the f32-MFMA peak over the 8 stream-K contraction launches of
+    a step, plus the per-stage table.  The events cost a few microseconds per launch: its own run, not a timed one."""
+    recs = model.trace_stages(lambda: run_attack(steps), max_records=64 * (steps + 2))
+    by = {}
+    for name, ms in recs:
+        by.setdefault(name, []).append(ms)
+    stages = {k: {"launches": len(v), "avg_us": 1e3 * statistics.mean(v), "min_us": 1e3 * min(v)} for k, v in by.items()}
+    for k, st in stages.items():
+        if k.startswith("tdnn"):
+            st["tflops"] = 2.0 * LAYER_MACS[int(k[4])] * B / (st["avg_us"] * 1e-6) / 1e12
+    sk_time = sum(stages[k]["avg_us"] for k in STREAMK_STAGES)                       # us per step (dgrad launches: K of K+1 passes)
+    sk_flop = sum(2.0 * LAYER_MACS[int(k[4])] * B for k in STREAMK_STAGES)
+    fwd = [ms for k in STREAMK_STAGES[:4] for ms in by[k]]
+    bwd = [ms for k in STREAMK_STAGES[4:] for ms in by[k]]
+    return {"achieved": sk_flop / (sk_time * 1e-6) / 1e12, "us_per_step_in_kernel": sk_time, "flop_per_step": sk_flop,
+            "avg_us_forward_instantiation": 1e3 * statistics.mean(fwd), "avg_us_dgrad_instantiation": 1e3 * statistics.mean(bwd),
+            "stages": stages, "traced_records": len(recs)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=5, help="timed attacks of --steps steps; the line reports the median")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="utterances per GPU (default: 64 weak, 64 / N strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-points", action="store_true")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -156,69 +227,135 @@ def main():
     from speakerguard_amd import synth
     from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
     from speakerguard_amd.model.xv_plda import xv_plda
+    from speakerguard_amd.shard import shard_bounds
 
     weights = synth.make_xv_weights(seed=0, D=200, n_spk=10)
     model = xv_plda.from_weights(weights, device=dev, dither=0.0)
-    x = torch.from_numpy(synth.make_waveforms(B_PER_GPU, T_SAMPLES, seed=1234 + rank)).to(dev)
-    y = (torch.arange(B_PER_GPU) % 10).to(dev)
-    lower, upper = torch.clamp(x - EPS, min=-1), torch.clamp(x + EPS, max=1)
     spec = SEC4SR_CrossEntropy()
+    sync = torch.cuda.synchronize
 
-    def attack(k):
-        out = model.pgd_run(x, y, lower, upper, spec, STEP, k, 1)
-        return out, gather_flags(out[1], dist, world)  # inside the timed region
+    def make_attack(x_host, y_host):
+        """Resident inputs + the attack closure of one partition (flags all-gathered inside the timed region)."""
+        x = torch.from_numpy(np.ascontiguousarray(x_host)).to(dev)
+        y = torch.from_numpy(np.ascontiguousarray(y_host)).to(dev)
+        lower, upper = torch.clamp(x - EPS, min=-1), torch.clamp(x + EPS, max=1)
 
-    (out, flags), dt = timed_region(attack, args.steps, args.warmup, dist, torch.cuda.synchronize, dev)
+        def attack(k, gather=True):
+            out = model.pgd_run(x, y, lower, upper, spec, STEP, k, 1)
+            return out, (gather_flags(out[1], dist, world) if gather else out[1])
+        return attack
 
-    # roofline of the dominant kernel: TDNN layer 3 forward contraction (stream-K, 128x128 quad-fed tiles),
-    # HIP events on the launch stream inside the library
-    ms, flops, _ = model.time_layer(3, B_PER_GPU, T_SAMPLES, iters=20)
-    achieved = flops / (ms * 1e-3) / 1e12
-    # memory-side bytes of that launch come from the committed rocprofv3 --pmc passes (cannot be collected
-    # from inside this process); null if the summary is missing
-    traffic, traffic_src = None, None
-    for name in ("r02_pmc_tdnn3.json", "r01_pmc_tdnn3.json"):  # latest committed passes of this kernel
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
-            traffic_src = "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; fabric bytes incl. Infinity-Cache hits)" % name
-            break
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "conv_gemm_streamk_kernel<BIAS_RELU, KIND 2: 16 waves, 256x128 quad-fed> tdnn3 forward "
-                          "(B=64: M=17280 N=512 K=3584); 8 of the 10 contractions of a step run this kernel (86 % of the step)",
-                "ms_per_launch": ms, "flop_per_launch": flops,
-                # whole step against the same peak: algorithmic TDNN FLOPs of the job / wall time (front-end, pooling, tail and
-                # the final forward-only pass of the attack included in the time, not in the FLOPs)
-                "end_to_end_frac": world * args.steps * B_PER_GPU * FLOP_PER_UTT_STEP / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}
+    labels = np.arange(GLOBAL_BATCH) % 10
+    # weak: every rank its own 64 utterances; strong: rank r its contiguous shard of ONE batch of 64 (seed 1234)
+    weak_b = args.batch_per_gpu if (args.batch_per_gpu > 0 and args.scaling == "weak") else GLOBAL_BATCH
+    weak = make_attack(synth.make_waveforms(weak_b, T_SAMPLES, seed=1234 + rank), np.arange(weak_b) % 10)
+    lo, hi = shard_bounds(GLOBAL_BATCH, world)[rank]
+    if args.batch_per_gpu > 0 and args.scaling == "strong":
+        lo, hi = 0, args.batch_per_gpu  # one GPU standing in for a rank of a 64 / B-GPU run
+    strong_b = hi - lo
+    if strong_b < 1 or (world > 1 and GLOBAL_BATCH % world):
+        sys.exit("bench.py: the strong-scaling partition needs 64 %% N == 0 (N = %d)" % world)
+    global_x = synth.make_waveforms(GLOBAL_BATCH, T_SAMPLES, seed=1234)
+    strong = make_attack(global_x[lo:hi], labels[lo:hi])
 
-    steps_per_s = world * args.steps / dt
-    line = {
-        "metric": "PGD attack steps/sec (xv_plda, 3s@16kHz, batch 64)",
-        "value": steps_per_s,
-        "unit": "steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "PGD L-inf eps=0.002 step=0.0004 CE untargeted on xv_plda CSI-E, batch 64 x 3 s @ 16 kHz "
-                               "per GPU, EOT 1/1, dither off; timed = K steps + final forward-only pass",
-                   "batch_per_gpu": B_PER_GPU, "samples": T_SAMPLES, "global_batch": B_PER_GPU * world},
-        "utt_steps_per_s": steps_per_s * B_PER_GPU,
-        "model_tflops": steps_per_s * B_PER_GPU * FLOP_PER_UTT_STEP / 1e12 / world,
-        "success_count": int(flags.sum().item()),
-        "roofline": roofline,
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(weights, gpu_model=model)
-        line["gpu_vs_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
+    primary, primary_b = (weak, weak_b) if args.scaling == "weak" else (strong, strong_b)
+    (out, flags), samples = timed_reps(primary, args.steps, args.warmup, args.reps, dist, sync, dev)
+    prim = summarise(samples, args.steps)
+    dt = prim["ms_per_step"] * 1e-3 * args.steps
+    # a "step" of the metric is a batch-64 step: weak = N of them per time step of the job, strong = one
+    jobs_per_step = world * primary_b / GLOBAL_BATCH if args.scaling == "weak" else world * strong_b / GLOBAL_BATCH
+    steps_per_s = jobs_per_step * args.steps / dt
+
+    # ---- the other partition, same run (N > 1), or the per-rank shard sizes of 2 / 4 / 8 GPUs (N = 1)
+    other = None
+    if world > 1:
+        sec, sec_b = (strong, strong_b) if args.scaling == "weak" else (weak, weak_b)
+        (_, sflags), ssamples = timed_reps(sec, args.steps, min(args.warmup, 2), 3, dist, sync, dev)
+        s = summarise(ssamples, args.steps)
+        mult = 1.0 if args.scaling == "weak" else world * sec_b / GLOBAL_BATCH
+        other = dict(s, scaling="strong" if args.scaling == "weak" else "weak", batch_per_gpu=sec_b,
+                     value=mult * 1e3 / s["ms_per_step"], unit="steps/s", success_count=int(sflags.sum().item()),
+                     note="one batch of 64 cut into contiguous shards of 64 / N utterances (attack/PGD.py:62-73), flags all-gathered "
+                          "inside the timed region" if args.scaling == "weak" else "every rank its own batch")
+    shard_points = None
+    if world == 1 and not args.no_shard_points:
+        shard_points = []
+        for b in (32, 16, 8):
+            atk = make_attack(global_x[:b], labels[:b])
+            _, ss = timed_reps(atk, args.steps, min(args.warmup, 3), 3, None, sync, dev)
+            s = summarise(ss, args.steps)
+            shard_points.append(dict(s, batch_per_gpu=b, n_gpus_of_a_strong_run=GLOBAL_BATCH // b,
+                                     steps_per_s_of_that_run_without_exchange=1e3 / s["ms_per_step"],
+                                     utt_steps_per_s=b * 1e3 / s["ms_per_step"],
+                                     end_to_end_frac=b * FLOP_PER_UTT_STEP / (s["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS))
+
+    # ---- roofline of the dominant kernel (conv_gemm_streamk_kernel: 8 of the 10 contractions of a step), in the loop
+    roof = stage_roofline(model, lambda k: primary(k, gather=False), primary_b, args.steps) if rank == 0 else None
+    if dist is not None:
+        dist.barrier()
+    line = None
     if rank == 0:
+        ms_iso, flops_iso, _ = model.time_layer(3, primary_b, T_SAMPLES, iters=20)
+        traffic, traffic_src = None, None
+        for name in ("r03_pmc_tdnn3.json", "r02_pmc_tdnn3.json", "r01_pmc_tdnn3.json"):  # latest committed passes of this kernel
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
+                traffic_src = "profiles/%s: one tdnn3 forward launch at batch 64 (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; fabric " \
+                              "bytes incl. Infinity-Cache hits; cannot be collected from inside this process)" % name
+                break
+        roofline = {
+            "bound": "mfma", "achieved": roof["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": roof["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "conv_gemm_streamk_kernel (tdnn2-5 forward, tdnn5-2 data gradient: 8 launches per step, 98 % of a step's FLOPs)",
+            "how": "algorithmic FLOPs of the 8 launches / sum of their average in-loop durations; HIP-event pairs on the launch stream "
+                   "around every launch of one traced attack of the timed workload (sg_trace_begin / sg_trace_end); compare "
+                   "avg_us_*_instantiation with the rocprofv3 --kernel-trace --stats averages of the same command (profiles/)",
+            "us_per_step_in_kernel": roof["us_per_step_in_kernel"], "flop_per_step": roof["flop_per_step"],
+            "avg_us_forward_instantiation": roof["avg_us_forward_instantiation"],
+            "avg_us_dgrad_instantiation": roof["avg_us_dgrad_instantiation"],
+            "stages": roof["stages"],
+            "isolated_tdnn3_forward": {"ms_per_launch": ms_iso, "frac": flops_iso / (ms_iso * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       "note": "the best layer launched back to back with a warm L2 (sg_xv_time_layer): an upper bound, not `frac`"},
+            # whole step against the same peak: algorithmic TDNN FLOPs of the job / wall time (front-end, pooling, tail and the
+            # final forward-only pass of the attack included in the time, not in the FLOPs)
+            "end_to_end_frac": primary_b * FLOP_PER_UTT_STEP / (prim["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        }
+        line = {
+            "metric": "PGD attack steps/sec (xv_plda, 3s@16kHz, batch 64)",
+            "value": steps_per_s,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": prim["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "PGD L-inf eps=0.002 step=0.0004 CE untargeted on xv_plda CSI-E, %d x 3 s @ 16 kHz per GPU (%s), "
+                                   "EOT 1/1, dither off; timed = K steps + final forward-only pass; median of %d attacks"
+                                   % (primary_b, "every rank its own batch" if args.scaling == "weak" else "one batch of 64 cut over the ranks",
+                                      len(samples)),
+                       "batch_per_gpu": primary_b, "samples": T_SAMPLES,
+                       "global_batch": primary_b * world},
+            "timed_attacks": len(samples),
+            "ms_per_step_min": prim["ms_per_step_min"], "ms_per_step_max": prim["ms_per_step_max"],
+            "ms_per_step_samples": prim["ms_per_step_samples"],
+            "utt_steps_per_s": world * primary_b * args.steps / dt,
+            "model_tflops_per_gpu": primary_b * args.steps / dt * FLOP_PER_UTT_STEP / 1e12,
+            "success_count": int(flags.sum().item()),
+            "roofline": roofline,
+        }
+        if other is not None:
+            line["strong_scaling" if args.scaling == "weak" else "weak_scaling"] = other
+        if shard_points is not None:
+            line["shard_points"] = shard_points
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, gpu_model=model)
+            line["gpu_vs_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
