@@ -228,8 +228,10 @@ typedef struct sg_pgd_params {
 
 /* x_adv (B,T) dev: in = start point, out = adversarial audio; lower/upper (B,T) dev.
  * success (B) uint8, decisions (B) int64, scores (B,S), loss (B): state at the final pass (a single forward,
- * FGSM.py:45-47).  loss_trace ((max_iter+1)*B) / decision_trace ((max_iter+1)*B): optional per-step records (of the
- * step's first EOT repeat). */
+ * FGSM.py:45-47).  loss_trace ((max_iter+1)*B) / decision_trace ((max_iter+1)*B): optional per-step records, as the
+ * reference prints them (FGSM.py:50-58): the loss averaged over the step's EOT repeats, the decision voted over them
+ * (attack/utils.py:118-125, first seen wins a tie).  A loss of kind SG_LOSS_LINEAR passes ONE (B,S) coef table; the
+ * rows of the repeats of an utterance share its row. */
 int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev,
                   const float* upper_dev, int32_t B, int32_t T, const sg_pgd_params* params,
                   uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev, float* loss_dev,

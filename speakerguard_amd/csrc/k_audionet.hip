@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
                                                       float* __restrict__ emb_out, float* __restrict__ scores_out,
                                                       int64_t* __restrict__ dec_out, float* __restrict__ loss_out,
                                                       float* __restrict__ dact8, float* __restrict__ loss_trace,
-                                                      int64_t* __restrict__ dec_trace, uint8_t* __restrict__ success) {
+                                                      int64_t* __restrict__ dec_trace, uint8_t* __restrict__ success, int coef_rows) {
     __shared__ float emb[32];
     __shared__ int arg[32];
     __shared__ float sc[kLossMaxS], dsc[kLossMaxS];
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         __shared__ float bc[4];
         int64_t dec = 0;
         const float loss = loss_and_dscores_block(sc, dsc, ex, bc, S, threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, 256,
-                                                  ls.coef_dev ? ls.coef_dev + (size_t)b * S : nullptr);
+                                                  ls.coef_dev ? ls.coef_dev + (size_t)(coef_rows > 0 ? b % coef_rows : b) * S : nullptr);
         if (tid == 0) {
             if (dec_out) dec_out[b] = dec;
             if (dec_trace) dec_trace[b] = dec;
@@ -524,10 +524,10 @@ hipError_t launch_an_pool_bwd(const float* act, const float* dpool, float* dact,
 hipError_t launch_an_tail(const float* act8, int B, int T8, const float* fc_w, const float* fc_b, int S, float threshold,
                           const int64_t* y, const sg_loss_spec& ls, int want_grad, float* emb, float* scores,
                           int64_t* decisions, float* loss, float* dact8, float* loss_trace, int64_t* dec_trace,
-                          uint8_t* success, hipStream_t s) {
+                          uint8_t* success, hipStream_t s, int coef_rows) {
     if (S < 1 || S > kLossMaxS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(an_tail_kernel, dim3(B), dim3(256), 0, s, act8, T8, fc_w, fc_b, S, threshold, y, ls, want_grad, emb,
-                       scores, decisions, loss, dact8, loss_trace, dec_trace, success);
+                       scores, decisions, loss, dact8, loss_trace, dec_trace, success, coef_rows);
     return hipGetLastError();
 }
 

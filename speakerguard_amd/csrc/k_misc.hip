@@ -358,4 +358,38 @@ hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* d
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- per-step records of a step with R EOT repeats
+// rows r * B + b -> loss_out[b] = mean over r (repeat order), dec_out[b] = the most frequent decision, the first seen
+// winning a tie (attack/FGSM.py:50-58 divides the summed per-batch means; attack/utils.py:118-125 Counter.most_common)
+__global__ void eot_trace_reduce_kernel(const float* __restrict__ loss_rows, const int64_t* __restrict__ dec_rows, int R, int B,
+                                        float* __restrict__ loss_out, int64_t* __restrict__ dec_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (loss_out) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += loss_rows[(size_t)r * B + b];
+        loss_out[b] = s / (float)R;
+    }
+    if (dec_out) {
+        int64_t best = dec_rows[b];
+        int best_n = 0;
+        for (int r = 0; r < R; ++r) {
+            const int64_t d = dec_rows[(size_t)r * B + b];
+            bool seen = false;
+            for (int q = 0; q < r; ++q) seen |= dec_rows[(size_t)q * B + b] == d;
+            if (seen) continue;
+            int n = 0;
+            for (int q = r; q < R; ++q) n += dec_rows[(size_t)q * B + b] == d;
+            if (n > best_n) { best_n = n; best = d; }
+        }
+        dec_out[b] = best;
+    }
+}
+
+hipError_t launch_eot_trace_reduce(const float* loss_rows, const int64_t* dec_rows, int R, int B, float* loss_out,
+                                   int64_t* dec_out, hipStream_t s) {
+    hipLaunchKernelGGL(eot_trace_reduce_kernel, dim3((B + 127) / 128), dim3(128), 0, s, loss_rows, dec_rows, R, B, loss_out, dec_out);
+    return hipGetLastError();
+}
+
 }  // namespace sg

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
                                                    float* __restrict__ scores_out, int64_t* __restrict__ dec_out,
                                                    float* __restrict__ loss_out, float* __restrict__ demb,
                                                    float* __restrict__ loss_trace, int64_t* __restrict__ dec_trace,
-                                                   uint8_t* __restrict__ success, unsigned long long* __restrict__ trace) {
+                                                   uint8_t* __restrict__ success, unsigned long long* __restrict__ trace, int coef_rows) {
 #define TSTAMP(i) if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[i] = __builtin_amdgcn_s_memrealtime();
     TSTAMP(0)
     __shared__ float e1[kEmb];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     {
         int64_t dec = 0;  // scratch: `part` (kTailParts x kMaxD floats >= kMaxS) and `red` (16 floats), both idle here
         const float loss = loss_and_dscores_block(sc, dsc, part, red, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, NT,
-                                                  ls.coef_dev ? ls.coef_dev + (size_t)b * S : nullptr);
+                                                  ls.coef_dev ? ls.coef_dev + (size_t)(coef_rows > 0 ? b % coef_rows : b) * S : nullptr);
         if (tid == 0) {
             if (dec_out) dec_out[b] = dec;
             if (dec_trace) dec_trace[b] = dec;
@@ -279,7 +279,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     const int grid = a.B < 64 ? 64 : a.B;  // small batches: helper blocks up to one full set of 8 per XCD (see touch_matrices)
     hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(kTailThreads), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
                        a.tdnn_emb, a.emb, a.scores, a.decisions, a.loss_out, a.demb, a.loss_trace, a.decision_trace,
-                       a.success, tr_on ? tr_dev : nullptr);
+                       a.success, tr_on ? tr_dev : nullptr, a.coef_rows);
     if (tr_on && tr_dev && hipStreamSynchronize(s) == hipSuccess) {
         unsigned long long h[16];
         if (hipMemcpy(h, tr_dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -879,19 +879,18 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
             t.decisions = last ? decisions_dev : nullptr;
             t.loss_out = last ? loss_dev : nullptr;
             t.success = last ? success_dev : nullptr;
-            // per-pass records (verbose printing): those of the step's first repeat = rows 0 .. B-1 of the first group;
-            // a pass of several repeats records into the workspace and the first B rows are copied out
-            const bool rec = g0 == 0, direct = Gi == 1;
-            t.loss_trace = loss_trace_dev && rec ? (direct ? loss_trace_dev + (size_t)it * B : w.loss) : nullptr;
-            t.decision_trace = decision_trace_dev && rec ? (direct ? decision_trace_dev + (size_t)it * B : w.decisions) : nullptr;
+            // per-step records as the reference prints them (attack/FGSM.py:50-58): the loss averaged over the step's EOT
+            // repeats and the decision voted over them (attack/utils.py:118-125).  A pass of several repeats records its
+            // rows into the workspace and a small reduction writes the step's row; with more repeats than one pass holds
+            // (G < reps: activations past 2 GiB) the records cover the repeats of the step's first pass.
+            const bool rec = g0 == 0 && (loss_trace_dev || decision_trace_dev), direct = Gi == 1;
+            t.loss_trace = !rec ? nullptr : (direct && loss_trace_dev ? loss_trace_dev + (size_t)it * B : w.loss);
+            t.decision_trace = !rec ? nullptr : (direct && decision_trace_dev ? decision_trace_dev + (size_t)it * B : w.decisions);
+            t.coef_rows = B;  // SG_LOSS_LINEAR: the caller's (B, S) table serves every repeat of an utterance
             SG_STAGE(SG_STAGE_TAIL, launch_tail(t, s));
-            if (rec && !direct) {
-                if (loss_trace_dev)
-                    SG_HIP(hipMemcpyAsync(loss_trace_dev + (size_t)it * B, w.loss, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
-                if (decision_trace_dev)
-                    SG_HIP(hipMemcpyAsync(decision_trace_dev + (size_t)it * B, w.decisions, (size_t)B * sizeof(int64_t),
-                                          hipMemcpyDeviceToDevice, s));
-            }
+            if (rec && !direct)
+                SG_HIP(launch_eot_trace_reduce(w.loss, w.decisions, Gi, B, loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
+                                               decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr, s));
             if (!last) {
                 const bool final_group = g0 + Gi >= nrep;
                 rc = run_backward_to_input(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, final_group ? nullptr : w.grad,

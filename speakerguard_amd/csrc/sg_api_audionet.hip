@@ -566,17 +566,17 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
                                      w.feco_ids, w.feco_out, w.feco_cnt, s);
         if (rc) return rc;
         if ((rc = an_net_forward(ctx, w.feco_out, rows, k, s))) return rc;
-        // per-step records: those of the step's first repeat (rows 0 .. B-1)
-        const bool direct = R == 1;
-        float* ltr = !loss_trace_dev ? nullptr : (direct ? loss_trace_dev + (size_t)it * B : w.trace_l);
-        int64_t* dtr = !decision_trace_dev ? nullptr : (direct ? decision_trace_dev + (size_t)it * B : w.trace_d);
+        // per-step records as the reference prints them (attack/FGSM.py:50-58): the loss averaged over the step's EOT
+        // repeats, the decision voted over them
+        const bool direct = R == 1, rec = loss_trace_dev || decision_trace_dev;
+        float* ltr = !rec ? nullptr : (direct && loss_trace_dev ? loss_trace_dev + (size_t)it * B : w.trace_l);
+        int64_t* dtr = !rec ? nullptr : (direct && decision_trace_dev ? decision_trace_dev + (size_t)it * B : w.trace_d);
         AN_HIP(launch_an_tail(w.act[L], rows, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, w.y_rep, p->loss, !last,
                               nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
-                              w.dact[L], ltr, dtr, last ? success_dev : nullptr, s));
-        if (!direct) {
-            if (ltr) AN_HIP(hipMemcpyAsync(loss_trace_dev + (size_t)it * B, ltr, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if (dtr) AN_HIP(hipMemcpyAsync(decision_trace_dev + (size_t)it * B, dtr, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-        }
+                              w.dact[L], ltr, dtr, last ? success_dev : nullptr, s, B));
+        if (rec && !direct)
+            AN_HIP(launch_eot_trace_reduce(w.trace_l, w.trace_d, R, B, loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
+                                           decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr, s));
         if (last) break;
         if ((rc = an_net_backward(ctx, rows, k, w.dfeco, s))) return rc;
         if ((rc = sg_feco_compress_backward_reps(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, R, w.dfeats, s))) return rc;

@@ -93,7 +93,7 @@ struct AnWorkspace {
     float* feco_out = nullptr;   // (B, k, 32)
     float* dfeco = nullptr;      // (B, k, 32)
     int64_t* y_rep = nullptr;    // (B) labels repeated for the EOT repeats batched into one pass
-    float* trace_l = nullptr;    // (B) per-pass loss / decision records of such a pass (the first repeat's rows are kept)
+    float* trace_l = nullptr;    // (B * R) per-row loss / decision records of such a pass (reduced over the repeats afterwards)
     int64_t* trace_d = nullptr;
     float* mel_cache = nullptr;  // (B, F, 32) mel energies of the forward pass, kept for the backward of the same pass
     // which input the mel cache belongs to (sg_an_logmel_backward(reuse_forward) checks pointer and shape, not contents)
@@ -294,6 +294,10 @@ hipError_t launch_fakebob_step(float* x, float* grad, const float* prev_grad, co
 
 hipError_t launch_loss_eval(const float* scores, const int64_t* y, int B, int S, float threshold, const sg_loss_spec& ls,
                             int64_t* dec, float* loss, float* dscores, hipStream_t s);
+// per-step records of a step that ran R EOT repeats (rows r * B + b): loss_out[b] = mean over the repeats, dec_out[b] = the
+// majority vote with first-seen tie-break (attack/FGSM.py:50-58, attack/utils.py:118-125 Counter.most_common)
+hipError_t launch_eot_trace_reduce(const float* loss_rows, const int64_t* dec_rows, int R, int B, float* loss_out,
+                                   int64_t* dec_out, hipStream_t s);
 
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 hipStream_t s);
@@ -309,7 +313,7 @@ hipError_t launch_an_pool_bwd(const float* act, const float* dpool, float* dact,
 hipError_t launch_an_tail(const float* act8, int B, int T8, const float* fc_w, const float* fc_b, int S, float threshold,
                           const int64_t* y, const sg_loss_spec& ls, int want_grad, float* emb, float* scores,
                           int64_t* decisions, float* loss, float* dact8, float* loss_trace, int64_t* dec_trace,
-                          uint8_t* success, hipStream_t s);
+                          uint8_t* success, hipStream_t s, int coef_rows = 0);
 
 struct TailArgs {
     const float* fc1_part; int nsplit; int B;
@@ -318,6 +322,7 @@ struct TailArgs {
     float* tdnn_emb; float* emb; float* scores; int64_t* decisions; float* loss_out; float* demb;
     // optional per-pass records for the fused loop
     float* loss_trace; int64_t* decision_trace; uint8_t* success;
+    int coef_rows;  // SG_LOSS_LINEAR: rows of the caller's coef table (0: B); rows of batched EOT repeats wrap (row % coef_rows)
 };
 hipError_t launch_tail(const TailArgs& a, hipStream_t s);
 

@@ -178,6 +178,8 @@ class audionet_csine(EngineOps):
         y = y.to(self.device, torch.int64).contiguous()
         lower = lower.to(self.device, torch.float32).expand_as(x).contiguous()
         upper = upper.to(self.device, torch.float32).expand_as(x).contiguous()
+        if hasattr(loss_spec, "check"):
+            loss_spec.check(B, self.num_spks)  # ScoreVJP: one (B, S) table, shared by the EOT repeats of an utterance
         p = N.PgdParams()
         p.loss = loss_spec.native()
         p.step_size, p.max_iter, p.grad_sign = float(step_size), int(max_iter), int(grad_sign)

@@ -145,16 +145,20 @@ class defended_model:
         tape, mean = [], None
         for flag, d in branches:
             out, sv = self._fwd(d, x if flag == 0 else (feats if flag == 1 else cm))
-            sc = bm.forward(out, flag=flag)
+            # a waveform-level branch runs the (dithered) front-end inside the model: ONE noise realisation serves its
+            # scores here and its gradient below, like the single autograd graph of the reference (EOT.py:32-35)
+            key = bm.next_dither_seed() if flag == 0 and hasattr(bm, 'next_dither_seed') else None
+            sc = bm.forward(out, flag=flag, dither_seed=key) if key is not None else bm.forward(out, flag=flag)
             mean = sc if mean is None else mean + sc
-            tape.append((flag, d, out, sv))
+            tape.append((flag, d, out, sv, key))
         mean = mean / n
         decisions, loss, g = loss_dscores(bm, mean, y, loss_spec)
         vjp = ScoreVJP(g / n)
         y0 = torch.zeros(x.shape[0], device=bm.device, dtype=torch.int64)
         grad, dfeat = None, None
-        for flag, d, out, sv in tape:
-            gi = d.bwd(sv, bm.loss_grad(out, y0, vjp, flag=flag, want_grad=True)[3])
+        for flag, d, out, sv, key in tape:
+            kw = {} if key is None else {'dither_seed': key}
+            gi = d.bwd(sv, bm.loss_grad(out, y0, vjp, flag=flag, want_grad=True, **kw)[3])
             if flag == 0:
                 grad = gi if grad is None else grad + gi
             else:

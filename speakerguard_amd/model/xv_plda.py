@@ -162,6 +162,12 @@ class xv_plda(EngineOps):
             raise N.NativeError("the engine context is bound to %s" % self.device)
         return self
 
+    def next_dither_seed(self):
+        """Draws the generator key the next pass would use (and advances the draw counter like that pass would)."""
+        key = self.noise_seed(self.dither_seed, self._draw)
+        self._draw += 1
+        return key
+
     def _dither(self, noise=None, seed=None):
         d = N.Dither()
         d.dither = self.dither
@@ -266,14 +272,14 @@ class xv_plda(EngineOps):
     def cmvn(self, feats):
         return self.comput_feat_from_feat(feats)
 
-    def _forward(self, x, flag, want_emb=False, want_tdnn=False, dither_noise=None, enroll=None):
+    def _forward(self, x, flag, want_emb=False, want_tdnn=False, dither_noise=None, enroll=None, dither_seed=None):
         x, B, TF = self._prep(x, flag)
         n_spk = self.num_spks if enroll is None else enroll.shape[0]
         dec = torch.empty(B, device=self.device, dtype=torch.int64)
         scores = torch.empty(B, n_spk, device=self.device, dtype=torch.float32)
         emb = torch.empty(B, self.dim, device=self.device, dtype=torch.float32) if want_emb else None
         temb = torch.empty(B, 512, device=self.device, dtype=torch.float32) if want_tdnn else None
-        dz = self._dither(dither_noise)
+        dz = self._dither(dither_noise, dither_seed)
         if enroll is not None:
             self.ctx.call("sg_xv_enroll_override", N._ptr(enroll), enroll.shape[0])
         try:
@@ -288,9 +294,11 @@ class xv_plda(EngineOps):
     def embedding(self, x, flag=0):
         return self._forward(x, flag, want_emb=True)[2]
 
-    def forward(self, x, flag=0, return_emb=False, enroll_embs=None):
+    def forward(self, x, flag=0, return_emb=False, enroll_embs=None, dither_seed=None):
+        """`dither_seed`: explicit generator key of this pass's dither (a caller that scores an input and then asks
+        ``loss_grad`` for the gradient of the SAME noise realisation passes one key to both: defended_model 'average')."""
         enroll = self._enroll_for_call(enroll_embs)
-        _, scores, emb, _ = self._forward(x, flag, want_emb=return_emb, enroll=enroll)
+        _, scores, emb, _ = self._forward(x, flag, want_emb=return_emb, enroll=enroll, dither_seed=dither_seed)
         return (scores, emb) if return_emb else scores
 
     __call__ = forward
@@ -340,12 +348,14 @@ class xv_plda(EngineOps):
                 trace=False):
         """attack/FGSM.py:38-70 attack_batch as one device-resident loop, including EOT over the front-end's random
         dither (eot_size fresh-noise passes per gradient step, gradients summed on the device; the traces record each
-        step's first pass)."""
+        step's loss averaged and decision voted over its repeats, like the reference's verbose print)."""
         x, B, T = self._prep(x, 0)
         x_adv = x.clone()
         y = y.to(self.device, torch.int64).contiguous()
         lower = lower.to(self.device, torch.float32).expand_as(x).contiguous()
         upper = upper.to(self.device, torch.float32).expand_as(x).contiguous()
+        if hasattr(loss_spec, "check"):
+            loss_spec.check(B, self.num_spks)  # ScoreVJP: one (B, S) table, shared by the EOT repeats of an utterance
         p = N.PgdParams()
         p.loss = loss_spec.native()
         p.step_size, p.max_iter, p.grad_sign = float(step_size), int(max_iter), int(grad_sign)

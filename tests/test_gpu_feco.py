@@ -376,14 +376,18 @@ def test_audionet_feco_fused_loop(capsys):
         xr = x.clone()
         for it in range(K):
             feats, saved = hip.frontend_forward(xr)  # only the defense is random: one front-end pass per step
-            dsum = None
+            dsum, lsum, decs = None, None, []
             for r in range(R):
                 comp, sv = replay.fwd(feats, seed=hip.fused_pass_seed(base_seed, it, r))
                 dec_p, _, ls_p, g = hip.loss_grad(comp, y, spec, flag=1)
-                if r == 0:  # the per-step records are those of the step's first repeat
-                    assert torch.equal(ls_p, ltr[it]) and torch.equal(dec_p, dtr[it]), (R, it)
+                lsum = ls_p if lsum is None else lsum + ls_p
+                decs.append(dec_p.cpu().tolist())
                 df = replay.bwd(sv, g)
                 dsum = df if dsum is None else dsum + df  # feature-level sum in repeat order (the compression is linear)
+            # the per-step records are the reference's (attack/FGSM.py:50-58): loss averaged, decision voted over the repeats
+            from collections import Counter
+            assert torch.equal(lsum / R, ltr[it]), (R, it)
+            assert dtr[it].cpu().tolist() == [Counter(decs[r][b] for r in range(R)).most_common(1)[0][0] for b in range(x.shape[0])]
             gw = hip.frontend_backward(saved, dsum)
             hip.pgd_update(xr, gw.contiguous(), lower.contiguous(), upper.contiguous(), step, 1)
         comp, _ = replay.fwd(hip.compute_feat(xr, flag=1), seed=hip.fused_pass_seed(base_seed, K, 0))
@@ -504,6 +508,36 @@ def test_score_vjp_and_average_order_gradient(hip_model, oracle_model):
     assert dec.cpu().tolist() == om.argmax(1).tolist()
     assert (mean.cpu() - om.detach()).abs().max().item() < 5e-3
     assert bad < 5e-3 and err < 2e-2, (bad, err)
+
+
+def test_average_order_uses_one_dither_realisation_per_branch(xv_weights):
+    """with the reference's default dither (xv_plda.py:119 dither = 1.0) a waveform-level branch of the 'average'
+    order scored its input with one noise draw and back-propagated through ANOTHER (two native passes, two draws); the
+    reference's autograd graph holds one.  Now one key serves both: the returned mean score and the returned gradient are
+    those of the same realisation (replayed here with the key), and a branch costs one draw."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.adaptive_attack.BPDA import straight_through
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.defended_model import defended_model
+    from speakerguard_amd.model.xv_plda import xv_plda
+    m = xv_plda.from_weights(xv_weights, device=DEV, dither=1.0, dither_seed=5)
+    x = torch.from_numpy(synth.make_waveforms(3, 24000, seed=81)).to(DEV)
+    y = torch.tensor([1, 4, 7], device=DEV)
+    quant = lambda w: torch.round(w * 512.0) / 512.0
+    dm = defended_model(m, defense=[(0, straight_through(quant))], order='average')
+    ce = SEC4SR_CrossEntropy()
+    draw0 = m._draw
+    key = m.noise_seed(m.dither_seed, draw0)
+    dec, mean, loss, grad = dm.loss_grad(x, y, ce)
+    assert m._draw == draw0 + 1                                     # one draw for the branch, not two
+    xq = quant(x)
+    assert torch.equal(mean, m.forward(xq, flag=0, dither_seed=key))  # the scores of THAT realisation
+    d2, s2, l2, g2 = m.loss_grad(xq, y, ce, dither_seed=key)
+    assert torch.equal(dec, d2) and torch.allclose(loss, l2, rtol=1e-5, atol=1e-6)
+    scale = g2.abs().max().item()
+    assert (grad - g2).abs().max().item() < 2e-4 * scale            # ... and its gradient (score-VJP vs direct CE chain)
+    g_other = m.loss_grad(xq, y, ce, dither_seed=key + 1)[3]          # another realisation is measurably different
+    assert (g_other - g2).abs().max().item() > 50 * (grad - g2).abs().max().item()
 
 
 def test_randomised_feco_is_shard_invariant():

@@ -22,6 +22,12 @@ from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
+
+def _vote(decisions):
+    """attack/utils.py:118-125 resolve_prediction for one utterance: Counter.most_common(1), first seen wins a tie."""
+    from collections import Counter
+    return Counter(decisions).most_common(1)[0][0]
+
 LOG = os.path.join(ROOT, "gpurun_out", "parity_log.txt")
 
 
@@ -467,30 +473,45 @@ def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev, monkeypat
     xa, success, dec, scores, loss, _, _ = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2)
     base = m.last_fused_seed
     xb = x.clone()
-    grads = []
+    grads, step_loss, step_dec = [], [], []
     for it in range(iters):
-        acc = None
+        acc, lsum, decs = None, None, []
         for r in range(reps):
-            _, _, _, g = m.loss_grad(xb, y, spec, dither_seed=m.fused_pass_seed(base, it, r))
+            d_r, _, l_r, g = m.loss_grad(xb, y, spec, dither_seed=m.fused_pass_seed(base, it, r))
             grads.append(g)
             acc = g if acc is None else acc + g
+            lsum = l_r if lsum is None else lsum + l_r
+            decs.append(d_r.cpu().tolist())
+        step_loss.append(lsum / reps)
+        step_dec.append([_vote([decs[r][b] for r in range(reps)]) for b in range(x.shape[0])])
         m.pgd_update(xb, acc.contiguous(), lower, upper, 0.0004, 1)
     d2, s2, l2, _ = m.loss_grad(xb, y, spec, want_grad=False, dither_seed=m.fused_pass_seed(base, iters, 0))
     assert torch.equal(xa, xb)
     assert torch.equal(dec, d2) and torch.equal(scores, s2) and torch.equal(loss, l2)
     assert success.bool().tolist() == (dec != y).tolist()
     # the device loop runs the 4 repeats as one batch of 12 rows; when a pass cannot hold them all they go in groups with
-    # the sum handed on (here forced: 2 + 2 repeats, then 1 + 1 + 1 + 1) -- same bits, and the per-step records are those
-    # of the step's first repeat either way
+    # the sum handed on (here forced: 2 + 2 repeats, then 1 + 1 + 1 + 1) -- same bits.  The per-step records are what the
+    # reference prints (attack/FGSM.py:50-58): the loss averaged over the step's repeats, the decision voted over them
+    # (round 3; round 2 recorded the first repeat) -- with forced groups, over the repeats of the step's first pass.
     m._draw = 100  # same generator key for the three runs
     ref_tr = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
     for cap in (6, 3):
         monkeypatch.setenv("SG_EOT_MAX_ROWS", str(cap))
         m._draw = 100
         got = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
-        for a, b in zip(got, ref_tr):
+        for a, b in zip(got[:5], ref_tr[:5]):
             assert torch.equal(a, b), cap
+        assert torch.equal(got[5][iters], ref_tr[5][iters]) and torch.equal(got[6][iters], ref_tr[6][iters])  # the final single pass
     monkeypatch.delenv("SG_EOT_MAX_ROWS")
+    # the records of the un-grouped run against the replayed repeats (a fresh run with the first run's key)
+    m2 = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=11)
+    m2.make_decision(x)  # the one pass `m` had made before its fused run: same generator key
+    tr = m2.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
+    assert m2.last_fused_seed == base and torch.equal(tr[0], xa)
+    for it in range(iters):
+        assert torch.equal(tr[5][it], step_loss[it]), it
+        assert tr[6][it].cpu().tolist() == step_dec[it], it
+    assert torch.equal(tr[5][iters], loss) and torch.equal(tr[6][iters], dec)
     # the repeats really are different draws, and EOT changes the trajectory
     assert not torch.equal(grads[0], grads[1])
     x1 = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=1)[0]
