@@ -386,7 +386,8 @@ def test_audionet_feco_fused_loop(capsys):
                 dsum = df if dsum is None else dsum + df  # feature-level sum in repeat order (the compression is linear)
             # the per-step records are the reference's (attack/FGSM.py:50-58): loss averaged, decision voted over the repeats
             from collections import Counter
-            assert torch.equal(lsum / R, ltr[it]), (R, it)
+            # (numpy's true division: torch divides a device tensor by a host scalar as a multiplication by 1 / R)
+            assert np.array_equal(lsum.cpu().numpy() / np.float32(R), ltr[it].cpu().numpy()), (R, it)
             assert dtr[it].cpu().tolist() == [Counter(decs[r][b] for r in range(R)).most_common(1)[0][0] for b in range(x.shape[0])]
             gw = hip.frontend_backward(saved, dsum)
             hip.pgd_update(xr, gw.contiguous(), lower.contiguous(), upper.contiguous(), step, 1)

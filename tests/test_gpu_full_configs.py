@@ -1,0 +1,246 @@
+"""The BASELINE.json configurations at (or near) their full sizes, HIP path vs the oracle, with parameters chosen so that BOTH
+outcomes of the success predicate occur (round-2 review: several flag comparisons were all-False against all-False), plus
+the two drop-in gaps of the x-vector system: the file-based constructor on the GPU and PGD's random restarts on the engine.
+
+The oracle (reference-pinned CPU restatement) is the checker; these tests need tens of seconds of it
+each on the GPU box's host cores.  Which parameters leave some utterances un-fooled was found with the HIP path alone
+(tests/tools/probe_outcomes.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import log
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip_model(xv_weights):
+    from speakerguard_amd.model.xv_plda import xv_plda
+    return xv_plda.from_weights(xv_weights, device=DEV, dither=0.0)
+
+
+@pytest.fixture(scope="module")
+def oracle_model(xv_weights):
+    from oracle.xv_plda import XvPlda
+    return XvPlda(xv_weights, faithful=False, freeze=True)
+
+
+def _compare(tag, x, adv, succ, oadv, osucc, hip_dec, ora_dec, eps, steps, want_mixed=True):
+    """north_star's parity statement: success flags and predicted ids bit-exact, perturbation within the stated tolerance
+    (<= 2 % of the samples differ per sign step, by at most 2 eps: DESIGN.md section 2)."""
+    B = x.shape[0]
+    succ, osucc = [bool(s) for s in succ], [bool(s) for s in osucc]
+    diff = (adv.cpu() - oadv).abs()
+    frac = float((diff > 1e-7).float().mean())
+    with torch.no_grad():
+        hd, od = hip_dec(adv), ora_dec(oadv)
+        od_on_h, hd_on_o = ora_dec(adv.cpu()), hip_dec(oadv.to(DEV))
+    log("%s: success HIP %d/%d oracle %d/%d (equal per utterance: %s); ids on own audio equal %d/%d; samples differing %.2f %%, max |diff| %.6f"
+        % (tag, sum(succ), B, sum(osucc), B, succ == osucc, int((hd.cpu() == od).sum()), B, 100 * frac, diff.max().item()))
+    assert succ == osucc, (tag, succ, osucc)
+    if want_mixed:
+        assert 0 < sum(succ) < B, "%s: the parameters were chosen so that both outcomes occur (%d/%d)" % (tag, sum(succ), B)
+    assert hd.cpu().tolist() == od.tolist()                      # predicted ids on the adversarial audio
+    assert hd.cpu().tolist() == od_on_h.tolist() and hd_on_o.cpu().tolist() == od.tolist()  # both models agree on either audio
+    assert (adv.cpu() - x).abs().max().item() <= eps + 1e-7
+    assert diff.max().item() <= 2 * eps + 1e-6 and frac <= 0.02 * steps
+
+
+def test_config1_full_size_both_outcomes(hip_model, oracle_model):
+    """configs[1] at full size -- 64 utterances x 3 s, PGD-5, cross-entropy, untargeted, CSI-E -- with the model's own clean
+    decisions as labels and a ball small enough (eps 0.0005) that ~47 of 64 utterances are fooled and the rest are not."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    eps, step, K, B = 0.0005, 0.0001, 5, 64
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=1234))
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    assert hip_model.make_decision(x.to(DEV))[0].cpu().tolist() == y.tolist()
+    adv, succ = PGD(hip_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0).attack(x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.PGD(oracle_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B).attack(x, y)
+    _compare("configs[1] PGD-5 x 64 x 3 s, eps 0.0005", x, adv, succ, oadv, osucc,
+             lambda a: hip_model.make_decision(a)[0], lambda a: oracle_model.make_decision(a)[0], eps, K)
+
+
+def test_config1_bench_workload_targeted(hip_model, oracle_model):
+    """The bench's inputs (labels arange % 10, eps 0.002, step 0.0004) as a TARGETED PGD-5 towards label + 3: ~59 of 64
+    reach the target, the others do not."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    eps, step, K, B = 0.002, 0.0004, 5, 64
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=1234))
+    y = (torch.arange(B) % 10 + 3) % 10
+    adv, succ = PGD(hip_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, targeted=True, verbose=0).attack(
+        x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.PGD(oracle_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, targeted=True).attack(x, y)
+    _compare("configs[1] targeted PGD-5 x 64 x 3 s", x, adv, succ, oadv, osucc,
+             lambda a: hip_model.make_decision(a)[0], lambda a: oracle_model.make_decision(a)[0], eps, K)
+
+
+def test_config3_one_gpus_shard(capsys):
+    """configs[3] on one GPU's shard: PGD-10 against the FeCo-defended AudioNet (FeCo at the log-mel level, cl_r 0.5,
+    deterministic clustering), 64 utterances x 3 s, through the ONE device loop (sg_an_pgd_run_feco) vs the oracle --
+    reference-pinned AudioNet restatement + oracle.feco on ITS OWN features + torch autograd.  25 of 64 utterances are
+    fooled."""
+    from oracle import attacks as oatk
+    from oracle import feco
+    from oracle.audionet import AudioNet
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    eps, step, K, B, ratio = 0.002, 0.0004, 10, 64, 0.5
+    sd = synth.make_audionet_state_dict(seed=0, num_class=251)
+    hip, ora = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
+
+    class OracleDefended:
+        threshold = -np.inf
+
+        def make_decision(self, xx):
+            feats = ora.compute_feat(xx, flag=1)
+            k = int(feats.shape[1] * ratio)
+            comp = [feco.compress_from_ids(feats[b], feco.kmeans_ids(feats[b].detach().numpy(), k), k, force=True)
+                    for b in range(feats.shape[0])]
+            return ora.make_decision(torch.stack(comp), flag=1)
+
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=3))
+    dm, om = defended_model(hip, defense=[(1, FeCoDefense(ratio))]), OracleDefended()
+    y = dm.make_decision(x.to(DEV))[0].cpu()
+    with torch.no_grad():
+        assert om.make_decision(x)[0].tolist() == y.tolist()
+    atk = PGD(dm, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0)
+    assert atk._fused_feco(B) is not None  # the device loop, not the host-chained one
+    adv, succ = atk.attack(x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.PGD(om, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B).attack(x, y)
+
+    def odec(a):
+        with torch.no_grad():
+            return om.make_decision(a)[0]
+    _compare("configs[3] PGD-10 vs FeCo-defended AudioNet x 64 x 3 s", x, adv, succ, oadv, osucc, lambda a: dm.make_decision(a)[0], odec, eps, K)
+
+
+def test_audionet_fgsm_and_pgd_both_outcomes():
+    """configs[0] (FGSM on AudioNet CSI-NE) on 16 utterances x 3 s and PGD-5 on the same: eps 0.002 fools 5 / 7 of 16."""
+    from oracle import attacks as oatk
+    from oracle.audionet import AudioNet
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FGSM import FGSM
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    sd = synth.make_audionet_state_dict(seed=0, num_class=251)
+    hip, ora = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
+    x = torch.from_numpy(synth.make_waveforms(16, 48000, seed=3))
+    with torch.no_grad():
+        y = ora.make_decision(x)[0]
+    assert hip.make_decision(x.to(DEV))[0].cpu().tolist() == y.tolist()
+    eps = 0.002
+
+    def odec(a):
+        with torch.no_grad():
+            return ora.make_decision(a)[0]
+    adv, succ = FGSM(hip, task="CSI", epsilon=eps, batch_size=16, verbose=0).attack(x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.FGSM(ora, task="CSI", epsilon=eps, batch_size=16).attack(x.clone(), y)
+    _compare("configs[0] FGSM on AudioNet x 16 x 3 s", x, adv, succ, oadv, osucc, lambda a: hip.make_decision(a)[0], odec, eps, 1)
+    adv, succ = PGD(hip, task="CSI", epsilon=eps, step_size=eps / 5, max_iter=5, batch_size=16, verbose=0).attack(x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.PGD(ora, task="CSI", epsilon=eps, step_size=eps / 5, max_iter=5, batch_size=16).attack(x.clone(), y)
+    _compare("PGD-5 on AudioNet x 16 x 3 s", x, adv, succ, oadv, osucc, lambda a: hip.make_decision(a)[0], odec, eps, 5)
+
+
+def test_config4_fakebob_osi_targeted_s50(xv_weights):
+    """configs[4] as written: FAKEBOB / NES on the x-vector system in the OSI task, 50 samples per draw (+ the clean query),
+    targeted at each voice's nearest enrolled speaker, threshold -5: two voices are accepted as their target from the start
+    (the early-stop / delete_found branch, attack/FAKEBOB.py:85-90,125-168), one rejected voice (top score -8.3) is pushed over
+    the threshold, one (-54.7) is not within 4 iterations.  Both sides draw the NES noise from the same seeded host stream."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    from speakerguard_amd.model.xv_plda import xv_plda
+    th, eps = -5.0, 0.002
+    hm = xv_plda.from_weights(xv_weights, threshold=th, device=DEV, dither=0.0)
+    om = XvPlda(xv_weights, threshold=th, faithful=False, freeze=True)
+    x = torch.from_numpy(synth.make_waveforms(64, 48000, seed=1234))[[0, 1, 4, 5]]
+    with torch.no_grad():
+        d0, s0 = om.make_decision(x)
+    hd0, hs0 = hm.make_decision(x.to(DEV))
+    assert hd0.cpu().tolist() == d0.tolist() and sorted(d0.tolist())[0] == -1  # some voices start rejected
+    yt = s0.argmax(1)
+    kw = dict(task="OSI", targeted=True, threshold=th, epsilon=eps, max_iter=4, max_lr=0.001, min_lr=1e-6, samples_per_draw=50,
+              samples_per_draw_batch_size=50, sigma=0.001, stop_early=True, stop_early_iter=100, batch_size=4)
+    g = torch.Generator().manual_seed(5)
+    oadv, osucc = oatk.FAKEBOB(om, noise_fn=lambda shape: torch.randn(shape, generator=g), **kw).attack(x.clone(), yt)
+    g2 = torch.Generator().manual_seed(5)
+    adv, succ = FAKEBOB(hm, verbose=0, noise_fn=lambda shape: torch.randn(shape, generator=g2), **kw).attack(x.to(DEV), yt.to(DEV))
+
+    def odec(a):
+        with torch.no_grad():
+            return om.make_decision(a)[0]
+    _compare("configs[4] FAKEBOB OSI targeted S=50 x 4 x 3 s", x, adv, succ, oadv, osucc, lambda a: hm.make_decision(a)[0], odec, eps, 4)
+    # a voice that started rejected ended accepted as its target
+    hd1 = hm.make_decision(adv)[0].cpu()
+    assert any(int(a) == -1 and int(b) == int(t) for a, b, t in zip(d0, hd1, yt))
+
+
+def test_file_based_constructor_on_the_gpu(xv_weights, tmp_path):
+    """The drop-in entry point: xv_plda(extractor_file, plda_file, mean_file, transform_mat_file, model_file, ...) exactly as
+    reference model/xv_plda.py:17-47 is called, on files written in the reference's formats (state_dict checkpoint, Kaldi-text
+    PLDA, mean.vec, transform.txt, speaker_model list + per-speaker embedding files) -- equals from_weights bit for bit on the device."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.xv_plda import xv_plda
+    paths = synth.write_xv_model_dir(str(tmp_path), xv_weights)
+    from_files = xv_plda(paths["extractor_file"], paths["plda_file"], paths["mean_file"], paths["transform_mat_file"],
+                         model_file=paths.get("model_file"), device=DEV, dither=0.0)
+    direct = xv_plda.from_weights(xv_weights, device=DEV, dither=0.0)
+    assert from_files.num_spks == direct.num_spks and list(from_files.allowed_flags) == [0, 1, 2]
+    x = torch.from_numpy(synth.make_waveforms(3, 32000, seed=91)).to(DEV)
+    d1, s1 = from_files.make_decision(x)
+    d2, s2 = direct.make_decision(x)
+    assert torch.equal(d1, d2) and torch.equal(s1, s2)
+    y = torch.tensor([0, 1, 2], device=DEV)
+    g1 = from_files.loss_grad(x, y, SEC4SR_CrossEntropy())
+    g2 = direct.loss_grad(x, y, SEC4SR_CrossEntropy())
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert torch.equal(from_files.embedding(x), direct.embedding(x))
+
+
+def test_pgd_random_restarts_on_the_engine(hip_model, oracle_model):
+    """attack/PGD.py:58-61,74-77 on the HIP engine: three random restarts drawn from numpy's global generator (seeded alike on
+    both sides), the restart with the best WHOLE-BATCH success rate is returned.  eps 0.0002 leaves some utterances
+    un-fooled, so the restarts differ in their success counts."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    eps, step, K, B = 0.0002, 0.00004, 4, 8
+    x = torch.from_numpy(synth.make_waveforms(B, 32000, seed=1234))
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    np.random.seed(77)
+    adv, succ = PGD(hip_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, num_random_init=3, batch_size=B, verbose=0).attack(
+        x.to(DEV), y.to(DEV))
+    np.random.seed(77)
+    oadv, osucc = oatk.PGD(oracle_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, num_random_init=3, batch_size=B).attack(x.clone(), y)
+    # every restart, replayed one by one on the engine: the returned one is the first with the best batch success rate
+    np.random.seed(77)
+    rates = []
+    for _ in range(3):
+        noise = torch.tensor(np.random.uniform(-eps, eps, tuple(x.shape)), dtype=x.dtype)  # PGD.py:60
+        xi = (x + noise).to(DEV)
+        one = PGD(hip_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0)
+        lower, upper = torch.clamp(x - eps, min=-1).to(DEV), torch.clamp(x + eps, max=1).to(DEV)
+        one._begin_attack()
+        a_i, s_i = one._run_batches(xi, y.to(DEV), lower, upper, tag=0)
+        rates.append((sum(s_i), a_i))
+    best = max(range(3), key=lambda i: (rates[i][0], -i))
+    assert sum(succ) == rates[best][0] and torch.equal(adv, rates[best][1])
+    _compare("PGD-4 with 3 random restarts x 8 x 2 s", x, adv, succ, oadv, osucc,
+             lambda a: hip_model.make_decision(a)[0], lambda a: oracle_model.make_decision(a)[0], eps, K, want_mixed=False)
+    log("  success counts of the three restarts on the engine: %s (returned: restart %d)" % ([r[0] for r in rates], best))

@@ -482,7 +482,7 @@ def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev, monkeypat
             acc = g if acc is None else acc + g
             lsum = l_r if lsum is None else lsum + l_r
             decs.append(d_r.cpu().tolist())
-        step_loss.append(lsum / reps)
+        step_loss.append(torch.from_numpy(lsum.cpu().numpy() / np.float32(reps)).to(dev))  # true division, like the kernel
         step_dec.append([_vote([decs[r][b] for r in range(reps)]) for b in range(x.shape[0])])
         m.pgd_update(xb, acc.contiguous(), lower, upper, 0.0004, 1)
     d2, s2, l2, _ = m.loss_grad(xb, y, spec, want_grad=False, dither_seed=m.fused_pass_seed(base, iters, 0))
