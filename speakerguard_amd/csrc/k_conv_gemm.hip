@@ -674,145 +674,151 @@ __device__ __forceinline__ void gemm_segment_q1(const ConvGemmArgs& p, float* sm
 // WM computing waves along M x 4 along N; a computing wave owns (32 MI) x 32 of the (32 MI WM) x 128 tile.
 // Loads past the segment's last chunk carry out-of-range offsets (the bounds check returns zeros without touching
 // memory), so the staging loop has no conditional loads (a load behind a branch makes hipcc drain vmcnt at the join).
-// Every wave of the block executes the same number of barriers: one after the prologue, one per chunk.
-template <int WM, int MI>
-__device__ __forceinline__ void gemm_segment_ws(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin,
-                                                int c_end, f32x16 (&acc)[MI][1]) {
-    constexpr int BM = 32 * MI * WM, BN = 128, NC = 256 * WM;                       // NC computing threads, then 256 staging threads
+// Every wave of the block executes the same number of barriers: one after the prologue, one per chunk.  The two sides are
+// separate functions (ws_stage_segment / ws_compute_segment) and the kernel branches on the role ONCE, at its top: with
+// the branch inside one segment function the staging waves kept the (dead) accumulators alive through their loop -- 64
+// registers at 64 x 64 wave tiles -- and the 168-register budget of three waves per SIMD spilled.
+// The staging waves' side of a segment (threads NC .. NC + 255 of the block).
+template <int WM, int WNC, int MI, int NI>
+__device__ __forceinline__ void ws_stage_segment(const ConvGemmArgs& p, float* smem, int m0, int n0, int c_begin, int c_end) {
+    static_assert(WNC * NI == 4, "a tile is 128 columns wide");
+    constexpr int BM = 32 * MI * WM, BN = 128, NC = 64 * WM * WNC;
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;  // floats; stage s = [A | W] at s * STAGE
     const int n = c_end - c_begin;
-    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) >= 4 * WM) {
-        // ============================================================ staging waves
-        constexpr int LA = BM * 8 / 256, LW = 1024 / 256, APASS = 32;  // float4 per thread and chunk; A rows per pass
-        const int tid = (int)threadIdx.x - NC;
-        constexpr unsigned kOob = 0x80000000u;
-        const int kchunks = p.Kc / BK;
-        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
-        const int c4 = tid & 7, r0 = tid >> 3;
-        unsigned a_row[LA], a_voff[LA], w_voff[LW];
-        int a_t[LA];
-        {
-            int b = (m0 + r0) / p.Tc;
-            int t = (m0 + r0) - b * p.Tc;
+    // ============================================================ staging waves
+    constexpr int LA = BM * 8 / 256, LW = 1024 / 256, APASS = 32;  // float4 per thread and chunk; A rows per pass
+    const int tid = (int)threadIdx.x - NC;
+    constexpr unsigned kOob = 0x80000000u;
+    const int kchunks = p.Kc / BK;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wq), 0, p.w_bytes, 0x00020000);
+    const int c4 = tid & 7, r0 = tid >> 3;
+    // per-thread rows m0 + r0 + 32 i: only their per-tap byte offsets are kept (a_voff); (utterance, frame) of the first row
+    // are, the others are re-derived when the chunk stream moves to the next tap (every Kc / 32 chunks) -- eight rows per
+    // thread at 256-row tiles, and the staging waves share the 168 registers of three waves per SIMD
+    unsigned a_voff[LA], w_voff[LW];
+    const int row0 = m0 + r0;
+    const int b0 = row0 / p.Tc, t0 = row0 - b0 * p.Tc;
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                const int r = m0 + r0 + APASS * i;
-                a_row[i] = ((unsigned)(b * p.Ta + t) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u;
-                a_t[i] = r < p.M ? t : -(1 << 28);
-                t += APASS;
-                while (t >= p.Tc) {
-                    t -= p.Tc;
-                    ++b;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < LW; ++i) {
-                const int f = tid + i * 256;  // float4 index in the [8 k4-groups][128 columns] chunk image
-                w_voff[i] = (unsigned)(((f >> 7) * p.ldw + n0 + (f & 127)) * 16);
-            }
-        }
-        float* st_a = smem + r0 * 32 + ((c4 ^ ((r0 >> 1) & 7)) << 2);  // + i * APASS * 32: rows 16 apart keep the swizzle
-        float* st_w = smem + A_STAGE + tid * 4;                          // + i * 1024
-        int ld_j = c_begin / kchunks;
-        int ld_kc = (c_begin - ld_j * kchunks) * BK;
-        int ld_left = n;
-        auto set_tap = [&](int j) __attribute__((always_inline)) {
-            const int off = p.tap_base + j * p.tap_step;
-#pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                const bool okv = (unsigned)(a_t[i] + off) < (unsigned)p.Ta;
-                a_voff[i] = okv ? a_row[i] + (unsigned)(off * p.lda * 4) : kOob;
-            }
-        };
-        set_tap(ld_j);
-        // Register ring: slot = chunk % D, D chunks of loads in flight.  With two (round 3, first version) a load had two
-        // chunk times to land -- 0.85 us at 32-row tiles while all 256 CUs pull ~7 TB/s out of the L2s: the staging waves were
-        // latency-bound again (0.66 us per chunk).  The staging waves hold no accumulators or operands, so the ring is cheap.
-        constexpr int D = WM == 1 ? 6 : 2;  // 128-row tiles: a chunk is 1.7 us of compute, and three waves per SIMD leave 168 registers
-        i32x4 ra[D][LA], rw[D][LW];
-        auto issue = [&](i32x4 (&a)[LA], i32x4 (&w)[LW]) __attribute__((always_inline)) {
-            const int soff_a = ld_kc * 4, soff_w = (ld_j * p.Kc + ld_kc) * p.ldw * 4;
-#pragma unroll
-            for (int i = 0; i < LA; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], soff_a, 0);
-#pragma unroll
-            for (int i = 0; i < LW; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], soff_w, 0);
-            ld_kc += BK;
-            --ld_left;
-            if (ld_left <= 0) {  // the segment's chunks are all requested: further loads return zeros
-#pragma unroll
-                for (int i = 0; i < LA; ++i) a_voff[i] = kOob;
-#pragma unroll
-                for (int i = 0; i < LW; ++i) w_voff[i] = kOob;
-                ld_kc = 0;
-            } else if (ld_kc == p.Kc) {
-                ld_kc = 0;
-                ++ld_j;
-                set_tap(ld_j);
-            }
-        };
-        auto store = [&](const i32x4 (&a)[LA], const i32x4 (&w)[LW], int stage_off) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < LA; ++i) *reinterpret_cast<i32x4*>(st_a + stage_off + i * APASS * 32) = a[i];
-#pragma unroll
-            for (int i = 0; i < LW; ++i) *reinterpret_cast<i32x4*>(st_w + stage_off + i * 1024) = w[i];
-        };
-        // prologue: D + 2 chunks requested, chunks 0 and 1 staged
-#pragma unroll
-        for (int d = 0; d < D; ++d) issue(ra[d], rw[d]);
-        store(ra[0], rw[0], 0);
-        issue(ra[0], rw[0]);
-        store(ra[1], rw[1], STAGE);
-        issue(ra[1], rw[1]);
-        __syncthreads();  // barrier 0
-        // iteration i: chunk i + 2 goes from ring slot (i + 2) % D to stage (i + 2) % 3 (last read two barriers ago), the slot
-        // is refilled with chunk i + 2 + D.  Six iterations per trip: slot and stage are compile-time; one back edge, no exits
-        // inside (never-taken structurizer edges would make the waitcnt insertion wait for the loads issued one iteration ago).
-        auto step = [&](auto jtag) __attribute__((always_inline)) {
-            constexpr int J = decltype(jtag)::value;
-            store(ra[(J + 2) % D], rw[(J + 2) % D], ((J + 2) % 3) * STAGE);
-            issue(ra[(J + 2) % D], rw[(J + 2) % D]);
-            __syncthreads();
-        };
-        const int trips = n / 6;
-        for (int q = 0; q < trips; ++q) {
-            step(std::integral_constant<int, 0>{});
-            step(std::integral_constant<int, 1>{});
-            step(std::integral_constant<int, 2>{});
-            step(std::integral_constant<int, 3>{});
-            step(std::integral_constant<int, 4>{});
-            step(std::integral_constant<int, 5>{});
-        }
-        const int rest = n - 6 * trips;
-        if (rest >= 1) step(std::integral_constant<int, 0>{});
-        if (rest >= 2) step(std::integral_constant<int, 1>{});
-        if (rest >= 3) step(std::integral_constant<int, 2>{});
-        if (rest >= 4) step(std::integral_constant<int, 3>{});
-        if (rest >= 5) step(std::integral_constant<int, 4>{});
-        return;
+    for (int i = 0; i < LW; ++i) {
+        const int f = tid + i * 256;  // float4 index in the [8 k4-groups][128 columns] chunk image
+        w_voff[i] = (unsigned)(((f >> 7) * p.ldw + n0 + (f & 127)) * 16);
     }
+    float* st_a = smem + r0 * 32 + ((c4 ^ ((r0 >> 1) & 7)) << 2);  // + i * APASS * 32: rows 16 apart keep the swizzle
+    float* st_w = smem + A_STAGE + tid * 4;                          // + i * 1024
+    int ld_j = c_begin / kchunks;
+    int ld_kc = (c_begin - ld_j * kchunks) * BK;
+    int ld_left = n;
+    auto set_tap = [&](int j) __attribute__((always_inline)) {
+        const int off = p.tap_base + j * p.tap_step;
+        int b = b0, t = t0;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const bool okv = row0 + APASS * i < p.M && (unsigned)(t + off) < (unsigned)p.Ta;
+            a_voff[i] = okv ? ((unsigned)(b * p.Ta + t + off) * (unsigned)p.lda + (unsigned)(c4 * 4)) * 4u : kOob;
+            t += APASS;
+            while (t >= p.Tc) {
+                t -= p.Tc;
+                ++b;
+            }
+        }
+    };
+    set_tap(ld_j);
+    // Register ring: slot = chunk % D, D chunks of loads in flight.  With two (round 3, first version) a load had two
+    // chunk times to land -- 0.85 us at 32-row tiles while all 256 CUs pull ~7 TB/s out of the L2s: the staging waves were
+    // latency-bound again (0.66 us per chunk).  The staging waves hold no accumulators or operands, so the ring is cheap.
+    constexpr int D = WM == 1 ? 6 : 2;  // taller tiles: a chunk is >= 1.7 us of compute, and three waves per SIMD leave 168 registers
+    i32x4 ra[D][LA], rw[D][LW];
+    auto issue = [&](i32x4 (&a)[LA], i32x4 (&w)[LW]) __attribute__((always_inline)) {
+        const int soff_a = ld_kc * 4, soff_w = (ld_j * p.Kc + ld_kc) * p.ldw * 4;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], soff_a, 0);
+#pragma unroll
+        for (int i = 0; i < LW; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], soff_w, 0);
+        ld_kc += BK;
+        --ld_left;
+        if (ld_left <= 0) {  // the segment's chunks are all requested: further loads return zeros
+#pragma unroll
+            for (int i = 0; i < LA; ++i) a_voff[i] = kOob;
+#pragma unroll
+            for (int i = 0; i < LW; ++i) w_voff[i] = kOob;
+            ld_kc = 0;
+        } else if (ld_kc == p.Kc) {
+            ld_kc = 0;
+            ++ld_j;
+            set_tap(ld_j);
+        }
+    };
+    auto store = [&](const i32x4 (&a)[LA], const i32x4 (&w)[LW], int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<i32x4*>(st_a + stage_off + i * APASS * 32) = a[i];
+#pragma unroll
+        for (int i = 0; i < LW; ++i) *reinterpret_cast<i32x4*>(st_w + stage_off + i * 1024) = w[i];
+    };
+    // prologue: D + 2 chunks requested, chunks 0 and 1 staged
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(ra[d], rw[d]);
+    store(ra[0], rw[0], 0);
+    issue(ra[0], rw[0]);
+    store(ra[1], rw[1], STAGE);
+    issue(ra[1], rw[1]);
+    __syncthreads();  // barrier 0
+    // iteration i: chunk i + 2 goes from ring slot (i + 2) % D to stage (i + 2) % 3 (last read two barriers ago), the slot
+    // is refilled with chunk i + 2 + D.  Six iterations per trip: slot and stage are compile-time; one back edge, no exits
+    // inside (never-taken structurizer edges would make the waitcnt insertion wait for the loads issued one iteration ago).
+    auto step = [&](auto jtag) __attribute__((always_inline)) {
+        constexpr int J = decltype(jtag)::value;
+        store(ra[(J + 2) % D], rw[(J + 2) % D], ((J + 2) % 3) * STAGE);
+        issue(ra[(J + 2) % D], rw[(J + 2) % D]);
+        __syncthreads();
+    };
+    const int trips = n / 6;
+    for (int q = 0; q < trips; ++q) {
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+    }
+    const int rest = n - 6 * trips;
+    if (rest >= 1) step(std::integral_constant<int, 0>{});
+    if (rest >= 2) step(std::integral_constant<int, 1>{});
+    if (rest >= 3) step(std::integral_constant<int, 2>{});
+    if (rest >= 4) step(std::integral_constant<int, 3>{});
+    if (rest >= 5) step(std::integral_constant<int, 4>{});
+}
+
+// The computing waves' side of a segment (threads 0 .. NC - 1): acc += the segment's chunks.
+template <int WM, int WNC, int MI, int NI>
+__device__ __forceinline__ void ws_compute_segment(float* smem, int c_begin, int c_end, f32x16 (&acc)[MI][NI]) {
+    static_assert(WNC * NI == 4, "a tile is 128 columns wide");
+    constexpr int BM = 32 * MI * WM, BN = 128;
+    constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;
+    const int n = c_end - c_begin;
     // ================================================================ computing waves
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
+    const int wm = wid / WNC, wn = wid % WNC;
     const int l31 = lane & 31, lhi = lane >> 5;
     // per-lane operand addresses: A row, slot of k-group kg XOR-swizzled; W column
     const int sw = (l31 >> 1) & 7;
     const float* a_base = smem + (wm * 32 * MI + l31) * 32;
     const float* a_kg[4] = {a_base + (((0 * 2 + lhi) ^ sw) << 2), a_base + (((1 * 2 + lhi) ^ sw) << 2),
                             a_base + (((2 * 2 + lhi) ^ sw) << 2), a_base + (((3 * 2 + lhi) ^ sw) << 2)};
-    const float* b_base = smem + A_STAGE + (lhi * BN + wn * 32 + l31) * 4;
-    // Operand sets: the 16-byte pieces of KGS k-groups -- a whole chunk for MI = 1, half a chunk for MI = 2 (a whole chunk of
-    // 64 x 32 operands in two sets is 96 registers; with three waves per SIMD at 128-row tiles the budget is 168).
-    constexpr int PARTS = MI == 2 ? 2 : 1, KGS = 4 / PARTS;
-    float4 oa[2][MI][KGS], ob[2][KGS];  // [set][row fragment][k-group of the part]
-    auto read_set = [&](float4 (&a)[MI][KGS], float4 (&b)[KGS], int stage_off, int kg0) __attribute__((always_inline)) {
+    const float* b_base = smem + A_STAGE + (lhi * BN + wn * 32 * NI + l31) * 4;
+    // Operand sets: the 16-byte pieces of KGS k-groups -- a whole chunk for a 32 x 32 wave tile, half a chunk for the larger
+    // ones (a whole chunk of 64 x 32 operands in two sets is 96 registers; three waves per SIMD leave 168 in all).
+    constexpr int PARTS = MI * NI >= 4 ? 4 : MI * NI >= 2 ? 2 : 1, KGS = 4 / PARTS;  // 64 x 64 wave tiles: one k-group (16 MFMAs) per part
+    float4 oa[2][MI][KGS], ob[2][NI][KGS];  // [set][fragment][k-group of the part]
+    auto read_set = [&](float4 (&a)[MI][KGS], float4 (&b)[NI][KGS], int stage_off, int kg0) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < KGS; ++g) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a[mi][g] = *reinterpret_cast<const float4*>(a_kg[kg0 + g] + stage_off + mi * 32 * 32);
-            b[g] = *reinterpret_cast<const float4*>(b_base + stage_off + (kg0 + g) * 2 * BN * 4);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni][g] = *reinterpret_cast<const float4*>(b_base + stage_off + (kg0 + g) * 2 * BN * 4 + ni * 32 * 4);
         }
     };
     __syncthreads();  // barrier 0: chunks 0 and 1 are staged
@@ -827,8 +833,9 @@ __device__ __forceinline__ void gemm_segment_ws(const ConvGemmArgs& p, float* sm
             const int cur = PARTS == 1 ? J % 2 : h % 2;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < KGS; ++g) {
-                if (g == KGS / 2) {
+            for (int idx = 0; idx < 4 * KGS; ++idx) {  // the part's (k-group, step) pairs in k order
+                const int g = idx >> 2, st = idx & 3;
+                if (idx == 2 * KGS) {
                     // the reads sit in the MIDDLE of the part's MFMA chain: straight after a barrier release every
                     // non-MFMA instruction costs ~22 cycles (MI355X_MICROARCH.md) and the staging waves issue their own
                     // burst there; tools/native/mfma_burst.hip: 1170 cycles per chunk against 1330 with the reads first
@@ -837,16 +844,17 @@ __device__ __forceinline__ void gemm_segment_ws(const ConvGemmArgs& p, float* sm
                     else read_set(oa[1 - cur], ob[1 - cur], ((J + 1) % 3) * STAGE, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const float4 b = ob[cur][g];
-                const float4 x0 = oa[cur][0][g], x1 = oa[cur][MI - 1][g];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, b.x, acc[0][0], 0, 0, 0);
-                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, b.x, acc[MI - 1][0], 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, b.y, acc[0][0], 0, 0, 0);
-                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, b.y, acc[MI - 1][0], 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, b.z, acc[0][0], 0, 0, 0);
-                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, b.z, acc[MI - 1][0], 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, b.w, acc[0][0], 0, 0, 0);
-                if (MI == 2) acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, b.w, acc[MI - 1][0], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float4 x = oa[cur][mi][g];
+                    const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float4 y = ob[cur][ni][g];
+                        const float yb = st == 0 ? y.x : st == 1 ? y.y : st == 2 ? y.z : y.w;
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, yb, acc[mi][ni], 0, 0, 0);
+                    }
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1015,17 +1023,21 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_q_kernel(ConvGemmArgs p, int
 // 3: 4 waves, quad-fed 64x128 (small batches: one block per CU); 4: 4 waves, quad-fed 32x128 (batch 8).
 // 5 / 6 / 7: the shapes of 1 / 3 / 4 with the roles split between waves (gemm_segment_ws: the tile's waves only multiply,
 // four more waves only stage; three LDS stages) -- what the one-block-per-CU launches of 8 ... 32 utterances per GPU use.
+// 8: 256x128 with the roles split: eight computing waves of 64 x 64 (two per SIMD) + four staging waves -- the long-K layers of
+// the full batch (the all-in-one 16-wave kind 2 keeps the K = 512 layers, whose 16-chunk tiles feel the split's longer prologue).
+// 9: 128x128 as four computing waves of 64 x 64 + four staging waves (two waves per SIMD).
 constexpr bool sk_deep(int kind) { return kind >= 5; }
-constexpr int sk_wm(int kind) { return kind == 2 ? 4 : (kind == 3 || kind == 4 || kind == 6 || kind == 7) ? 1 : 2; }
+constexpr int sk_wm(int kind) { return (kind == 2 || kind == 8) ? 4 : (kind == 3 || kind == 4 || kind == 6 || kind == 7) ? 1 : 2; }  // waves along M (9: 2)
+constexpr int sk_wn(int kind) { return (kind == 8 || kind == 9) ? 2 : 4; }                                                                   // waves along N
 constexpr int sk_bm(int kind) { return (kind == 4 || kind == 7) ? 32 : 64 * sk_wm(kind); }
-constexpr int sk_threads(int kind) { return 256 * sk_wm(kind) + (sk_deep(kind) ? 256 : 0); }  // deep: + 4 staging waves
-constexpr int sk_min_waves(int kind) { return kind == 5 ? 3 : sk_deep(kind) ? 2 : sk_wm(kind) == 1 ? 1 : 4; }  // per SIMD: sets the VGPR budget
+constexpr int sk_threads(int kind) { return 64 * sk_wm(kind) * sk_wn(kind) + (sk_deep(kind) ? 256 : 0); }  // deep: + 4 staging waves
+constexpr int sk_min_waves(int kind) { return (kind == 5 || kind == 8) ? 3 : sk_deep(kind) ? 2 : sk_wm(kind) == 1 ? 1 : 4; }  // per SIMD: sets the VGPR budget
 constexpr size_t sk_lds_bytes(int kind) { return (size_t)(sk_deep(kind) ? 3 : 2) * BK * (sk_bm(kind) + 128) * sizeof(float); }
 template <int EPI, int KIND>
 __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gemm_streamk_kernel(ConvGemmArgs p, int ntiles, int tiles,
                                                                                       int iters_per_worker, float* slabs,
                                                                                       unsigned* flags, unsigned epoch) {
-    constexpr int WM = sk_wm(KIND), WN = 4;
+    constexpr int WM = sk_wm(KIND), WN = sk_wn(KIND);
     constexpr int BM = sk_bm(KIND), BN = 128;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 2x1 (or 1x1) fragments per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BK * (BM + BN) floats
@@ -1046,13 +1058,46 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
     const long it_end = min(total, it_begin + iters_per_worker);
     if (it_begin >= it_end) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // deep kinds: the waves past the tile's 4 WM only stage operands (gemm_segment_ws); they hold no accumulators and take
-    // part in the hand-off and the epilogue through the barriers alone
-    const bool computing = !sk_deep(KIND) || __builtin_amdgcn_readfirstlane(wid) < 4 * WM;
+    // Wave-specialised kinds: the waves past the tile's WM x WN only stage operands.  They run the worker's schedule of
+    // segments on their own -- same segments in the same order, and the same barriers as the computing waves execute around
+    // the hand-off -- and hold no accumulators.
+    if constexpr (sk_deep(KIND)) {
+        if (__builtin_amdgcn_readfirstlane(wid) >= WM * WN) {
+            const int first_tile = (int)(it_begin / C), first_c0 = (int)(it_begin % C);
+            const int last_tile = (int)((it_end - 1) / C), last_c1 = (int)((it_end - 1) % C) + 1;
+            const bool head_piece = last_c1 < C, tail_piece = first_c0 > 0;
+            auto origin = [&](int tile, int& m0, int& n0) {
+                if (p.sk_xcd == 1) {
+                    m0 = (tile % mtiles) * BM;
+                    n0 = (tile / mtiles) * BN;
+                } else {
+                    m0 = (tile / ntiles) * BM;
+                    n0 = (tile % ntiles) * BN;
+                }
+            };
+            int m0, n0;
+            if (head_piece && !(last_tile == first_tile && tail_piece)) {
+                origin(last_tile, m0, n0);
+                ws_stage_segment<WM, WN, MI, NI>(p, smem, m0, n0, 0, last_c1);
+                __syncthreads();  // the computing waves' barrier between parking the slab and publishing the flag
+            }
+            for (int tile = tail_piece ? first_tile + 1 : first_tile; tile < (head_piece ? last_tile : last_tile + 1); ++tile) {
+                origin(tile, m0, n0);
+                ws_stage_segment<WM, WN, MI, NI>(p, smem, m0, n0, 0, C);
+            }
+            if (tail_piece) {
+                origin(first_tile, m0, n0);
+                __syncthreads();  // the computing waves' barrier after the flag wait
+                ws_stage_segment<WM, WN, MI, NI>(p, smem, m0, n0, first_c0, first_tile == last_tile ? last_c1 : C);
+            }
+            return;
+        }
+    }
+    constexpr bool computing = true;
     f32x16 acc[MI][NI];
     auto segment = [&](int m0, int n0, int c0, int c1, unsigned long long* tr = nullptr) __attribute__((always_inline)) {
         if constexpr (KIND == 0) gemm_segment8(p, smem, m0, n0, c0, c1, acc);
-        else if constexpr (sk_deep(KIND)) gemm_segment_ws<WM, MI>(p, smem, m0, n0, c0, c1, acc);
+        else if constexpr (sk_deep(KIND)) ws_compute_segment<WM, WN, MI, NI>(smem, c0, c1, acc);
         else if constexpr (KIND == 3) gemm_segment_q1<2>(p, smem, m0, n0, c0, c1, acc);
         else if constexpr (KIND == 4) gemm_segment_q1<1>(p, smem, m0, n0, c0, c1, acc);
         else gemm_segment_q<WM>(p, smem, m0, n0, c0, c1, acc, tr);
@@ -1480,6 +1525,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         const char* e = getenv("SG_STREAMK_MID");  // 0 = off (tuning aid)
         return e ? atoi(e) : 1;
     }();
+    static const int mid9 = [] {
+        const char* e = getenv("SG_STREAMK_MID9");  // 1 = 128-row tiles as four 64 x 64 computing waves (kind 9) instead of kind 5
+        return e ? atoi(e) : 0;
+    }();
     if (mid && kind == 2 && a.force == 0 && ((a.M + 255) / 256) * (a.N / 128) < cus) {
         // deep = 1 (default): the three-stage / three-chunk pipeline of gemm_segment_deep (kinds 5 / 6 / 7); 0: kinds 1 / 3 / 4
         static const int deep = [] {
@@ -1487,7 +1536,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
             return e ? atoi(e) : 1;
         }();
         if (((a.M + 127) / 128) * (a.N / 128) >= cus) {
-            kind = deep ? 5 : 1;
+            kind = deep ? (mid9 ? 9 : 5) : 1;
             bm = 128;
             workers = cus;
         } else if (((a.M + 63) / 64) * (a.N / 128) >= cus) {
@@ -1502,9 +1551,22 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
             workers = cus;
         }
     }
-    if (a.force >= 6 && a.force <= 8 && a.Wq) {  // parity tests: the deep kinds on any shape that qualifies
+    // the full batch (>= 256 tiles of 256 rows): kind 8, the 256-row tile with the roles split between waves (round 3)
+    static const int ws256 = [] {
+        const char* e = getenv("SG_STREAMK_WS");  // 0 = the all-in-one 16-wave kernel (kind 2)
+        return e ? atoi(e) : 1;
+    }();
+    // measured per layer at 64 utterances (profiles/r03_layers.txt): tdnn2 / tdnn3 (80 / 112 chunks per tile) gain 1-3 % from
+    // the split, tdnn4 / tdnn5 (16 / 48 chunks) lose 4-8 %
+    static const int ws256_min_chunks = [] {
+        const char* e = getenv("SG_STREAMK_WS_MINCHUNKS");
+        return e ? atoi(e) : 64;
+    }();
+
+    if (ws256 && kind == 2 && a.force == 0 && a.total_chunks >= ws256_min_chunks) kind = 8;
+    if (a.force >= 6 && a.force <= 10 && a.Wq) {  // parity tests: the wave-specialised kinds on any shape that qualifies
         kind = a.force - 1;
-        bm = kind == 5 ? 128 : kind == 6 ? 64 : 32;
+        bm = kind == 5 || kind == 9 ? 128 : kind == 6 ? 64 : kind == 7 ? 32 : 256;
         workers = cus;
     }
     const int mtiles = (a.M + bm - 1) / bm, ntiles = a.N / 128;
@@ -1523,7 +1585,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     const int per_cu = kind == 2 ? streamk_blocks_per_cu<2>() : kind == 1 ? streamk_blocks_per_cu<1>()
                      : kind == 3 ? streamk_blocks_per_cu<3>() : kind == 4 ? streamk_blocks_per_cu<4>()
                      : kind == 5 ? streamk_blocks_per_cu<5>() : kind == 6 ? streamk_blocks_per_cu<6>()
-                     : kind == 7 ? streamk_blocks_per_cu<7>() : streamk_blocks_per_cu<0>();
+                     : kind == 7 ? streamk_blocks_per_cu<7>() : kind == 8 ? streamk_blocks_per_cu<8>() : kind == 9 ? streamk_blocks_per_cu<9>() : streamk_blocks_per_cu<0>();
     if ((long)per_cu * cus < workers) return hipErrorNotSupported;
     if ((size_t)workers * bm * 128 > (size_t)512 * 128 * 128) return hipErrorNotSupported;  // slab capacity (sg_api.hip)
     static std::atomic<unsigned> launch_counter{0};
@@ -1537,7 +1599,9 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     dim3 grid(workers);
 #define a at
 #define SG_SK(EPI)                                                                                          \
-    if (kind == 7) launch_streamk_kind<EPI, 7>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    if (kind == 9) launch_streamk_kind<EPI, 9>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);       \
+    else if (kind == 8) launch_streamk_kind<EPI, 8>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
+    else if (kind == 7) launch_streamk_kind<EPI, 7>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 6) launch_streamk_kind<EPI, 6>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 5) launch_streamk_kind<EPI, 5>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
     else if (kind == 4) launch_streamk_kind<EPI, 4>(a, workers, ntiles, tiles, ipw, slabs, flags, epoch, s);  \
@@ -1634,7 +1698,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
             if (splits == 1 && use_streamk && a.force != 1 && a.force != 4) {
                 const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
                 if (e != hipErrorNotSupported) return e;
-                if (a.force >= 6) return hipErrorInvalidValue;  // a forced deep kind never silently becomes a tile launch
+                if (a.force >= 6) return hipErrorInvalidValue;  // a forced wave-specialised kind never silently becomes a tile launch
             }
             if (a.Wq && splits == 1 && a.force != 1) return launch_tile_q(a, epi, s);
             return launch_tile<64, 128, 2, 2>(a, epi, splits, s);

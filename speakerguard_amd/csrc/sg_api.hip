@@ -940,7 +940,7 @@ int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c
     if (!ctx) return SG_ERR_ARG;
     if (!a_dev || !w_dev || !c_dev || B <= 0 || Ta <= 0 || Tc <= 0 || taps <= 0 || Kc <= 0 || Kc % 32 || N <= 0 || N % 128)
         return fail(ctx, SG_ERR_ARG, "sg_conv1d_rows: need Kc %% 32 == 0 and N %% 128 == 0 (got Kc=%d N=%d)", Kc, N);
-    if (epi < 0 || epi > 2 || (epi == 1 && !bias_dev) || (epi == 2 && !mask_dev) || kernel < 0 || kernel > 8)
+    if (epi < 0 || epi > 2 || (epi == 1 && !bias_dev) || (epi == 2 && !mask_dev) || kernel < 0 || kernel > 10)
         return fail(ctx, SG_ERR_ARG, "sg_conv1d_rows: bad epi/kernel");
     if (build_tables(ctx) != SG_OK) return SG_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;

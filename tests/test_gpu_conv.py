@@ -76,14 +76,14 @@ def test_conv_rows_matches_oracle_and_all_kernels_agree(ctx, shape):
     assert np.array_equal(outs[4], outs[1]), "quad-fed tile launch differs from the b32-fed tile launch"
     # v_mfma_f32_16x16x4_f32 fed the k values in the order the 32x32x2 kernels consume them: the same fmaf chain
     assert np.array_equal(outs[5], outs[1]), "16 x 16 blocks (small-batch kernel) differ from the tile launch"
-    # round 3: the deep pipeline (three LDS stages, three chunks of loads in flight) of the one-block-per-CU stream-K
-    # launches, forced on every shape that qualifies for it (enough tiles for 256 workers, a range >= one tile's chunks)
+    # round 3: the wave-specialised stream-K kernels (computing waves + four staging waves, three LDS stages), forced on
+    # every shape that qualifies (enough tiles for 256 workers, a range >= one tile's chunks)
     chunks = taps * (Kc // 32)
-    for k, rows in ((6, 128), (7, 64), (8, 32)):
+    for k, rows in ((6, 128), (7, 64), (8, 32), (9, 256), (10, 128)):
         tiles = -(-(B * Tc) // rows) * (n // 128)
         if chunks >= 16 and tiles >= 256 and -(-tiles * chunks // 256) >= chunks:
             o = _run(ctx, a, w, B, Ta, Tc, taps, step, base, 0, k)
-            assert np.array_equal(o, outs[1]), "deep stream-K with %d-row tiles differs from the tile launch" % rows
+            assert np.array_equal(o, outs[1]), "wave-specialised stream-K with %d-row tiles differs from the tile launch" % rows
     # and all of them ARE the documented arithmetic: one float32 fmaf chain per output in the kernels' k order, restated
     # in C on the CPU (oracle/conv_chain.c) -- bit for bit, signs of zeros included
     from oracle.conv_chain import conv_chain
@@ -119,7 +119,7 @@ def test_streamk_slabs_reused_back_to_back(ctx):
     for it in range(12):
         a = rng.standard_normal((B * Ta, Kc)).astype(np.float32)
         ref = _run(ctx, a, w, B, Ta, Tc, taps, step, 0, 0, 4)
-        for k in (0, 3, 6, 7, 8, 0):
+        for k in (0, 3, 6, 7, 8, 9, 10, 0):
             assert np.array_equal(_run(ctx, a, w, B, Ta, Tc, taps, step, 0, 0, k), ref), (it, k)
 
 
