@@ -3,8 +3,11 @@ import csv, glob, json, sys
 from collections import defaultdict
 root = sys.argv[1]
 vals = defaultdict(list)
+kernel_names = set()
 for f in glob.glob(root + "/*/*/*counter_collection.csv"):
-    rows = [r for r in csv.DictReader(open(f)) if "conv_gemm_streamk_kernel<1, 2>" in r["Kernel_Name"]]
+    # the forward (BIAS_RELU) instantiation of whatever stream-K kind the launcher picked (round 3: kind 8 for tdnn3 at batch 64)
+    rows = [r for r in csv.DictReader(open(f)) if "conv_gemm_streamk_kernel<1, " in r["Kernel_Name"]]
+    kernel_names.update(r["Kernel_Name"].split("(")[0] for r in rows[-4:])
     by_counter = defaultdict(list)
     for r in rows:
         by_counter[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
@@ -18,7 +21,7 @@ fetch_kb, write_kb = per.get("FETCH_SIZE", 0.0), per.get("WRITE_SIZE", 0.0)
 traffic = int((2.0 * fetch_kb + write_kb) * 1024)
 gui = per.get("GRBM_GUI_ACTIVE", 0.0)
 rec = {
-    "kernel": "conv_gemm_streamk_kernel<BIAS_RELU, KIND 2: 16 waves, 256x128 quad-fed> tdnn3 forward (B=64: M=17280 N=512 K=3584)",
+    "kernel": "%s: tdnn3 forward (B=64: M=17280 N=512 K=3584); round 3 = kind 8, 256x128 tile, eight 64x64 computing waves + four staging waves" % ", ".join(sorted(kernel_names)),
     "command": "bash tools/pmc_tdnn3.sh  (rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 tools/layer_bench.py "
                "--layers 3 --iters 4 --repeats 1; one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE | SQ_*)",
     "launches_averaged": {k: len(v) for k, v in vals.items()},
