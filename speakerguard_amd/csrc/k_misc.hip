@@ -341,7 +341,11 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const float alpha = dmean / (float)Tc;
     const float* a = act + (size_t)b * Tc * kPoolC + c;
     float* d = dact + (size_t)b * Tc * kPoolC + c;
-    for (int t = wid; t < Tc; t += 4) {
+    // elementwise from here on: the frames are dealt over the blocks of grid.z (small batches: 24 x 8 blocks of a 68-step
+    // loop left most CUs idle, 15 us at 8 utterances) -- any split gives the same bits
+    const int per = (Tc + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int t0 = (int)blockIdx.z * per, t1 = min(Tc, t0 + per);
+    for (int t = t0 + wid; t < t1; t += 4) {
         const float v = a[(size_t)t * kPoolC];
         d[(size_t)t * kPoolC] = v > 0.f ? alpha + beta * (v - mean) : 0.f;
     }
@@ -353,7 +357,8 @@ hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipSt
 }
 hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit, int B, int Tc,
                            float* dact5, hipStream_t s) {
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(kPoolC / 64, B), dim3(256), 0, s, act5, stats, dstats_part, nsplit, B, Tc,
+    const int z = B >= 64 ? 1 : (1536 + (kPoolC / 64) * B - 1) / ((kPoolC / 64) * B);  // >= ~1500 blocks in all
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(kPoolC / 64, B, z), dim3(256), 0, s, act5, stats, dstats_part, nsplit, B, Tc,
                        dact5);
     return hipGetLastError();
 }
