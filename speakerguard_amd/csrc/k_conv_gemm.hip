@@ -1530,7 +1530,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 0;
     }();
     if (mid && kind == 2 && a.force == 0 && ((a.M + 255) / 256) * (a.N / 128) < cus) {
-        // deep = 1 (default): the three-stage / three-chunk pipeline of gemm_segment_deep (kinds 5 / 6 / 7); 0: kinds 1 / 3 / 4
+        // deep = 1 (default): the wave-specialised kinds 5 / 6 / 7 (ws_stage_segment / ws_compute_segment); 0: the all-in-one kinds 1 / 3 / 4
         static const int deep = [] {
             const char* e = getenv("SG_STREAMK_DEEP");
             return e ? atoi(e) : 1;
