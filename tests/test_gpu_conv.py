@@ -195,3 +195,43 @@ print("CLEARED")
     env = dict(os.environ, SG_ABLATE="8", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert "RAISED True" in r.stdout and "CLEARED" in r.stdout, r.stdout + r.stderr
+
+
+def test_whole_model_is_bit_identical_with_and_without_streamk(tmp_path):
+    """Odd (batch, length) shapes -- ragged last tiles, utterances shorter than a tile, batches that pick the 32- / 64- /
+    128- / 256-row wave-specialised kinds and the 16x16 small-batch kernel -- through the WHOLE x-vector pass (scores and
+    d loss / d waveform): the launcher's own choice of kernels against the one-block-per-tile launches (SG_STREAMK=0, its own
+    process because the knob is read once), bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    code = r"""
+import sys, numpy as np, torch
+from speakerguard_amd import synth
+from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+from speakerguard_amd.model.xv_plda import xv_plda
+dev = torch.device("cuda:0")
+m = xv_plda.from_weights(synth.make_xv_weights(), device=dev, dither=0.0)
+out = {}
+for B, T in ((9, 48000), (17, 33000), (31, 48000), (33, 20000), (48, 48000), (96, 12000), (12, 100000), (5, 48000), (64, 48000)):
+    x = torch.from_numpy(synth.make_waveforms(B, T, seed=B + T)).to(dev)
+    y = (torch.arange(B) % 10).to(dev)
+    dec, sc, ls, g = m.loss_grad(x, y, SEC4SR_CrossEntropy())
+    out["s_%d_%d" % (B, T)] = sc.cpu().numpy()
+    out["g_%d_%d" % (B, T)] = g.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+    files = []
+    for tag, env in (("auto", {}), ("tiles", {"SG_STREAMK": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PYTHONPATH=ROOT, **env), cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files.append(np.load(f))
+    a, b = files
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 18
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
