@@ -1563,7 +1563,32 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 64;
     }();
 
-    if (ws256 && kind == 2 && a.force == 0 && a.total_chunks >= ws256_min_chunks) kind = 8;
+    if (ws256 && kind == 2 && a.force == 0) {
+        if (a.total_chunks >= ws256_min_chunks) {
+            kind = 8;
+        } else {
+            // the K = 512 / 1536 layers of the full batch: 128-row tiles on the wave-specialised kind 5 (eight 64x32 computing
+            // waves + four staging waves, one block per CU) -- 3-4 % faster than the 16-wave all-in-one 256-row kernel on each
+            // of tdnn4 / tdnn5 both ways (profiles/r03_layers.txt)
+            kind = 5;
+            bm = 128;
+            workers = cus;
+        }
+    }
+    static const int env_kind = [] {
+        const char* e = getenv("SG_STREAMK_KIND");  // tuning aid: 5 .. 9 = this wave-specialised kind wherever the shape qualifies
+        return e ? atoi(e) : 0;
+    }();
+    if (env_kind >= 5 && env_kind <= 9 && a.force == 0 && a.Wq) {
+        kind = env_kind;
+        bm = kind == 5 || kind == 9 ? 128 : kind == 6 ? 64 : kind == 7 ? 32 : 256;
+        workers = cus;
+        const long tl = (long)((a.M + bm - 1) / bm) * (a.N / 128);
+        if (tl < workers || (tl * a.total_chunks + workers - 1) / workers < a.total_chunks) {  // does not qualify: leave the choice alone
+            kind = 2;
+            bm = 256;
+        }
+    }
     if (a.force >= 6 && a.force <= 10 && a.Wq) {  // parity tests: the wave-specialised kinds on any shape that qualifies
         kind = a.force - 1;
         bm = kind == 5 || kind == 9 ? 128 : kind == 6 ? 64 : kind == 7 ? 32 : 256;
