@@ -888,18 +888,20 @@ __device__ __forceinline__ void tile_store(const ConvGemmArgs& p, float* C, int 
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    if (m0 + BM <= p.M) {
-        // Interior tile (all but the last row of tiles): no row checks, and every address is a wave-uniform
-        // 64-bit base (one per fragment row, SALU) plus ONE per-lane 32-bit offset, which the compiler folds
-        // into the saddr form of global_load/store -- no per-element VALU address arithmetic.  (The general
-        // path below costs ~10 instructions per element, ~350 per thread and tile.)
-        const unsigned lane_off = (unsigned)(4 * lhi * p.ldc + l31) * 4u;
+    // Per 32-row fragment (wave-uniform decision): rows all inside M -- every fragment of an interior tile, and of the last
+    // row of tiles all those above M (M is a multiple of 32 for most shapes of the model, so the slow form rarely runs; it
+    // used to serve every fragment of a partial tile and made the workers that own the last tiles finish ~10 us late) --
+    // take the fast form: no row checks, and every address is a wave-uniform 64-bit base (one per fragment row, SALU) plus
+    // ONE per-lane 32-bit offset, which the compiler folds into the saddr form of global_load/store -- no per-element VALU
+    // address arithmetic.  Rows all outside M: nothing to store.  Otherwise the general form (~10 instructions per element).
+    const unsigned lane_off = (unsigned)(4 * lhi * p.ldc + l31) * 4u;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
+        const int rowu = m0 + wm * (BM / WM) + mi * 32;  // uniform
+        if (rowu + 32 <= p.M) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int colu = n0 + wn * (BN / WN) + ni * 32;       // uniform
-                const int rowu = m0 + wm * (BM / WM) + mi * 32;       // uniform
+                const int colu = n0 + wn * (BN / WN) + ni * 32;  // uniform
                 const size_t base = (size_t)rowu * p.ldc + colu;
                 float bias = 0.f;
                 if (EPI == EPI_BIAS_RELU) bias = p.bias[colu + l31];
@@ -920,34 +922,31 @@ __device__ __forceinline__ void tile_store(const ConvGemmArgs& p, float* C, int 
                     *reinterpret_cast<float*>(cb + lane_off) = v;
                 }
             }
-        }
-        return;
-    }
+        } else if (rowu < p.M) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = n0 + wn * (BN / WN) + ni * 32 + l31;
+                const int row0 = rowu + 4 * lhi;
+                float bias = 0.f;
+                if (EPI == EPI_BIAS_RELU) bias = p.bias[col];
+                f32x16 mk;
+                if (EPI == EPI_RELU_MASK) {
+                    // all 16 mask loads in flight at once, rows clamped instead of branched around (a
+                    // guarded load makes hipcc wait vmcnt(0) per element: 64 serial L2 round trips)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int col = n0 + wn * (BN / WN) + ni * 32 + l31;
-            const int row0 = m0 + wm * (BM / WM) + mi * 32 + 4 * lhi;
-            float bias = 0.f;
-            if (EPI == EPI_BIAS_RELU) bias = p.bias[col];
-            f32x16 mk;
-            if (EPI == EPI_RELU_MASK) {
-                // all 16 mask loads in flight at once, rows clamped instead of branched around (a
-                // guarded load makes hipcc wait vmcnt(0) per element: 64 serial L2 round trips)
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = min(row0 + (e & 3) + 8 * (e >> 2), p.M - 1);
+                        mk[e] = p.mask[(size_t)row * p.ldc + col];
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = min(row0 + (e & 3) + 8 * (e >> 2), p.M - 1);
-                    mk[e] = p.mask[(size_t)row * p.ldc + col];
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    float v = acc[mi][ni][e];
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                    if (EPI == EPI_RELU_MASK) v = mk[e] > 0.f ? v : 0.f;
+                    if (row < p.M) C[(size_t)row * p.ldc + col] = v;
                 }
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + (e & 3) + 8 * (e >> 2);
-                float v = acc[mi][ni][e];
-                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-                if (EPI == EPI_RELU_MASK) v = mk[e] > 0.f ? v : 0.f;
-                if (row < p.M) C[(size_t)row * p.ldc + col] = v;
             }
         }
     }
