@@ -65,3 +65,60 @@ def test_two_processes_on_the_engine_match_one(tmp_path):
         got = torch.load(out % rank)
         assert got["succ"] == list(ref_succ) and torch.equal(got["adv"], ref_adv.cpu()), rank
         assert got["qsucc"] == list(ref_qsucc) and torch.equal(got["qadv"], ref_qadv.cpu()), rank
+
+
+def _rccl_worker(rank, port, out):
+    """One rank over the `nccl` backend (= RCCL): communicator creation on the GPU box, then every collective the product
+    issues -- ShardedAttack's flag all-gather and restart all-reduce, QueryShardedModel's score / gradient all-gathers,
+    bench.py's uint8 flag exchange and barrier -- on DEVICE tensors.  A single GPU admits a single RCCL rank, so the
+    exchange itself is degenerate; what this pins is that the calls, dtypes (RCCL has no bool) and tensor placement the
+    N > 1 path uses are accepted by RCCL."""
+    import sys
+    from conftest import ROOT
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=1, device_id=torch.device("cuda", 0))
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.shard import QueryShardedModel, ShardedAttack
+    model, x, y = _setup()
+    adv, succ = ShardedAttack(_pgd(model)).attack(x, y)
+    restarts = PGD(model, epsilon=0.002, step_size=0.0005, max_iter=2, num_random_init=2, batch_size=2, verbose=0)
+    import numpy as np
+    np.random.seed(5)
+    radv, rsucc = ShardedAttack(restarts).attack(x, y)
+    model._noise_epoch = 0
+    qadv, qsucc = _fakebob(QueryShardedModel(model)).attack(x[:2], y[:2])
+    sys.path.insert(0, ROOT)
+    import bench
+    flags = bench.gather_flags(torch.tensor(list(succ), device="cuda:0"), dist, 1)
+    (k, _), dt = bench.timed_region(lambda k: (k, None), 2, 1, dist, torch.cuda.synchronize, torch.device("cuda", 0))
+    torch.save({"adv": adv.cpu(), "succ": succ, "radv": radv.cpu(), "rsucc": rsucc, "qadv": qadv.cpu(), "qsucc": qsucc,
+                "flags": flags.cpu(), "backend": dist.get_backend(), "k": k, "dt": dt}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_backend_runs_the_exchange_on_device_tensors(tmp_path):
+    import numpy as np
+    from speakerguard_amd.attack.PGD import PGD
+    model, x, y = _setup()
+    ref_adv, ref_succ = _pgd(model).attack(x, y)
+    np.random.seed(5)
+    ref_radv, ref_rsucc = PGD(model, epsilon=0.002, step_size=0.0005, max_iter=2, num_random_init=2, batch_size=2,
+                              verbose=0).attack(x, y)
+    model._noise_epoch = 0
+    ref_qadv, ref_qsucc = _fakebob(model).attack(x[:2], y[:2])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["backend"] == "nccl"
+    assert got["succ"] == list(ref_succ) and torch.equal(got["adv"], ref_adv.cpu())
+    assert got["rsucc"] == list(ref_rsucc) and torch.equal(got["radv"], ref_radv.cpu())
+    assert got["qsucc"] == list(ref_qsucc) and torch.equal(got["qadv"], ref_qadv.cpu())
+    assert got["flags"].tolist() == [int(v) for v in ref_succ] and got["flags"].dtype == torch.uint8
+    assert got["k"] == 2 and got["dt"] >= 0
