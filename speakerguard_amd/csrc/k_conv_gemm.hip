@@ -1187,6 +1187,9 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
         for (int i = 1; i < 15; ++i) p.trace[(size_t)w * 16 + i] = 0;
     }
     SG_STAMP(0)
+    // (wave-specialised kinds: slots 13 / 14 = the shader clock counter at the worker's start and end -- tools/sk_trace.py
+    // prints the clock the CU actually ran at)
+    if (sk_deep(KIND) && p.trace && threadIdx.x == 0) p.trace[(size_t)w * 16 + 13] = __builtin_readcyclecounter();
     // 1. the head piece of my last tile (chunks [0, last_c1)): park it for worker w+1
     if (head_piece && !(last_tile == first_tile && tail_piece)) {
         int m0, n0;
@@ -1268,6 +1271,7 @@ __global__ __launch_bounds__(sk_threads(KIND), sk_min_waves(KIND)) void conv_gem
         if (computing) tile_store<BM, BN, WM, WN, EPI>(p, p.C, m0, n0, acc);
         SG_STAMP(12)
     }
+    if (sk_deep(KIND) && p.trace && threadIdx.x == 0) p.trace[(size_t)w * 16 + 14] = __builtin_readcyclecounter();
 #undef SG_STAMP
 }
 

@@ -49,6 +49,13 @@ end = np.nanmax(np.stack([col(i) for i in (2, 4, 6, 8, 12)]), axis=0)
 busy = end - start
 print("per-worker start->end: median %.1f p10 %.1f p90 %.1f max %.1f us;  last end inside its XCD: %.1f us" % (
     np.nanmedian(busy), np.nanpercentile(busy, 10), np.nanpercentile(busy, 90), np.nanmax(busy), np.nanmax(end)))
+cyc = t[:, 14].astype(np.float64) - t[:, 13].astype(np.float64)
+okc = (t[:, 13] != 0) & (t[:, 14] > t[:, 13]) & ~np.isnan(busy) & (busy > 0)
+if okc.sum() > 8:
+    mhz = cyc[okc] / busy[okc]
+    print("shader clock over the worker's busy time (s_memtime ticks per us): median %.0f MHz  p10 %.0f  p90 %.0f;  by XCD: %s" % (
+        np.median(mhz), np.percentile(mhz, 10), np.percentile(mhz, 90),
+        ["%d: %.0f" % (x, np.median(mhz[xcc[okc] == x])) for x in range(8) if (xcc[okc] == x).any()]))
 chunk_us = 128 * 128 * 32 * 2 * 2 / (157.3e12 / 256) * 1e6
 print("ideal chunk time at peak with 2 blocks per CU: %.2f us" % chunk_us)
 def rep(name, a, b, chunks=None):
