@@ -791,14 +791,15 @@ __device__ __forceinline__ void ws_stage_segment(const ConvGemmArgs& p, float* s
 }
 
 // The computing waves' side of a segment (threads 0 .. NC - 1): acc += the segment's chunks.
-// BG (32- and 64-row tiles): the W operands do not pass through LDS.  profiles/r03_staging_cost.txt: at 32-row tiles the
-// staging costs the computing waves 16 points of the MFMA peak, and 6.5 of them are the LDS WRITES of the W tile alone
-// (16 KB per chunk whatever the tile height; the reads of the same bytes, the staging instruction count -- LDS-DMA was
-// tried -- and the barrier cost nothing).  A computing wave's W operand of a k-group IS a coalesced 1 KB piece of the
+// BG (the 64-row kind, sk_bg): the W operands do not pass through LDS.  profiles/r03_staging_cost.txt: at small tiles the
+// staging costs the computing waves up to 16 points of the MFMA peak, and 4-6 of them are the LDS WRITES of the W tile
+// alone (16 KB per chunk whatever the tile height; the reads of the same bytes, the staging instruction count -- LDS-DMA
+// was tried -- and the barrier cost nothing).  A computing wave's W operand of a k-group IS a coalesced 1 KB piece of the
 // k4-packed weights (lane (column, k half) holds W[2 kg + half][column] as one float4), so each wave requests its own
 // 32-column slice straight from the L2: 4 x 16-byte buffer loads per chunk where it had 4 x ds_read_b128, into a register
 // ring DB chunks deep, refilled in the middle of the MFMA run like the A reads.  Same values in the same k order:
-// bit-identical.
+// bit-identical.  Pays at 64-row tiles (32 MFMAs per 4 loads: -1.7 % over the eight layers at 16 utterances); at 32-row
+// tiles (16 MFMAs per 4 loads) it is 8 % slower than staging W through LDS, so kind 7 keeps the LDS path.
 template <int WM, int WNC, int MI, int NI, bool BG>
 __device__ __forceinline__ void ws_compute_segment(const ConvGemmArgs& p, float* smem, int n0, int c_begin, int c_end,
                                                    f32x16 (&acc)[MI][NI]) {
