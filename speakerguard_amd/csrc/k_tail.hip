@@ -26,6 +26,7 @@ constexpr int kMaxS = kLossMaxS;
 struct TailModelDev {
     const float *fc1_b, *emb_mean, *lda, *lda_t, *plda_mean, *plda_p, *plda_pt, *plda_psi, *enroll;
     int D, S;
+    int Dp;  // D rounded up to a multiple of 4: row stride of lda_t / plda_p / plda_pt (zero-padded); lda rows are kLdaLd long
     float threshold, logdet_given, logdet_without;
 };
 
@@ -45,23 +46,38 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return r;
 }
 
-// out[n] = sum_k W[k * ld + n] * v[k] for n < N (v, out, part in LDS).  Quarter q of the block takes the k range
-// [q K/4, (q+1) K/4); the four partial sums are added in quarter order.  Ends with a barrier.
-__device__ __forceinline__ void matvec_cols(const float* __restrict__ W, int ld, int K, int N, const float* v,
-                                            float* out, float* part) {
-    const int q = threadIdx.x >> 8, c = threadIdx.x & 255;
-    const int k0 = (int)((long long)K * q / kTailParts), k1 = (int)((long long)K * (q + 1) / kTailParts);
-    for (int n = c; n < N; n += 256) {
-        float acc = 0.f;
+// out[n] = sum_k W[k * ld + n] * v[k] for n < 4 N4 (v, out, part in LDS; ld a multiple of 4 floats, W 16-byte aligned; columns
+// past the matrix's own width are zero padding).  A thread owns FOUR adjacent columns (one 16-byte load per row) and one
+// of NP = 1024 / N4 slices of the k range, so a product is 10-26 independent 16-byte loads per thread, all in flight at
+// once, where the first version (one column per thread, four k slices) issued 50-128 dependent-batch 4-byte loads: the
+// four products of a tail went from 20.9 to ~11 us (the 1.1 MB of matrices cross one CU's L1 at 64 B/clk: 7.4 us is the
+// floor).  The NP partial sums of a column are combined in slice order.  Ends with a barrier.
+constexpr int kTailPart = 4096;  // floats: NP x 4 N4 <= 1024 x 4
+__device__ __forceinline__ void matvec_cols4(const float* __restrict__ W, int ld, int K, int N4, const float* v, float* out,
+                                             float* part) {
+    const int NP = kTailThreads / N4, N = 4 * N4;
+    const int p = threadIdx.x / N4, cg = threadIdx.x - p * N4;
+    const int R = (K + NP - 1) / NP, k0 = p * R;
+    if (p < NP) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* col = W + 4 * cg;
+        // rows past the slice / the matrix are clamped to a valid row and weighted 0: no load sits behind a branch
 #pragma unroll 16
-        for (int k = k0; k < k1; ++k) acc += W[(size_t)k * ld + n] * v[k];
-        part[q * kMaxD + n] = acc;
+        for (int j = 0; j < R; ++j) {
+            const int k = k0 + j, kk = min(k, K - 1);
+            const float4 w = *reinterpret_cast<const float4*>(col + (size_t)kk * ld);
+            const float x = k < K ? v[kk] : 0.f;
+            acc.x += w.x * x;
+            acc.y += w.y * x;
+            acc.z += w.z * x;
+            acc.w += w.w * x;
+        }
+        *reinterpret_cast<float4*>(part + p * N + 4 * cg) = acc;
     }
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += kTailThreads) {
         float r = part[n];
-#pragma unroll
-        for (int i = 1; i < kTailParts; ++i) r += part[i * kMaxD + n];
+        for (int i = 1; i < NP; ++i) r += part[i * N + n];
         out[n] = r;
     }
     __syncthreads();
@@ -76,21 +92,17 @@ __device__ __forceinline__ float touch_matrices(const TailModelDev& m, int want_
     constexpr int NT = kTailThreads;
     const int D = m.D;
     const int nq = min(8, max(1, ((int)gridDim.x + 7) >> 3)), q = (b >> 3) % nq;
-    const size_t n_lda = (size_t)(kEmb + 1) * D, n_p = (size_t)D * D;
-    const size_t step = (size_t)NT * nq * 32;
+    const size_t n_ldat = (size_t)(kEmb + 1) * m.Dp, n_lda = (size_t)D * kLdaLd, n_p = (size_t)D * m.Dp;
+    const size_t step = (size_t)NT * nq * 32, first = ((size_t)tid * nq + q) * 32;
+    // Independent, clamped loads: the first line of every matrix for every thread is in flight at once
+    const float pa = m.lda_t[min(first, n_ldat - 1)], pb = want_grad ? m.lda[min(first, n_lda - 1)] : 0.f;
+    const float pc = m.plda_pt[min(first, n_p - 1)], pd2 = want_grad ? m.plda_p[min(first, n_p - 1)] : 0.f;
     float sink = 0.f;
-    float pa[2], pb[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const size_t j = min(((size_t)tid * nq + q) * 32 + r * step, n_lda - 1);
-        pa[r] = m.lda_t[j];
-        pb[r] = want_grad ? m.lda[j] : 0.f;
-    }
-    const size_t jp = min(((size_t)tid * nq + q) * 32, n_p - 1);
-    const float pc = m.plda_pt[jp], pd2 = want_grad ? m.plda_p[jp] : 0.f;
-    for (size_t j = ((size_t)tid * nq + q) * 32 + 2 * step; j < n_lda; j += step) sink += m.lda_t[j] + (want_grad ? m.lda[j] : 0.f);
-    for (size_t j = ((size_t)tid * nq + q) * 32 + step; j < n_p; j += step) sink += m.plda_pt[j] + (want_grad ? m.plda_p[j] : 0.f);
-    sink += (pa[0] + pa[1]) + (pb[0] + pb[1]) + (pc + pd2);
+    for (size_t j = first + step; j < n_ldat; j += step) sink += m.lda_t[j];
+    for (size_t j = first + step; j < n_p; j += step) sink += m.plda_pt[j] + (want_grad ? m.plda_p[j] : 0.f);
+    if (want_grad)
+        for (size_t j = first + step; j < n_lda; j += step) sink += m.lda[j];
+    sink += (pa + pb) + (pc + pd2);
     return sink;
 }
 
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     __shared__ float e2[kMaxD], e4[kMaxD], e5[kMaxD], dv[kMaxD];
     __shared__ float sc[kMaxS], dsc[kMaxS];
     __shared__ float red[kTailThreads / 64];
-    __shared__ float part[kTailParts * kMaxD];
+    __shared__ __attribute__((aligned(16))) float part[kTailPart];
     constexpr int NT = kTailThreads;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (b >= B) {  // helper block of a small batch: warm the L2 of an XCD that has an utterance to serve, nothing else
@@ -155,10 +167,10 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     __syncthreads();
     TSTAMP(1)
     // 2. LDA (the offset column of the (D, 513) matrix is row kEmb of the transposed copy)
-    matvec_cols(m.lda_t, D, kEmb, D, e1, e2, part);
+    matvec_cols4(m.lda_t, m.Dp, kEmb, m.Dp / 4, e1, e2, part);
     float n2 = 0.f;
     for (int d = tid; d < D; d += NT) {
-        const float acc = e2[d] + m.lda_t[(size_t)kEmb * D + d];
+        const float acc = e2[d] + m.lda_t[(size_t)kEmb * m.Dp + d];
         e2[d] = acc;
         n2 += acc * acc;
     }
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     __syncthreads();
     TSTAMP(3)
     // 4. PLDA transform + normalisation factor
-    matvec_cols(m.plda_pt, D, D, D, e2, e4, part);
+    matvec_cols4(m.plda_pt, m.Dp, D, m.Dp / 4, e2, e4, part);
     TSTAMP(4)
     float qp = 0.f;
     for (int d = tid; d < D; d += NT) qp += e4[d] * e4[d] / (m.plda_psi[d] + 1.f);
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     TSTAMP(6)
     // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
     {
-        int64_t dec = 0;  // scratch: `part` (kTailParts x kMaxD floats >= kMaxS) and `red` (16 floats), both idle here
+        int64_t dec = 0;  // scratch: `part` (kTailPart floats >= kMaxS) and `red` (16 floats), both idle here
         const float loss = loss_and_dscores_block(sc, dsc, part, red, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, NT,
                                                   ls.coef_dev ? ls.coef_dev + (size_t)(coef_rows > 0 ? b % coef_rows : b) * S : nullptr);
         if (tid == 0) {
@@ -250,12 +262,12 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     __syncthreads();
     TSTAMP(9)
     // 11-12. P^T, length-norm ratio
-    matvec_cols(m.plda_p, D, D, D, dv, e2, part);
+    matvec_cols4(m.plda_p, m.Dp, D, m.Dp / 4, dv, e2, part);
     TSTAMP(10)
     for (int j = tid; j < D; j += NT) e2[j] *= ratio;
     __syncthreads();
     // 13. LDA^T -> d loss / d fc1 output
-    matvec_cols(m.lda, kEmb + 1, D, kEmb, e2, e1, part);
+    matvec_cols4(m.lda, kLdaLd, D, kEmb / 4, e2, e1, part);
     TSTAMP(11)
     for (int i = tid; i < kEmb; i += NT) demb[(size_t)b * kEmb + i] = e1[i];
     TSTAMP(12)
@@ -270,7 +282,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     m.fc1_b = x.fc1_b; m.emb_mean = x.emb_mean; m.lda = x.lda; m.lda_t = x.lda_t; m.plda_mean = x.plda_mean;
     m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi;
     m.enroll = x.enroll_override ? x.enroll_override : x.enroll;
-    m.D = x.D; m.S = S; m.threshold = x.threshold;
+    m.D = x.D; m.Dp = x.Dp; m.S = S; m.threshold = x.threshold;
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
     // tuning aid: SG_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
     static const bool tr_on = getenv("SG_TAIL_TRACE") != nullptr;

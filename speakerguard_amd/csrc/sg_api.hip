@@ -594,12 +594,21 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
     }
     const int D = w->D, S = w->S;
     {
-        std::vector<float> lda(w->lda, w->lda + (size_t)D * (kEmb + 1)), ldat((size_t)(kEmb + 1) * D);
+        // device layouts for the tail kernel's 16-byte column loads: rows 16-byte aligned, zero padding
+        const int Dp = (D + 3) & ~3;
+        m.Dp = Dp;
+        std::vector<float> lda((size_t)D * kLdaLd, 0.f), ldat((size_t)(kEmb + 1) * Dp, 0.f);
         for (int d = 0; d < D; ++d)
-            for (int i = 0; i <= kEmb; ++i) ldat[(size_t)i * D + d] = lda[(size_t)d * (kEmb + 1) + i];
-        std::vector<float> p(w->plda_transform, w->plda_transform + (size_t)D * D), pt((size_t)D * D);
+            for (int i = 0; i <= kEmb; ++i) {
+                lda[(size_t)d * kLdaLd + i] = w->lda[(size_t)d * (kEmb + 1) + i];
+                ldat[(size_t)i * Dp + d] = w->lda[(size_t)d * (kEmb + 1) + i];
+            }
+        std::vector<float> p((size_t)D * Dp, 0.f), pt((size_t)D * Dp, 0.f);
         for (int d = 0; d < D; ++d)
-            for (int j = 0; j < D; ++j) pt[(size_t)j * D + d] = p[(size_t)d * D + j];
+            for (int j = 0; j < D; ++j) {
+                p[(size_t)d * Dp + j] = w->plda_transform[(size_t)d * D + j];
+                pt[(size_t)j * Dp + d] = w->plda_transform[(size_t)d * D + j];
+            }
         double ldg = 0.0, ldw = 0.0;
         for (int d = 0; d < D; ++d) {
             const double psi = w->plda_psi[d];

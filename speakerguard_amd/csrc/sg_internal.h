@@ -16,6 +16,7 @@ constexpr int kWin = 400;       // frame_length 25 ms
 constexpr int kFft = 512;       // round_to_power_of_two
 constexpr int kMel = 30;        // num_mel_bins
 constexpr int kCep = 30;        // num_ceps
+constexpr int kLdaLd = 516;     // row length of the device copy of the (D, 513) LDA matrix
 constexpr int kFeatPad = 32;    // cepstra padded to the GEMM K granule
 constexpr int kCmnWindow = 300; // iv_plda.py:310
 constexpr float kEps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
@@ -140,11 +141,12 @@ struct XvModel {
     float* fc1_wt = nullptr;    // [512][kStats] folded (for the backward GEMM)
     float* fc1_b = nullptr;     // [512] folded
     float* emb_mean = nullptr;  // [512]
-    float* lda = nullptr;       // [D][513]
-    float* lda_t = nullptr;     // [513][D]
+    int Dp = 0;                 // D rounded up to a multiple of 4 (row stride of the transposed / PLDA matrices below)
+    float* lda = nullptr;       // [D][kLdaLd]: the (D, 513) LDA matrix, rows padded to 516 floats (16-byte aligned rows)
+    float* lda_t = nullptr;     // [513][Dp], zero-padded columns
     float* plda_mean = nullptr; // [D]
-    float* plda_p = nullptr;    // [D][D]
-    float* plda_pt = nullptr;   // [D][D] transposed
+    float* plda_p = nullptr;    // [D][Dp], zero-padded columns
+    float* plda_pt = nullptr;   // [D][Dp] transposed, zero-padded columns
     float* plda_psi = nullptr;  // [D]
     float* enroll = nullptr;    // [S][D]
     int enroll_cap = 0;         // speakers the enroll buffer holds (sg_xv_set_enroll reuses it)
