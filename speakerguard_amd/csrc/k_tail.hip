@@ -10,8 +10,9 @@
 // One block of 1024 threads per utterance; reductions are wavefront shuffles + a 16-entry LDS pass.
 // The four matrix-vector products are bound by the LATENCY of the (L2-resident) matrix loads, not by bandwidth
 // (1.2 MB per utterance): un-unrolled they issued one dependent load at a time (157 us for the kernel), unrolled
-// 8-16x with 256 threads 97 us; now the K range of every product is split over the four 256-thread quarters of
-// the block (4x the loads in flight), partial sums are combined in a fixed order through LDS.
+// 8-16x with 256 threads 97 us; with the K range of every product split over the four 256-thread quarters of the block
+// 35 us; now every thread owns four adjacent columns (16-byte loads) of one of 8-20 k slices (matvec_cols4): 26 us.
+// Partial sums are combined in a fixed order through LDS.
 #include <cstdio>
 #include <cstdlib>
 
