@@ -170,25 +170,41 @@ __global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __r
     __shared__ double total[kCep];
     __shared__ double part[kCmvnParts][32];
     if (F <= kCmnWindow) {
-        // every window is the whole utterance: one column sum per cepstrum, 32 row-strided partial
-        // sums per column combined in a fixed order
-        {
-            const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
-            double acc = 0.0;
-            if (d < kCep)
-                for (int t = r; t < F; t += kCmvnParts) acc += (double)x[(size_t)t * ld_in + d];
-            part[r][d] = acc;
+        // every window is the whole utterance: one column sum per cepstrum, 32 row-strided partial sums per column
+        // combined in a fixed order.  Thread (column d, row class r) keeps its <= 10 values (rows r, r + 32, ...) in
+        // registers -- loaded in one batch of independent, clamped loads -- and writes the same elements back: one global
+        // round trip and two barriers, where the first version read the utterance twice (9.1 -> see profiles/).
+        constexpr int kRows = (kCmnWindow + kCmvnParts - 1) / kCmvnParts;
+        const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
+        float v[kRows];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int t = min(r + j * kCmvnParts, F - 1);
+            v[j] = d < kCep ? x[(size_t)t * ld_in + d] : 0.f;
         }
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j)
+            if (r + j * kCmvnParts < F) acc += (double)v[j];
+        part[r][d] = acc;
         __syncthreads();
         if (threadIdx.x < kCep) {
-            double acc = 0.0;
-            for (int r = 0; r < kCmvnParts; ++r) acc += part[r][threadIdx.x];
-            total[threadIdx.x] = acc;
+            double a2 = 0.0;
+            for (int rr = 0; rr < kCmvnParts; ++rr) a2 += part[rr][threadIdx.x];
+            total[threadIdx.x] = a2;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < F * ld_out; i += kCmvnThreads) {
-            const int t = i / ld_out, d = i - t * ld_out;
-            y[i] = d < kCep ? x[(size_t)t * ld_in + d] - (float)(total[d] / (double)F) : 0.f;
+        const float mean = d < kCep ? (float)(total[d] / (double)F) : 0.f;
+        if (d < ld_out) {
+#pragma unroll
+            for (int j = 0; j < kRows; ++j) {
+                const int t = r + j * kCmvnParts;
+                if (t < F) y[(size_t)t * ld_out + d] = d < kCep ? v[j] - mean : 0.f;
+            }
+        }
+        for (int i = threadIdx.x; i < F * (ld_out - 32); i += kCmvnThreads) {  // (row stride above 32: the rest of the zero padding)
+            const int t = i / (ld_out - 32), dd = 32 + i - t * (ld_out - 32);
+            y[(size_t)t * ld_out + dd] = 0.f;
         }
     } else {
         for (int i = threadIdx.x; i < F * ld_out; i += kCmvnThreads) {
@@ -208,44 +224,64 @@ __global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __r
 
 // d_in[u] = d_out[u] - sum_{t : u in window(t)} d_out[t] / |window(t)|
 // d_out arrives as `nsplit` split-K slabs of the tdnn1 data-gradient contraction (summed in order).
-__global__ __launch_bounds__(kCmvnThreads) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout, int nsplit,
+// NS > 0: the slab count as a compile-time constant (the attack loop's kL1BwdSplitK): the slab loads of a row are then one
+// batch of independent loads instead of two dependent ones.
+template <int NS>
+__global__ __launch_bounds__(kCmvnThreads) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout, int nsplit_rt,
                                                        long long slab_stride, float* __restrict__ din, int ld_din,
                                                        int F) {
     const int b = blockIdx.x;
     const float* g = dout + (size_t)b * F * ld_dout;
     float* y = din + (size_t)b * F * ld_din;
-    auto gsum = [&](int t, int d) {
+    const int nsplit = NS > 0 ? NS : nsplit_rt;
+    auto gsum = [&](int t, int d) __attribute__((always_inline)) {
+        const float* src = g + (size_t)t * ld_dout + d;
+        if (NS > 0) {
+            float part[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int z = 0; z < NS; ++z) part[z] = src[(size_t)z * slab_stride];
+            float v = 0.f;
+#pragma unroll
+            for (int z = 0; z < NS; ++z) v += part[z];
+            return v;
+        }
         float v = 0.f;
 #pragma unroll 5
-        for (int z = 0; z < nsplit; ++z) v += g[(size_t)z * slab_stride + (size_t)t * ld_dout + d];
+        for (int z = 0; z < nsplit; ++z) v += src[(size_t)z * slab_stride];
         return v;
     };
     __shared__ double total[kCep];
     __shared__ double part[kCmvnParts][32];
-    __shared__ float stage[kCmnWindow * kCep];  // summed slabs of one utterance (<= 300 frames)
     if (F <= kCmnWindow) {
-        for (int i = threadIdx.x; i < F * kCep; i += kCmvnThreads) {
-            const int t = i / kCep, d = i - t * kCep;
-            stage[i] = gsum(t, d);
+        // thread (column d, row class r): the slab sums of its <= 10 rows stay in registers (kRows x nsplit independent
+        // loads, slabs added in order), the column means come from the same row-strided partial sums as before
+        constexpr int kRows = (kCmnWindow + kCmvnParts - 1) / kCmvnParts;
+        const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
+        float v[kRows];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int t = min(r + j * kCmvnParts, F - 1);
+            v[j] = d < kCep ? gsum(t, d) : 0.f;
         }
-        __syncthreads();
-        {
-            const int d = threadIdx.x & 31, r = threadIdx.x >> 5;
-            double acc = 0.0;
-            if (d < kCep)
-                for (int t = r; t < F; t += kCmvnParts) acc += (double)stage[t * kCep + d];
-            part[r][d] = acc;
-        }
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j)
+            if (r + j * kCmvnParts < F) acc += (double)v[j];
+        part[r][d] = acc;
         __syncthreads();
         if (threadIdx.x < kCep) {
-            double acc = 0.0;
-            for (int r = 0; r < kCmvnParts; ++r) acc += part[r][threadIdx.x];
-            total[threadIdx.x] = acc / (double)F;
+            double a2 = 0.0;
+            for (int rr = 0; rr < kCmvnParts; ++rr) a2 += part[rr][threadIdx.x];
+            total[threadIdx.x] = a2 / (double)F;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < F * kCep; i += kCmvnThreads) {
-            const int t = i / kCep, d = i - t * kCep;
-            y[(size_t)t * ld_din + d] = stage[i] - (float)total[d];
+        if (d < kCep) {
+            const float mean = (float)total[d];
+#pragma unroll
+            for (int j = 0; j < kRows; ++j) {
+                const int t = r + j * kCmvnParts;
+                if (t < F) y[(size_t)t * ld_din + d] = v[j] - mean;
+            }
         }
     } else {
         for (int i = threadIdx.x; i < F * kCep; i += kCmvnThreads) {
@@ -267,7 +303,10 @@ hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, i
 }
 hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long slab_stride, float* din, int ld_din,
                            int B, int F, hipStream_t s) {
-    hipLaunchKernelGGL(cmvn_bwd_kernel, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
+    if (nsplit == kL1BwdSplitK)
+        hipLaunchKernelGGL(cmvn_bwd_kernel<kL1BwdSplitK>, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
+    else
+        hipLaunchKernelGGL(cmvn_bwd_kernel<0>, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
     return hipGetLastError();
 }
 
