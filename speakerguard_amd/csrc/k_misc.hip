@@ -363,6 +363,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 
 // d act[t][c] = relu'(act) * ( dmean[c]/T + dstd[c] * (act - mean) / ((T-1) * std) ), std == 0 -> no std term
 // (torch std_backward masks result == 0).  dstats arrives as `nsplit` split-K partials.
+// NS > 0: the slab count at compile time (kFc1BwdSplitK): all 2 NS loads of the slab sums in flight at once.
+template <int NS>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ act, const float* __restrict__ stats,
                                                        const float* __restrict__ dpart, int nsplit, int B, int Tc,
                                                        float* __restrict__ dact) {
@@ -370,9 +372,23 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const int c = blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
     float dmean = 0.f, dstd = 0.f;
-    for (int z = 0; z < nsplit; ++z) {
-        dmean += dpart[((size_t)z * B + b) * kStats + c];
-        dstd += dpart[((size_t)z * B + b) * kStats + kPoolC + c];
+    if (NS > 0) {
+        float pm[NS > 0 ? NS : 1], ps[NS > 0 ? NS : 1];
+#pragma unroll
+        for (int z = 0; z < NS; ++z) {
+            pm[z] = dpart[((size_t)z * B + b) * kStats + c];
+            ps[z] = dpart[((size_t)z * B + b) * kStats + kPoolC + c];
+        }
+#pragma unroll
+        for (int z = 0; z < NS; ++z) {
+            dmean += pm[z];
+            dstd += ps[z];
+        }
+    } else {
+        for (int z = 0; z < nsplit; ++z) {
+            dmean += dpart[((size_t)z * B + b) * kStats + c];
+            dstd += dpart[((size_t)z * B + b) * kStats + kPoolC + c];
+        }
     }
     const float mean = stats[(size_t)b * kStats + c];
     const float sd = stats[(size_t)b * kStats + kPoolC + c];
@@ -397,8 +413,11 @@ hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipSt
 hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit, int B, int Tc,
                            float* dact5, hipStream_t s) {
     const int z = B >= 64 ? 1 : (1536 + (kPoolC / 64) * B - 1) / ((kPoolC / 64) * B);  // >= ~1500 blocks in all
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(kPoolC / 64, B, z), dim3(256), 0, s, act5, stats, dstats_part, nsplit, B, Tc,
-                       dact5);
+    if (nsplit == kFc1BwdSplitK)
+        hipLaunchKernelGGL(pool_bwd_kernel<kFc1BwdSplitK>, dim3(kPoolC / 64, B, z), dim3(256), 0, s, act5, stats, dstats_part, nsplit, B,
+                           Tc, dact5);
+    else
+        hipLaunchKernelGGL(pool_bwd_kernel<0>, dim3(kPoolC / 64, B, z), dim3(256), 0, s, act5, stats, dstats_part, nsplit, B, Tc, dact5);
     return hipGetLastError();
 }
 

@@ -32,8 +32,8 @@ constexpr int kDil[kLayers] = {1, 2, 3, 1, 1};
 constexpr int kEmb = 512;
 constexpr int kPoolC = 1536;           // padded tdnn5 channels
 constexpr int kStats = 2 * kPoolC;     // [mean | std], padded
-constexpr int kFc1SplitK = 24;         // fc1 forward split-K (3072 / 128)
-constexpr int kFc1BwdSplitK = 4;
+constexpr int kFc1SplitK = 48;         // fc1 forward split-K (3072 / 64: two chunks per block)
+constexpr int kFc1BwdSplitK = 8;          // (512 / 64: two chunks per block)
 constexpr int kL1BwdSplitK = 10;       // tdnn1 data gradient: two K-slabs per tap (N = 32 gives only 19 tiles per 8 utterances: with one
                                        // slab per tap 95 blocks for 256 CUs, 19 -> 11 us at 8 utterances, 29 -> 24 at 32, same at 64).  A
                                        // constant of the arithmetic: the slabs are summed in order, whatever the batch
