@@ -59,11 +59,14 @@ __device__ __forceinline__ double2 tw512(const double2* __restrict__ tw, int m, 
     return make_double2(f * w.x, -sgn * f * w.y);
 }
 
-__device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
-    double2 v0, v1, v2, v3, v4, v5, v6, v7;
-    // ---- pass 1
+// The three passes, separately, with the transform's input and output in REGISTERS: a caller that knows its input (real,
+// zero-padded: the MFCC forward; one-sided: the gradient spectrum) or needs only part of the output (bins 0..255; the real
+// part of samples 0..399) skips the LDS traffic of the parts it does not need -- 16-byte LDS accesses are what these
+// kernels are short of (PMC: the LDS pipe is busy 54 % of the MFCC forward kernel, 31 % of that in bank conflicts).
+// pass 1: lane n2 holds v_j = x[n2 + 64 j]; leaves y[k1][n2] at SP(n2 + 64 k1).
+__device__ __forceinline__ void fft512_pass1(double2* buf, const double2* __restrict__ tw, int lane, double sgn, double2 v0,
+                                             double2 v1, double2 v2, double2 v3, double2 v4, double2 v5, double2 v6, double2 v7) {
     double2* p1 = buf + SP(lane);  // SP(lane + 64 j) = SP(lane) + 72 j
-    v0 = p1[0]; v1 = p1[72]; v2 = p1[144]; v3 = p1[216]; v4 = p1[288]; v5 = p1[360]; v6 = p1[432]; v7 = p1[504];
     SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
     p1[0] = v0;
     p1[72] = cmul(v1, tw512(tw, lane, sgn));
@@ -74,34 +77,45 @@ __device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restric
     p1[432] = cmul(v6, tw512(tw, 6 * lane, sgn));
     p1[504] = cmul(v7, tw512(tw, 7 * lane, sgn));
     wave_sync();
-    // ---- pass 2: lane = (k1, b)
-    {
-        const int k1 = lane >> 3, b = lane & 7;
-        const double2* r = buf + k1 * 72 + b;  // SP(64 k1 + 8 a + b) = 72 k1 + 9 a + b
-        v0 = r[0]; v1 = r[9]; v2 = r[18]; v3 = r[27]; v4 = r[36]; v5 = r[45]; v6 = r[54]; v7 = r[63];
-        wave_sync();
-        SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
-        double2* w = buf + k1 * 72 + 9 * b;  // z[k1][b][c] at SP(64 k1 + 8 b + c)
-        w[0] = v0;
-        w[1] = cmul(v1, tw512(tw, 8 * b, sgn));
-        w[2] = cmul(v2, tw512(tw, 16 * b, sgn));
-        w[3] = cmul(v3, tw512(tw, 24 * b, sgn));
-        w[4] = cmul(v4, tw512(tw, 32 * b, sgn));
-        w[5] = cmul(v5, tw512(tw, 40 * b, sgn));
-        w[6] = cmul(v6, tw512(tw, 48 * b, sgn));
-        w[7] = cmul(v7, tw512(tw, 56 * b, sgn));
-    }
+}
+// pass 2: lane = (k1, b), in place
+__device__ __forceinline__ void fft512_pass2(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
+    double2 v0, v1, v2, v3, v4, v5, v6, v7;
+    const int k1 = lane >> 3, b = lane & 7;
+    const double2* r = buf + k1 * 72 + b;  // SP(64 k1 + 8 a + b) = 72 k1 + 9 a + b
+    v0 = r[0]; v1 = r[9]; v2 = r[18]; v3 = r[27]; v4 = r[36]; v5 = r[45]; v6 = r[54]; v7 = r[63];
     wave_sync();
-    // ---- pass 3: lane = (k1, c)
-    {
-        const int k1 = lane >> 3, c = lane & 7;
-        const double2* r = buf + k1 * 72 + c;
-        v0 = r[0]; v1 = r[9]; v2 = r[18]; v3 = r[27]; v4 = r[36]; v5 = r[45]; v6 = r[54]; v7 = r[63];
-        wave_sync();
-        SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
-        double2* w = buf + k1 + 9 * c;  // SP(k1 + 8 c + 64 d) = k1 + 9 c + 72 d
-        w[0] = v0; w[72] = v1; w[144] = v2; w[216] = v3; w[288] = v4; w[360] = v5; w[432] = v6; w[504] = v7;
-    }
+    SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+    double2* w = buf + k1 * 72 + 9 * b;  // z[k1][b][c] at SP(64 k1 + 8 b + c)
+    w[0] = v0;
+    w[1] = cmul(v1, tw512(tw, 8 * b, sgn));
+    w[2] = cmul(v2, tw512(tw, 16 * b, sgn));
+    w[3] = cmul(v3, tw512(tw, 24 * b, sgn));
+    w[4] = cmul(v4, tw512(tw, 32 * b, sgn));
+    w[5] = cmul(v5, tw512(tw, 40 * b, sgn));
+    w[6] = cmul(v6, tw512(tw, 48 * b, sgn));
+    w[7] = cmul(v7, tw512(tw, 56 * b, sgn));
+    wave_sync();
+}
+// pass 3: lane = (k1, c) = (lane >> 3, lane & 7); out[d] = X[k1 + 8 c + 64 d].  Ends with the fence that lets the caller
+// overwrite the buffer.
+__device__ __forceinline__ void fft512_pass3(const double2* buf, int lane, double sgn, double2 (&out)[8]) {
+    const int k1 = lane >> 3, c = lane & 7;
+    const double2* r = buf + k1 * 72 + c;
+    double2 v0 = r[0], v1 = r[9], v2 = r[18], v3 = r[27], v4 = r[36], v5 = r[45], v6 = r[54], v7 = r[63];
+    wave_sync();
+    SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+    out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3; out[4] = v4; out[5] = v5; out[6] = v6; out[7] = v7;
+}
+
+__device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
+    const double2* p1 = buf + SP(lane);
+    fft512_pass1(buf, tw, lane, sgn, p1[0], p1[72], p1[144], p1[216], p1[288], p1[360], p1[432], p1[504]);
+    fft512_pass2(buf, tw, lane, sgn);
+    double2 v[8];
+    fft512_pass3(buf, lane, sgn, v);
+    double2* w = buf + (lane >> 3) + 9 * (lane & 7);  // SP(k1 + 8 c + 64 d) = k1 + 9 c + 72 d
+    w[0] = v[0]; w[72] = v[1]; w[144] = v[2]; w[216] = v[3]; w[288] = v[4]; w[360] = v[5]; w[432] = v[6]; w[504] = v[7];
     wave_sync();
 }
 

@@ -162,10 +162,16 @@ __device__ __forceinline__ void lane_const_init(const TabLds& tb, int lane, Lane
 
 // MODE 0: full forward (writes the spectrum / mel cache when t.spec_cache is set); MODE 1: backward with a cache:
 // only the sample statistics are recomputed, spectrum and mel energies are read back (no FFT, no mel/DCT loops).
-template <int MODE>
+// WANT_SPEC (the backward kernels): Xk[i] = the spectrum at bin lane + 64 i, in registers.
+// The transform's input and output stay out of the 16-byte LDS traffic where they can: the windowed frame is real and
+// zero beyond sample 399, so pass 1 takes it as 7 floats per lane (from L.samp, rewritten in place) instead of 8 complex
+// doubles; pass 3 leaves bins k1 + 8 c + 64 d (d < 4: the 256 bins that exist) in registers, and power, spectrum cache and
+// -- for the backward -- the gradient spectrum are computed from there without writing the transform back.
+template <int MODE, bool WANT_SPEC>
 __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, const LaneConst& lc, FrameLds& L,
                                               const float (&raw)[7], int F, int b, int f, bool active, float scale,
-                                              const sg_dither& dz, int lane, FrameState& st, float& cep_out) {
+                                              const sg_dither& dz, int lane, FrameState& st, float& cep_out,
+                                              double2 (&Xk)[4]) {
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -192,45 +198,65 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         if (n < kWin) {
             st.s[i] -= mean;
             e += st.s[i] * st.s[i];
-            L.samp[n] = st.s[i];
+            if (MODE == 0) L.samp[n] = st.s[i];
         }
     }
     st.energy = wave_sum(e);
-    wave_sync();
     const size_t gfi = (size_t)b * F + f;
     if (MODE == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = lane + 64 * i;
-            const float2 c = t.spec_cache[gfi * 256 + k];
-            L.spec[SP(k)] = make_double2((double)c.x, (double)c.y);
+            const float2 c = t.spec_cache[gfi * 256 + lane + 64 * i];
+            Xk[i] = make_double2((double)c.x, (double)c.y);
         }
         if (lane < 32) L.mel[lane] = t.mel_cache[gfi * 32 + lane];
         wave_sync();
         cep_out = 0.f;
         return;
     }
-    // pre-emphasis (replicate pad on the left), povey window, zero-padded into the FFT buffer
+    wave_sync();
+    // pre-emphasis (replicate pad on the left), povey window: the windowed frame replaces the samples in L.samp (every lane
+    // reads its left neighbours before any lane writes: the LDS runs a wave's instructions in order)
+    float w[7];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 7; ++i) {
         const int n = lane + 64 * i;
-        float w = 0.f;
-        if (n < kWin) {
-            const float prev = L.samp[n > 0 ? n - 1 : 0];
-            w = (st.s[i < 7 ? i : 6] - 0.97f * prev) * tb.window[n];
-        }
-        L.spec[SP(n)] = make_double2((double)w, 0.0);
+        w[i] = 0.f;
+        if (n < kWin) w[i] = (st.s[i] - 0.97f * L.samp[n > 0 ? n - 1 : 0]) * tb.window[n];
     }
     wave_sync();
-    if (!(t.ablate & 1)) fft512_r8(L.spec, tb.tw, lane, -1.0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = lane + 64 * i;
-        const double2 c = L.spec[SP(k)];
-        L.power[k] = (float)(c.x * c.x + c.y * c.y);
-        if (t.spec_cache) t.spec_cache[gfi * 256 + k] = make_float2((float)c.x, (float)c.y);
+    for (int i = 0; i < 7; ++i) L.samp[lane + 64 * i] = w[i];  // samples 400 .. 447 zero, 448 .. 511 are not read
+    wave_sync();
+    double2 out[8];
+    if (!(t.ablate & 1)) {
+        const double2 z = make_double2(0.0, 0.0);
+        fft512_pass1(L.spec, tb.tw, lane, -1.0, make_double2((double)L.samp[lane], 0.0), make_double2((double)L.samp[lane + 64], 0.0),
+                     make_double2((double)L.samp[lane + 128], 0.0), make_double2((double)L.samp[lane + 192], 0.0),
+                     make_double2((double)L.samp[lane + 256], 0.0), make_double2((double)L.samp[lane + 320], 0.0),
+                     make_double2((double)L.samp[lane + 384], 0.0), z);
+        fft512_pass2(L.spec, tb.tw, lane, -1.0);
+        fft512_pass3(L.spec, lane, -1.0, out);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) out[d] = make_double2(0.0, 0.0);
+    }
+    {
+        const int kb = (lane >> 3) + 8 * (lane & 7);  // this lane's bins after pass 3: kb + 64 d
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int k = kb + 64 * d;
+            const double2 c = out[d];
+            L.power[k] = (float)(c.x * c.x + c.y * c.y);
+            if (t.spec_cache) t.spec_cache[gfi * 256 + k] = make_float2((float)c.x, (float)c.y);
+            if (WANT_SPEC) L.spec[SP(k)] = c;  // (the transform's buffer is free again: pass 3 ended with a fence)
+        }
     }
     wave_sync();
+    if (WANT_SPEC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xk[i] = L.spec[SP(lane + 64 * i)];
+    }
     // 30 triangular mel filters, two lanes per filter (each sums half of the filter's bins); the weight
     // of bin k in filter m is bin_w0[k] if m is the lower of the two filters covering k, else bin_w1[k]
     if (!(t.ablate & 2)) {
@@ -280,7 +306,8 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
         load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
         FrameState st;
         float cep;
-        frame_forward<0>(t, tb, lc, L, raw, F, b, f, active, scale, dz, lane, st, cep);
+        double2 Xk[4];
+        frame_forward<0, false>(t, tb, lc, L, raw, F, b, f, active, scale, dz, lane, st, cep, Xk);
         if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
@@ -329,7 +356,8 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
         const int fa = active ? f : 0;
         FrameState st;
         float cep;
-        frame_forward<CACHED ? 1 : 0>(t, tb, lc, L, raw, F, b, fa, active, scale, dz, lane, st, cep);
+        double2 Xk[4];
+        frame_forward<CACHED ? 1 : 0, true>(t, tb, lc, L, raw, F, b, fa, active, scale, dz, lane, st, cep, Xk);
         // ---- cepstra -> log-mel
         float dc = 0.f;
         if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];
@@ -348,28 +376,38 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             L.lmel[lane] = dm;  // d loss / d mel energy (entries 30,31 = 0)
         }
         wave_sync();
-        // ---- mel -> power -> spectrum gradient G[k] = 2 X[k] dP[k], in place, bins 256..511 zero
+        // ---- mel -> power -> spectrum gradient G[k] = 2 X[k] dP[k] at this lane's bins k = lane + 64 i, i < 4 -- which are
+        //      exactly pass 1's inputs x[n2 + 64 j] of lane n2 (j >= 4: bins 256..511, zero): the gradient spectrum goes
+        //      into the inverse transform from registers.  Pass 3 leaves samples k1 + 8 c + 64 d in registers; their real
+        //      part times the window goes straight to L.samp (samples 0..399).
+        double2 g[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = lane + 64 * i;
-            double2 g = make_double2(0.0, 0.0);
-            if (k < 256) {
-                const int m0 = bin_m0[i & 3];
-                if (m0 >= 0) {
-                    const double dp = 2.0 * (double)(L.lmel[m0] * bin_w0[i & 3] + L.lmel[m0 + 1] * bin_w1[i & 3]);
-                    const double2 c = L.spec[SP(k)];
-                    g = make_double2(c.x * dp, c.y * dp);
-                }
+        for (int i = 0; i < 4; ++i) {
+            g[i] = make_double2(0.0, 0.0);
+            const int m0 = bin_m0[i];
+            if (m0 >= 0) {
+                const double dp = 2.0 * (double)(L.lmel[m0] * bin_w0[i] + L.lmel[m0 + 1] * bin_w1[i]);
+                g[i] = make_double2(Xk[i].x * dp, Xk[i].y * dp);
             }
-            L.spec[SP(k)] = g;
         }
-        wave_sync();
-        if (!(t.ablate & 1)) fft512_r8(L.spec, tb.tw, lane, 1.0);
-        // ---- window, pre-emphasis, energy, DC removal
+        {
+            double2 out[8];
+            if (!(t.ablate & 1)) {
+                const double2 z = make_double2(0.0, 0.0);
+                fft512_pass1(L.spec, tb.tw, lane, 1.0, g[0], g[1], g[2], g[3], z, z, z, z);
+                fft512_pass2(L.spec, tb.tw, lane, 1.0);
+                fft512_pass3(L.spec, lane, 1.0, out);
+            } else {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int n = lane + 64 * i;
-            if (n < kWin) L.samp[n] = (float)L.spec[SP(n)].x * tb.window[n];
+                for (int d = 0; d < 8; ++d) out[d] = make_double2(0.0, 0.0);
+            }
+            // ---- window, pre-emphasis, energy, DC removal
+            const int nb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+            for (int d = 0; d < 7; ++d) {
+                const int n = nb + 64 * d;
+                if (n < kWin) L.samp[n] = (float)out[d].x * tb.window[n];
+            }
         }
         wave_sync();
         float ds[7];
