@@ -108,6 +108,60 @@ __device__ __forceinline__ void fft512_pass3(const double2* buf, int lane, doubl
     out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3; out[4] = v4; out[5] = v5; out[6] = v6; out[7] = v7;
 }
 
+// The same passes 1 and 2 with their twiddles in dedicated tables (PMC, MFCC forward: of 240 bank-conflict cycles per
+// frame 152 came from the transform, and the butterfly exchanges are conflict-free -- it was the GATHER of twiddles from the
+// half-circle table: pass 2 reads tw[8 b c], eight distinct addresses per 16-lane group all on one or two 16-byte slots of
+// the 256-byte bank row, 4- to 8-way, ~130 extra LDS cycles per transform):
+//   tw1[(j - 1) * 64 + lane] = W512^(j lane), j = 1..7   (lane-linear reads: conflict-free)
+//   tw2[9 b + c]             = W64^(b c),     b, c < 8   (row pad 1: the eight b of a lane group fall on eight slots)
+// both for the forward sign; sgn = +1 conjugates.
+constexpr int kFftTw1 = 7 * 64, kFftTw2 = 72;
+__device__ __forceinline__ double2 tw_sgn(double2 w, double sgn) { return make_double2(w.x, -sgn * w.y); }
+__device__ __forceinline__ void fft512_fill_tables(const double2* __restrict__ half_circle, double2* tw1, double2* tw2) {
+    auto w512 = [&](int m) {
+        const double2 w = half_circle[m & 255];
+        return (m & 256) ? make_double2(-w.x, -w.y) : w;
+    };
+    for (int i = threadIdx.x; i < kFftTw1; i += blockDim.x) tw1[i] = w512((i / 64 + 1) * (i % 64));
+    for (int i = threadIdx.x; i < kFftTw2; i += blockDim.x) {
+        const int b = i / 9, c = i - 9 * b;
+        tw2[i] = c < 8 ? w512(8 * b * c) : make_double2(0.0, 0.0);
+    }
+}
+__device__ __forceinline__ void fft512_pass1_t(double2* buf, const double2* __restrict__ tw1, int lane, double sgn, double2 v0,
+                                               double2 v1, double2 v2, double2 v3, double2 v4, double2 v5, double2 v6, double2 v7) {
+    double2* p1 = buf + SP(lane);
+    SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+    p1[0] = v0;
+    p1[72] = cmul(v1, tw_sgn(tw1[lane], sgn));
+    p1[144] = cmul(v2, tw_sgn(tw1[64 + lane], sgn));
+    p1[216] = cmul(v3, tw_sgn(tw1[128 + lane], sgn));
+    p1[288] = cmul(v4, tw_sgn(tw1[192 + lane], sgn));
+    p1[360] = cmul(v5, tw_sgn(tw1[256 + lane], sgn));
+    p1[432] = cmul(v6, tw_sgn(tw1[320 + lane], sgn));
+    p1[504] = cmul(v7, tw_sgn(tw1[384 + lane], sgn));
+    wave_sync();
+}
+__device__ __forceinline__ void fft512_pass2_t(double2* buf, const double2* __restrict__ tw2, int lane, double sgn) {
+    double2 v0, v1, v2, v3, v4, v5, v6, v7;
+    const int k1 = lane >> 3, b = lane & 7;
+    const double2* r = buf + k1 * 72 + b;
+    v0 = r[0]; v1 = r[9]; v2 = r[18]; v3 = r[27]; v4 = r[36]; v5 = r[45]; v6 = r[54]; v7 = r[63];
+    wave_sync();
+    SG_DFT8(v0, v1, v2, v3, v4, v5, v6, v7, sgn)
+    double2* w = buf + k1 * 72 + 9 * b;
+    const double2* t2 = tw2 + 9 * b;
+    w[0] = v0;
+    w[1] = cmul(v1, tw_sgn(t2[1], sgn));
+    w[2] = cmul(v2, tw_sgn(t2[2], sgn));
+    w[3] = cmul(v3, tw_sgn(t2[3], sgn));
+    w[4] = cmul(v4, tw_sgn(t2[4], sgn));
+    w[5] = cmul(v5, tw_sgn(t2[5], sgn));
+    w[6] = cmul(v6, tw_sgn(t2[6], sgn));
+    w[7] = cmul(v7, tw_sgn(t2[7], sgn));
+    wave_sync();
+}
+
 __device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
     const double2* p1 = buf + SP(lane);
     fft512_pass1(buf, tw, lane, sgn, p1[0], p1[72], p1[144], p1[216], p1[288], p1[360], p1[432], p1[504]);

@@ -44,7 +44,8 @@ struct FrameLds {
 // Constant tables staged once per block into LDS: every per-frame table access was a dependent global
 // load (L1/L2 hit, but ~0.3 us of latency each with only 2 waves per SIMD to hide it).
 struct TabLds {
-    double2 tw[256];
+    double2 tw1[kFftTw1];  // pass-1 / pass-2 twiddles as the lanes read them (fft512.h)
+    double2 tw2[kFftTw2];
     float window[kWin];
     float dct[kMel * kCep];
     float lifter[32];
@@ -56,8 +57,8 @@ struct TabLds {
 };
 
 __device__ __forceinline__ void stage_tables(const MfccTables& t, TabLds& tb) {
+    fft512_fill_tables(t.twiddle, tb.tw1, tb.tw2);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        tb.tw[i] = t.twiddle[i];
         tb.bin_m0[i] = t.bin_m0[i];
         tb.bin_w0[i] = t.bin_w0[i];
         tb.bin_w1[i] = t.bin_w1[i];
@@ -231,11 +232,11 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
     double2 out[8];
     if (!(t.ablate & 1)) {
         const double2 z = make_double2(0.0, 0.0);
-        fft512_pass1(L.spec, tb.tw, lane, -1.0, make_double2((double)L.samp[lane], 0.0), make_double2((double)L.samp[lane + 64], 0.0),
+        fft512_pass1_t(L.spec, tb.tw1, lane, -1.0, make_double2((double)L.samp[lane], 0.0), make_double2((double)L.samp[lane + 64], 0.0),
                      make_double2((double)L.samp[lane + 128], 0.0), make_double2((double)L.samp[lane + 192], 0.0),
                      make_double2((double)L.samp[lane + 256], 0.0), make_double2((double)L.samp[lane + 320], 0.0),
                      make_double2((double)L.samp[lane + 384], 0.0), z);
-        fft512_pass2(L.spec, tb.tw, lane, -1.0);
+        fft512_pass2_t(L.spec, tb.tw2, lane, -1.0);
         fft512_pass3(L.spec, lane, -1.0, out);
     } else {
 #pragma unroll
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             double2 out[8];
             if (!(t.ablate & 1)) {
                 const double2 z = make_double2(0.0, 0.0);
-                fft512_pass1(L.spec, tb.tw, lane, 1.0, g[0], g[1], g[2], g[3], z, z, z, z);
-                fft512_pass2(L.spec, tb.tw, lane, 1.0);
+                fft512_pass1_t(L.spec, tb.tw1, lane, 1.0, g[0], g[1], g[2], g[3], z, z, z, z);
+                fft512_pass2_t(L.spec, tb.tw2, lane, 1.0);
                 fft512_pass3(L.spec, lane, 1.0, out);
             } else {
 #pragma unroll
