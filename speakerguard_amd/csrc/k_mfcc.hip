@@ -199,7 +199,6 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         if (n < kWin) {
             st.s[i] -= mean;
             e += st.s[i] * st.s[i];
-            if (MODE == 0) L.samp[n] = st.s[i];
         }
     }
     st.energy = wave_sum(e);
@@ -215,27 +214,24 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         cep_out = 0.f;
         return;
     }
-    wave_sync();
-    // pre-emphasis (replicate pad on the left), povey window: the windowed frame replaces the samples in L.samp (every lane
-    // reads its left neighbours before any lane writes: the LDS runs a wave's instructions in order)
+    // pre-emphasis (replicate pad on the left), povey window -- in registers: sample n - 1 of n = lane + 64 i is the left
+    // neighbour lane's s[i] (a whole-wave DPP shift), for lane 0 lane 63's s[i - 1] (sample 0: itself); and the windowed
+    // values w[i] ARE pass 1's inputs x[lane + 64 j] of this lane: no LDS round trip between the samples and the transform
     float w[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int n = lane + 64 * i;
-        w[i] = 0.f;
-        if (n < kWin) w[i] = (st.s[i] - 0.97f * L.samp[n > 0 ? n - 1 : 0]) * tb.window[n];
+        const float edge = i > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.s[i - 1]), 63)) : st.s[0];
+        const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, st.s[i]),
+                                                                                  0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+        w[i] = n < kWin ? (st.s[i] - 0.97f * prev) * tb.window[n] : 0.f;
     }
-    wave_sync();
-#pragma unroll
-    for (int i = 0; i < 7; ++i) L.samp[lane + 64 * i] = w[i];  // samples 400 .. 447 zero, 448 .. 511 are not read
-    wave_sync();
     double2 out[8];
     if (!(t.ablate & 1)) {
         const double2 z = make_double2(0.0, 0.0);
-        fft512_pass1_t(L.spec, tb.tw1, lane, -1.0, make_double2((double)L.samp[lane], 0.0), make_double2((double)L.samp[lane + 64], 0.0),
-                     make_double2((double)L.samp[lane + 128], 0.0), make_double2((double)L.samp[lane + 192], 0.0),
-                     make_double2((double)L.samp[lane + 256], 0.0), make_double2((double)L.samp[lane + 320], 0.0),
-                     make_double2((double)L.samp[lane + 384], 0.0), z);
+        fft512_pass1_t(L.spec, tb.tw1, lane, -1.0, make_double2((double)w[0], 0.0), make_double2((double)w[1], 0.0),
+                       make_double2((double)w[2], 0.0), make_double2((double)w[3], 0.0), make_double2((double)w[4], 0.0),
+                       make_double2((double)w[5], 0.0), make_double2((double)w[6], 0.0), z);
         fft512_pass2_t(L.spec, tb.tw2, lane, -1.0);
         fft512_pass3(L.spec, lane, -1.0, out);
     } else {
