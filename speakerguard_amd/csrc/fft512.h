@@ -162,6 +162,19 @@ __device__ __forceinline__ void fft512_pass2_t(double2* buf, const double2* __re
     wave_sync();
 }
 
+// the full in-place transform with the twiddle tables
+__device__ __forceinline__ void fft512_r8_t(double2* buf, const double2* __restrict__ tw1, const double2* __restrict__ tw2, int lane,
+                                            double sgn) {
+    const double2* p1 = buf + SP(lane);
+    fft512_pass1_t(buf, tw1, lane, sgn, p1[0], p1[72], p1[144], p1[216], p1[288], p1[360], p1[432], p1[504]);
+    fft512_pass2_t(buf, tw2, lane, sgn);
+    double2 v[8];
+    fft512_pass3(buf, lane, sgn, v);
+    double2* w = buf + (lane >> 3) + 9 * (lane & 7);  // SP(k1 + 8 c + 64 d) = k1 + 9 c + 72 d
+    w[0] = v[0]; w[72] = v[1]; w[144] = v[2]; w[216] = v[3]; w[288] = v[4]; w[360] = v[5]; w[432] = v[6]; w[504] = v[7];
+    wave_sync();
+}
+
 __device__ __forceinline__ void fft512_r8(double2* buf, const double2* __restrict__ tw, int lane, double sgn) {
     const double2* p1 = buf + SP(lane);
     fft512_pass1(buf, tw, lane, sgn, p1[0], p1[72], p1[144], p1[216], p1[288], p1[360], p1[432], p1[504]);

@@ -115,8 +115,8 @@ __device__ __forceinline__ void an_split(double2 zk, double2 zr, double2 w, doub
 // packed spectrum Z of the frame into L.spec (element i at SP(i)), power of bins 0..512 into L.power, mel into L.mel
 // WITH_MEL = false: only the packed spectrum (the cached backward takes the mel energies from the forward pass)
 template <bool WITH_MEL>
-__device__ __forceinline__ void an_frame_forward(const double2* tw512, AnFrameLds& L, const AnLaneConst& lc, const AnRaw& r,
-                                                 float scale, int lane) {
+__device__ __forceinline__ void an_frame_forward(const double2* tw1, const double2* tw2, AnFrameLds& L, const AnLaneConst& lc,
+                                                 const AnRaw& r, float scale, int lane) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float v0 = (r.b[2 * i] - 0.97f * r.a[2 * i]) * scale * lc.win[2 * i];
@@ -124,7 +124,7 @@ __device__ __forceinline__ void an_frame_forward(const double2* tw512, AnFrameLd
         L.spec[SP(lane + 64 * i)] = make_double2((double)v0, (double)v1);
     }
     wave_sync();
-    fft512_r8(L.spec, tw512, lane, -1.0);
+    fft512_r8_t(L.spec, tw1, tw2, lane, -1.0);
     if (!WITH_MEL) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -153,16 +153,20 @@ __device__ __forceinline__ void an_frame_forward(const double2* tw512, AnFrameLd
     wave_sync();
 }
 
-__device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) tw512[i] = t.twiddle[2 * i];  // W512^i = W1024^(2 i)
+// the 512-point transform's twiddles as its lanes read them (fft512.h: conflict-free tables), from the half circle of
+// W512^i = W1024^(2 i) staged in tw512
+__device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512, double2* tw1, double2* tw2) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) tw512[i] = t.twiddle[2 * i];
+    __syncthreads();
+    fft512_fill_tables(tw512, tw1, tw2);
     __syncthreads();
 }
 
 __global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p, float* __restrict__ feats) {
     __shared__ AnFrameLds lds[kAnWavesPerBlock];
-    __shared__ double2 tw512[256];
-    an_stage_tw(t, tw512);
+    __shared__ double2 tw512[256], tw1[kFftTw1], tw2[kFftTw2];
+    an_stage_tw(t, tw512, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLds& L = lds[wid];
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const
     AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
     for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
         an_load_frame(x, T, F, gf, total, lane, cur);
-        an_frame_forward<true>(tw512, L, lc, cur, scale, lane);
+        an_frame_forward<true>(tw1, tw2, L, lc, cur, scale, lane);
         if (lane < kAnMel) {
             feats[(size_t)gf * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
             if (t.mel_cache) t.mel_cache[(size_t)gf * kAnMel + lane] = L.mel[lane];
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
                                                             const float* __restrict__ scale_p,
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
     __shared__ AnFrameLds lds[kAnWavesPerBlock];
-    __shared__ double2 tw512[256];
-    an_stage_tw(t, tw512);
+    __shared__ double2 tw512[256], tw1[kFftTw1], tw2[kFftTw2];
+    an_stage_tw(t, tw512, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLds& L = lds[wid];
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
     AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
     for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
         an_load_frame(x, T, F, gf, total, lane, cur);
-        an_frame_forward<!CACHED>(tw512, L, lc, cur, scale, lane);
+        an_frame_forward<!CACHED>(tw1, tw2, L, lc, cur, scale, lane);
         if (lane < 34) {
             float dm = 0.f;
             if (lane < kAnMel) {
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
             L.spec[SP(256)] = make_double2(d0.x + d1.x, d0.y + d1.y);
         }
         wave_sync();
-        fft512_r8(L.spec, tw512, lane, 1.0);
+        fft512_r8_t(L.spec, tw1, tw2, lane, 1.0);
         float* out = dframes + (size_t)gf * kAnWin;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
