@@ -257,13 +257,15 @@ struct PassDims {
 };
 
 // waveform / features -> padded CMVN features in ws.feats
-int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz, hipStream_t s) {
+// want_grad: a backward of this pass follows (the forward leaves its spectra and mel energies for it: 39 MB at 64 utterances,
+// not written by forward-only calls -- decisions, NES / FAKEBOB queries, the last pass of an attack)
+int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const sg_dither* dz, bool want_grad, hipStream_t s) {
     Workspace& w = ctx->ws;
     if (flag == SG_FLAG_WAV) {
         if (!d.keep_scale) SG_HIP(launch_input_scale(x, (int64_t)(d.Bu > 0 ? d.Bu : d.B) * d.T, ctx->range_scratch, w.scale, 0, s));
         MfccTables tab = ctx->tab;
-        tab.spec_cache = w.spec_cache;  // the backward of this pass starts from the stored spectrum
-        tab.mel_cache = w.mel_cache;
+        tab.spec_cache = want_grad ? w.spec_cache : nullptr;  // the backward of this pass starts from the stored spectrum
+        tab.mel_cache = want_grad ? w.mel_cache : nullptr;
         tab.rep_utts = d.Bu;
         SG_STAGE(SG_STAGE_MFCC_FWD, launch_mfcc_fwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
         SG_STAGE(SG_STAGE_CMVN_FWD, launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
@@ -719,7 +721,7 @@ int sg_xv_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, in
     if (rc) return rc;
     if (!x_dev) return fail(ctx, SG_ERR_ARG, "x is NULL");
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = run_frontend(ctx, x_dev, d, flag, dither, s))) return rc;
+    if ((rc = run_frontend(ctx, x_dev, d, flag, dither, false, s))) return rc;
     if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
     Workspace& w = ctx->ws;
     TailArgs t{};
@@ -752,7 +754,7 @@ int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     if (rc) return rc;
     if (!x_dev || !y_dev || !loss) return fail(ctx, SG_ERR_ARG, "x, y and loss are required");
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = run_frontend(ctx, x_dev, d, flag, dither, s))) return rc;
+    if ((rc = run_frontend(ctx, x_dev, d, flag, dither, grad_dev != nullptr, s))) return rc;
     if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
     Workspace& w = ctx->ws;
     TailArgs t{};
@@ -879,7 +881,7 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
             // every iterate is clamped into [lower, upper] within [-1, 1], so check_input_range takes the
             // same branch as for the start point: decide once
             d.keep_scale = it > 0 || g0 > 0;
-            if ((rc = run_frontend(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, s))) return rc;
+            if ((rc = run_frontend(ctx, x_adv_dev, d, SG_FLAG_WAV, &dz, !last, s))) return rc;
             if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
             TailArgs t{};
             t.fc1_part = w.fc1_part; t.nsplit = kFc1SplitK; t.B = d.B; t.m = &ctx->xv; t.y = w.y_rep; t.loss = p->loss;
