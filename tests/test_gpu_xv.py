@@ -1001,3 +1001,42 @@ def test_nes_and_fakebob_kernels(hip_model, dev):
     xx, gg = x.clone(), grad.clone()
     hip_model.fakebob_step(xx, gg, prev, lr, lower, upper, 0.9, -1)
     assert torch.equal(xx, want_x) and torch.equal(gg, mg)
+
+
+@pytest.mark.parametrize("D,n_spk", [(150, 7), (37, 3), (512, 10)])
+def test_backend_dimensions_not_multiples_of_four(dev, D, n_spk):
+    """LDA / PLDA dimension read from the model files (iv_plda.py:424): the tail kernel's device copies pad the matrix rows
+    to 16-byte multiples (its products use 16-byte column loads).  Scores and decisions from the waveform, and d loss / d raw
+    MFCC features of the SAME feature tensor, against the oracle, for dimensions that need the padding (150, 37) and for the
+    largest one the kernel admits (512).  (The gradient is compared at feature level on purpose: with these uncalibrated random
+    weights a 6e-5 difference between the two MFCC implementations flips a few ReLU units of some utterances and moves
+    d loss / d waveform by up to 3 % -- tests/tools/grad_sensitivity.py shows that the HIP chain fed the oracle's features, and
+    the HIP MFCC backward fed the oracle's feature gradient, each agree with the oracle to 1e-5.)"""
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.xv_plda import xv_plda
+    w = synth.make_xv_weights(seed=3, D=D, n_spk=n_spk, calibrated=False)
+    hip = xv_plda.from_weights(w, device=dev, dither=0.0)
+    om = XvPlda(w, faithful=False)
+    x = torch.from_numpy(synth.make_waveforms(3, 16000, seed=77))
+    y = torch.arange(3) % n_spk
+    dec, scores = hip.make_decision(x.to(dev))
+    with torch.no_grad():
+        odec, oscores = om.make_decision(x)
+        feats = om.compute_feat(x, 1)
+    sc = np.abs(oscores.numpy()).max()
+    np.testing.assert_allclose(scores.cpu().numpy(), oscores.numpy(), rtol=0, atol=2e-4 * sc + 1e-3)
+    assert dec.cpu().tolist() == odec.tolist()
+    fin = feats.clone().requires_grad_(True)
+    _, fsc = om.make_decision(fin, flag=1)
+    torch.nn.functional.cross_entropy(fsc, y, reduction="none").backward(torch.ones(3))
+    want = fin.grad.numpy()
+    _, hsc, _, grad = hip.loss_grad(feats.to(dev), y.to(dev), SEC4SR_CrossEntropy(), flag=1)
+    got = grad.cpu().numpy()
+    gs = np.abs(want).max()
+    assert gs > 0
+    np.testing.assert_allclose(hsc.cpu().numpy(), fsc.detach().numpy(), rtol=0, atol=2e-4 * sc + 1e-3)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * gs)
+    log("back-end D=%d, %d speakers: scores max err %.2e of %.1f; d loss / d raw feats max err / max %.2e" % (
+        D, n_spk, np.abs(scores.cpu().numpy() - oscores.numpy()).max(), sc, np.abs(got - want).max() / gs))
