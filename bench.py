@@ -14,13 +14,21 @@ Protocol: W untimed warm-up steps, then R timed attacks 
 barrier + device synchronise on both sides and timed as the MAX over ranks; `value` is computed from the MEDIAN attack,
 all samples are in the line.
 
+Every timed attack is the PRODUCT's call: ``speakerguard_amd.attack.PGD(model, ..., batch_size=64).attack(x, y)``
+(reference attack/PGD.py:40-79: input checks, epsilon box, one chunk -> the fused device loop, flags to the host), and
+for N > 1 ``speakerguard_amd.shard.ShardedAttack`` around it -- not a bench-private partition.
+
 N > 1, two partitions of the work, both measured in the same run:
   * ``--scaling weak`` (default, the line's `value`): every rank attacks its own batch of 64; no data-path collective,
     one RCCL all-gather of the per-utterance success flags at the end of the attack, inside the timed region;
-  * ``strong`` (the line's ``strong_scaling`` object; `value` with ``--scaling strong``): ONE batch of 64 cut into
+  * ``strong`` (the line's ``value_metric_partition`` / ``strong_scaling``; `value` with ``--scaling strong``): the
+    metric's own partition -- ONE batch of 64, ``ShardedAttack(PGD(batch_size=64)).attack(x64, y64)`` on every rank, i.e.
     contiguous shards of 64/N utterances (reference attack/PGD.py:62-73 chunks one batch; BASELINE.md section 3 "batch 64
-    sharded B/G per GPU"), same exchange.  On one GPU the shard sizes 32 / 16 / 8 are timed as well (``shard_points``):
-    what a rank of a 2 / 4 / 8-GPU strong-scaling run does.
+    sharded B/G per GPU"), flags all-gathered by the wrapper.  On one GPU the shard sizes 32 / 16 / 8 are timed as well
+    (``shard_points``): what a rank of a 2 / 4 / 8-GPU strong-scaling run does.
+
+``other_configs``: the other BASELINE.json configurations (configs[0], [2], [3], [4]) on this GPU, a few seconds in
+all (tools/config_bench.py); ``--no-other-configs`` skips them.
 """
 import argparse
 import json
@@ -196,6 +204,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="utterances per GPU (default: 64 weak, 64 / N strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-points", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -225,45 +234,57 @@ def main():
     dev = torch.device("cuda", local)
 
     from speakerguard_amd import synth
-    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.attack.PGD import PGD
     from speakerguard_amd.model.xv_plda import xv_plda
-    from speakerguard_amd.shard import shard_bounds
+    from speakerguard_amd.shard import ShardedAttack
 
     weights = synth.make_xv_weights(seed=0, D=200, n_spk=10)
     model = xv_plda.from_weights(weights, device=dev, dither=0.0)
-    spec = SEC4SR_CrossEntropy()
     sync = torch.cuda.synchronize
 
-    def make_attack(x_host, y_host):
-        """Resident inputs + the attack closure of one partition (flags all-gathered inside the timed region)."""
-        x = torch.from_numpy(np.ascontiguousarray(x_host)).to(dev)
+    def pgd(k):
+        """the product's attack object for K steps (PGD-K: K steps + the final forward-only pass)"""
+        return PGD(model, task="CSI", epsilon=EPS, step_size=STEP, max_iter=k, loss="Entropy", targeted=False,
+                   batch_size=GLOBAL_BATCH, EOT_size=1, EOT_batch_size=1, verbose=0)
+
+    def make_attack(x_host, y_host, sharded=False):
+        """Resident inputs + the attack closure of one partition.  sharded: ShardedAttack cuts the batch over the ranks and
+        all-gathers the flags itself; otherwise the rank attacks all of (x, y) and the flags are gathered here -- inside
+        the timed region either way."""
+        x = torch.from_numpy(np.ascontiguousarray(x_host)).to(dev).unsqueeze(1)
         y = torch.from_numpy(np.ascontiguousarray(y_host)).to(dev)
-        lower, upper = torch.clamp(x - EPS, min=-1), torch.clamp(x + EPS, max=1)
 
         def attack(k, gather=True):
-            out = model.pgd_run(x, y, lower, upper, spec, STEP, k, 1)
-            return out, (gather_flags(out[1], dist, world) if gather else out[1])
+            if sharded:
+                adv, succ = ShardedAttack(pgd(k), gather_audio=False).attack(x, y)
+                return adv, torch.tensor(succ, dtype=torch.uint8, device=dev)
+            adv, succ = pgd(k).attack(x, y)
+            flags = torch.tensor(succ, dtype=torch.uint8, device=dev)
+            return adv, (gather_flags(flags, dist, world) if gather else flags)
         return attack
 
     labels = np.arange(GLOBAL_BATCH) % 10
-    # weak: every rank its own 64 utterances; strong: rank r its contiguous shard of ONE batch of 64 (seed 1234)
+    # weak: every rank its own 64 utterances; strong: ONE batch of 64 (seed 1234), resident on every rank, cut by ShardedAttack
     weak_b = args.batch_per_gpu if (args.batch_per_gpu > 0 and args.scaling == "weak") else GLOBAL_BATCH
     weak = make_attack(synth.make_waveforms(weak_b, T_SAMPLES, seed=1234 + rank), np.arange(weak_b) % 10)
-    lo, hi = shard_bounds(GLOBAL_BATCH, world)[rank]
-    if args.batch_per_gpu > 0 and args.scaling == "strong":
-        lo, hi = 0, args.batch_per_gpu  # one GPU standing in for a rank of a 64 / B-GPU run
-    strong_b = hi - lo
-    if strong_b < 1 or (world > 1 and GLOBAL_BATCH % world):
-        sys.exit("bench.py: the strong-scaling partition needs 64 %% N == 0 (N = %d)" % world)
     global_x = synth.make_waveforms(GLOBAL_BATCH, T_SAMPLES, seed=1234)
-    strong = make_attack(global_x[lo:hi], labels[lo:hi])
+    if args.batch_per_gpu > 0 and args.scaling == "strong":
+        strong_b = args.batch_per_gpu  # one GPU standing in for a rank of a 64 / B-GPU run (no exchange)
+        strong = make_attack(global_x[:strong_b], labels[:strong_b])
+    else:
+        lo, hi = ShardedAttack(pgd(1)).bounds(GLOBAL_BATCH)[rank] if world > 1 else (0, GLOBAL_BATCH)
+        strong_b = hi - lo
+        if strong_b < 1:
+            sys.exit("bench.py: more ranks (%d) than utterances in the metric's batch" % world)
+        strong = make_attack(global_x, labels, sharded=world > 1)
 
     primary, primary_b = (weak, weak_b) if args.scaling == "weak" else (strong, strong_b)
     (out, flags), samples = timed_reps(primary, args.steps, args.warmup, args.reps, dist, sync, dev)
     prim = summarise(samples, args.steps)
     dt = prim["ms_per_step"] * 1e-3 * args.steps
     # a "step" of the metric is a batch-64 step: weak = N of them per time step of the job, strong = one
-    jobs_per_step = world * primary_b / GLOBAL_BATCH if args.scaling == "weak" else world * strong_b / GLOBAL_BATCH
+    strong_jobs = strong_b / GLOBAL_BATCH if args.batch_per_gpu > 0 else 1.0  # ShardedAttack: the ranks share ONE batch of 64
+    jobs_per_step = world * primary_b / GLOBAL_BATCH if args.scaling == "weak" else strong_jobs
     steps_per_s = jobs_per_step * args.steps / dt
 
     # ---- the other partition, same run (N > 1), or the per-rank shard sizes of 2 / 4 / 8 GPUs (N = 1)
@@ -272,11 +293,12 @@ def main():
         sec, sec_b = (strong, strong_b) if args.scaling == "weak" else (weak, weak_b)
         (_, sflags), ssamples = timed_reps(sec, args.steps, min(args.warmup, 2), 3, dist, sync, dev)
         s = summarise(ssamples, args.steps)
-        mult = 1.0 if args.scaling == "weak" else world * sec_b / GLOBAL_BATCH
+        mult = strong_jobs if args.scaling == "weak" else world * sec_b / GLOBAL_BATCH
         other = dict(s, scaling="strong" if args.scaling == "weak" else "weak", batch_per_gpu=sec_b,
                      value=mult * 1e3 / s["ms_per_step"], unit="steps/s", success_count=int(sflags.sum().item()),
-                     note="one batch of 64 cut into contiguous shards of 64 / N utterances (attack/PGD.py:62-73), flags all-gathered "
-                          "inside the timed region" if args.scaling == "weak" else "every rank its own batch")
+                     note="ShardedAttack(PGD(batch_size=64)).attack(x64, y64): one batch of 64 cut into contiguous shards of 64 / N "
+                          "utterances (attack/PGD.py:62-73), flags all-gathered inside the timed region" if args.scaling == "weak"
+                          else "every rank its own batch")
     shard_points = None
     if world == 1 and not args.no_shard_points:
         shard_points = []
@@ -350,13 +372,31 @@ def main():
             "success_count": int(flags.sum().item()),
             "roofline": roofline,
         }
+        # the metric's own partition (GPU-N = the batch of 64 cut B/N per GPU), next to `value`
+        if args.scaling == "strong" or world == 1:
+            line["value_metric_partition"] = steps_per_s
+        elif other is not None:
+            line["value_metric_partition"] = other["value"]
+        line["value_metric_partition_note"] = ("steps/s of ONE batch of 64 cut over the %d GPUs by the product's ShardedAttack (strong "
+                                               "scaling); `value` is %s" % (world, "the same number" if (args.scaling == "strong" or world == 1)
+                                                                            else "weak scaling: every rank its own batch of 64"))
         if other is not None:
             line["strong_scaling" if args.scaling == "weak" else "weak_scaling"] = other
         if shard_points is not None:
             line["shard_points"] = shard_points
+        if world == 1 and not args.no_other_configs:
+            import contextlib
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import config_bench
+            with contextlib.redirect_stdout(sys.stderr):  # the attack classes print like the reference's; the line stays alone
+                t0 = time.perf_counter()
+                line["other_configs"] = config_bench.measure(dev, reps=3, xv_weights=weights)
+                line["other_configs"]["seconds_spent"] = time.perf_counter() - t0
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, gpu_model=model)
             line["gpu_vs_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
+        order = ["metric", "value", "value_metric_partition"]
+        line = {**{k: line[k] for k in order if k in line}, **{k: v for k, v in line.items() if k not in order}}
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -114,14 +114,21 @@ typedef struct sg_loss_spec {
 
 /* Dither policy for the MFCC front-end (xv_plda.py:119 hard-codes dither=1.0 from the global
  * RNG).  dither == 0 disables it.  Otherwise the noise is kaldi's sqrt(-2 ln u) cos(2 pi u) with
- * u from a counter-based generator keyed by (seed, utterance index + index_base, frame, sample),
- * so results do not depend on how a batch is sharded over GPUs.  noise_dev, when non-NULL, is an
- * explicit (B,F,400) tensor that is added instead (parity tests). */
+ * u from a counter-based generator keyed by (key, utterance, frame, sample), where for row b of the call
+ *     g = row_base + b,  repeat = rep_rows > 0 ? g / rep_rows : 0,  key = seed + repeat * 0xC2B2AE3D27D4EB4F,
+ *     utterance = index_base + (g - repeat * rep_rows)
+ * i.e. index_base is the GLOBAL index of the first utterance (times the rows an utterance contributes to the call),
+ * row_base the position of row 0 inside the full call this one is a slice of, and rep_rows > 0 says that the full
+ * call's rows are EOT repeats of rep_rows rows (adaptive_attack/EOT.py:29 `x_batch.repeat(EOT_batch_size, 1, 1)`):
+ * the noise an utterance sees does not depend on how a batch is chunked or sharded over GPUs.  noise_dev, when
+ * non-NULL, is an explicit (B,F,400) tensor that is added instead (parity tests). */
 typedef struct sg_dither {
     float dither;
     uint64_t seed;
     int64_t index_base;
     const float* noise_dev;
+    int64_t row_base;
+    int32_t rep_rows;
 } sg_dither;
 
 /* ---- per-stage entry points (parity tests; also what model.compute_feat etc. call) --------- */
@@ -298,11 +305,14 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
 int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t iters,
                      float* ms_per_launch, double* flops, int32_t* tile_rows, void* stream);
 
-/* Stage trace of the x-vector pass sequences (what rocprofv3 --kernel-trace shows, from inside the process).  The
+/* Stage trace of the pass sequences (what rocprofv3 --kernel-trace shows, from inside the process).  The
  * reference has no counterpart: its only timing is a time.time() per training batch (adver_train.py:185,237); this
  * is the measurement hook SURVEY.md section 5 asks for "around the C-ABI step call".
- * Between sg_trace_begin and sg_trace_end every launch of sg_xv_forward / sg_xv_loss_grad / sg_xv_pgd_run is bracketed
- * by a pair of HIP events on the launch stream, up to max_records launches (further launches are not recorded).
+ * Between sg_trace_begin and sg_trace_end every launch of sg_xv_forward / sg_xv_loss_grad / sg_xv_pgd_run and of
+ * sg_an_forward / sg_an_loss_grad / sg_an_pgd_run / sg_an_pgd_run_feco (tags 30..) is bracketed by a pair of HIP events
+ * on the launch stream, up to max_records launches (further launches are not recorded).  The per-stage entry points
+ * (sg_xv_mfcc, sg_an_logmel, sg_feco_*, the attack-state updates) are not traced.  An event record that fails drops
+ * its launch record, and sg_trace_end then returns SG_ERR_HIP with the count in sg_last_error.
  * sg_trace_end waits for the last recorded event, writes tag and elapsed milliseconds of each record in launch order
  * (at most `capacity`), the number of records to *n_out, and switches the trace off.  Tags: +l / -l = forward /
  * data-gradient contraction of TDNN layer l (1..5), others below.  Event records cost a few microseconds between
@@ -317,6 +327,21 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
 #define SG_STAGE_CMVN_BWD 17
 #define SG_STAGE_MFCC_BWD 18
 #define SG_STAGE_OVERLAP_ADD 19
+/* AudioNet: 30 + l / 40 + l = forward / data-gradient contraction of conv block l (0..6 = conv2..conv8) */
+#define SG_STAGE_AN_LOGMEL_FWD 20
+#define SG_STAGE_AN_PREFILTER_FWD 21
+#define SG_STAGE_AN_POOL_FWD 22
+#define SG_STAGE_AN_TAIL 23
+#define SG_STAGE_AN_POOL_BWD 24
+#define SG_STAGE_AN_PREFILTER_BWD 25
+#define SG_STAGE_AN_LOGMEL_BWD 26
+#define SG_STAGE_AN_OVERLAP_ADD 27
+#define SG_STAGE_AN_FECO_FWD 28
+#define SG_STAGE_AN_FECO_BWD 29
+#define SG_STAGE_AN_CONV_FWD 30
+#define SG_STAGE_AN_CONV_BWD 40
+#define SG_STAGE_AN_FUSED_FWD 50 /* the whole conv stack of a pass in one launch (round 4) */
+#define SG_STAGE_AN_FUSED_BWD 51
 int sg_trace_begin(sg_ctx* ctx, int32_t max_records);
 int sg_trace_end(sg_ctx* ctx, int32_t* tags_out, float* ms_out, int32_t capacity, int32_t* n_out);
 

@@ -62,7 +62,8 @@ class LossSpec(C.Structure):
 
 
 class Dither(C.Structure):
-    _fields_ = [("dither", C.c_float), ("seed", C.c_uint64), ("index_base", C.c_int64), ("noise_dev", C.c_void_p)]
+    _fields_ = [("dither", C.c_float), ("seed", C.c_uint64), ("index_base", C.c_int64), ("noise_dev", C.c_void_p),
+                ("row_base", C.c_int64), ("rep_rows", C.c_int32)]
 
 
 class PgdParams(C.Structure):

@@ -26,10 +26,18 @@ class EOT:
         scores = None
         loss = 0
         decisions = [[] for _ in range(n_audios)]
+        base = getattr(self.model, 'base_model', self.model)
+        keyed = hasattr(base, 'row_keys')  # the engine keys its noise by (utterance, repeat), not by the row of the call
         for EOT_index in range(EOT_num_batches):
             x_rep = x_batch.repeat(EOT_batch_size, 1, 1)
             y_rep = y_batch.repeat(EOT_batch_size)
-            dec, sc, ls, g = self.model.loss_grad(x_rep, y_rep, self.loss, want_grad=bool(use_grad))
+            if keyed:
+                base._rep_rows = n_audios if EOT_batch_size > 1 else 0
+            try:
+                dec, sc, ls, g = self.model.loss_grad(x_rep, y_rep, self.loss, want_grad=bool(use_grad))
+            finally:
+                if keyed:
+                    base._rep_rows = 0
             sc_m = sc.view(EOT_batch_size, -1, sc.shape[1]).mean(0)
             ls_m = ls.view(EOT_batch_size, -1).mean(0)
             if EOT_index == 0:

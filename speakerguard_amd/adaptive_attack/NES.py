@@ -31,8 +31,8 @@ class NES:
         x = x.contiguous()
         index_base = 0
         if hasattr(base, 'noise_seed'):
-            # keyed by (seed, attack call, restart, chunk base, NES call inside the chunk) + global example index in
-            # the kernel: independent of the shard layout (model/_engine_ops.py)
+            # keyed by (seed, attack call, restart, NES call inside the chunk) + global example index in the kernel:
+            # independent of the chunking and of the shard layout (model/_engine_ops.py)
             base._nes_draw += 1
             seed = base.noise_seed(self.seed ^ 0x4E4553, base._nes_draw)
             index_base = base._index_base
@@ -49,7 +49,13 @@ class NES:
             eval_input, _ = base.nes_queries(x, half, with_clean, self.sigma, seed, i * half, noise_in, index_base=index_base)
             per = 2 * half + int(with_clean)
             eval_y = y.repeat_interleave(per)
-            scores, loss, _, decisions = self.EOT_wrapper(eval_input, eval_y)
+            if hasattr(base, 'row_keys'):
+                base._row_scale = per  # example e of the chunk owns rows [e * per, (e + 1) * per) of the model call
+            try:
+                scores, loss, _, decisions = self.EOT_wrapper(eval_input, eval_y)
+            finally:
+                if hasattr(base, 'row_keys'):
+                    base._row_scale = 1
             loss = (loss / EOT_num_batches).view(n_audios, -1).contiguous()
             scores = (scores / EOT_num_batches).view(n_audios, -1, scores.shape[1])
             last = i == num_batches - 1

@@ -82,7 +82,8 @@ class CW2(FGSM):
                         batch_id, const.cpu().numpy(), n_iter, loss.cpu().numpy().tolist(), loss1.cpu().numpy().tolist(),
                         loss2.cpu().numpy().tolist(), decisions.cpu().numpy(), y_batch.cpu().numpy()))
                 if self.stop_early and n_iter % self.stop_early_iter == 0:
-                    mean_loss = float(loss.mean().item())  # batch-mean criterion (CW2.py:96-100)
+                    # batch-mean criterion (CW2.py:96-100); a sharded run takes the mean over the whole chunk (shard.py)
+                    mean_loss = self.batch_mean(loss) if self.batch_mean is not None else float(loss.mean().item())
                     if mean_loss > 0.9999 * prev_loss:
                         print("Early Stop ! ")
                         continue_flag = False
@@ -109,6 +110,13 @@ class CW2(FGSM):
 
         success = (global_best_score != -2).tolist()
         return global_best_adver_x, success
+
+    batch_mean = None  # shard.ShardedAttack: mean of the chunk's losses over all ranks
+
+    @property
+    def chunk_coupling(self):
+        """The examples of a chunk share the early-stop test (their mean loss) and nothing else."""
+        return 'mean' if self.stop_early else None
 
     def attack(self, x, y):
         return super().attack(x, y)

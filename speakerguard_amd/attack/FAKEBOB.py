@@ -56,6 +56,10 @@ class FAKEBOB(Attack):
         self.EOT_batch_size = EOT_batch_size
         self.verbose = verbose
 
+    # the plateau history aliases over the examples of a chunk (``[[]] * n``, see above): a chunk's examples have to
+    # be attacked together for the reference's result, so shard.ShardedAttack cuts on multiples of batch_size
+    chunk_coupling = 'chunk'
+
     @staticmethod
     def delete_found(flags, tensors, lists):
         """Drop the examples whose flag is < 0 from every per-example tensor / list (:125-168)."""

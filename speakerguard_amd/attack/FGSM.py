@@ -116,6 +116,7 @@ class FGSM(Attack):
         return x_batch, success
 
     index_offset = 0  # global index of x[0] when this object attacks one shard of a larger batch (shard.py)
+    chunk_coupling = None  # nothing ties the examples of a chunk together (EOT.py:33-35: per-example loss vector)
 
     def _begin_attack(self):
         base = getattr(self.model, 'base_model', self.model)

@@ -1634,13 +1634,15 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         return e ? atoi(e) : 0;
     }();
     if (env_kind >= 5 && env_kind <= 9 && a.force == 0 && a.Wq) {
+        const int kind0 = kind, bm0 = bm, workers0 = workers;
         kind = env_kind;
         bm = kind == 5 || kind == 9 ? 128 : kind == 6 ? 64 : kind == 7 ? 32 : 256;
         workers = cus;
         const long tl = (long)((a.M + bm - 1) / bm) * (a.N / 128);
         if (tl < workers || (tl * a.total_chunks + workers - 1) / workers < a.total_chunks) {  // does not qualify: leave the choice alone
-            kind = 2;
-            bm = 256;
+            kind = kind0;
+            bm = bm0;
+            workers = workers0;
         }
     }
     if (a.force >= 6 && a.force <= 10 && a.Wq) {  // parity tests: the wave-specialised kinds on any shape that qualifies

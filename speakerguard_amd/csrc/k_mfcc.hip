@@ -183,8 +183,12 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
             if (dz.noise_dev) v += dz.noise_dev[((size_t)b * F + f) * kWin + n];
             else if (dz.dither != 0.f) {
                 // repeat r of the batched EOT passes draws from key seed + r * 0xC2B2AE3D27D4EB4F, like the r-th of the
-                // sequential passes it replaces (sg_xv_pgd_run)
-                const int rep = t.rep_utts > 0 ? b / t.rep_utts : 0, utt = t.rep_utts > 0 ? b - rep * t.rep_utts : b;
+                // sequential passes it replaces (sg_xv_pgd_run); a caller that materialised the repeats itself
+                // (EOT.py:29) names their length in dz.rep_rows, and a row slice of a larger call its offset in
+                // dz.row_base (speakerguard_hip.h, sg_dither): same draws however the work was cut
+                const int64_t g = dz.row_base + b;
+                const int64_t rlen = t.rep_utts > 0 ? t.rep_utts : dz.rep_rows;
+                const int64_t rep = rlen > 0 ? g / rlen : 0, utt = g - rep * rlen;
                 v += dither_draw(dz.seed + (uint64_t)rep * 0xC2B2AE3D27D4EB4Full, dz.index_base + utt, f, n, dz.dither);
             }
         }
@@ -552,7 +556,11 @@ hipError_t launch_frames_to_wave(const float* dframes, int B, int T, int F, int 
                                  hipStream_t s) {
     // four samples per thread once the launch is bandwidth-bound (19.4 -> ~12 us at 64 utterances); small batches are
     // latency-bound and keep one sample per thread (5.1 us at 8 utterances against 6.5)
-    if (T % 4 == 0 && (long)B * T >= 16L * 48000) {  // (T % 4: rows stay 16-byte aligned)
+    // (T % 4 and 16-byte aligned bases: every row of the caller-owned buffers is read / written as 16-byte vectors)
+    const uintptr_t bases = reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x_io) |
+                            reinterpret_cast<uintptr_t>(lower) | reinterpret_cast<uintptr_t>(upper) |
+                            reinterpret_cast<uintptr_t>(acc_in) | reinterpret_cast<uintptr_t>(dframes);
+    if (T % 4 == 0 && bases % 16 == 0 && (long)B * T >= 16L * 48000) {
         dim3 grid((T / 4 + 255) / 256, B);
         hipLaunchKernelGGL(frames_to_wave_kernel<4>, grid, dim3(256), 0, s, dframes, B, T, F, R, acc_in, grad_out, x_io, lower, upper,
                            step, grad_sign);

@@ -29,19 +29,6 @@ int fail(sg_ctx* ctx, int code, const char* fmt, ...) {
                                           hipGetErrorString(e_), __FILE__, __LINE__);                  \
     } while (0)
 
-// stage trace: event pair around one launch (no-op unless sg_trace_begin switched it on and records are left)
-inline void trace_mark(sg_ctx* ctx, int tag, hipStream_t s, int after) {
-    if (!ctx->trace_on) return;
-    if (!after) {
-        if (ctx->trace_used >= (int)ctx->trace_tag.size()) return;
-        ctx->trace_tag[ctx->trace_used] = tag;
-        (void)hipEventRecord(ctx->trace_ev[2 * ctx->trace_used], s);
-    } else {
-        if (ctx->trace_used >= (int)ctx->trace_tag.size() || ctx->trace_tag[ctx->trace_used] != tag) return;
-        (void)hipEventRecord(ctx->trace_ev[2 * ctx->trace_used + 1], s);
-        ++ctx->trace_used;
-    }
-}
 #define SG_STAGE(tag, expr)          \
     do {                             \
         trace_mark(ctx, (tag), s, 0); \
@@ -869,6 +856,14 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     Workspace& w = ctx->ws;
     for (int r = 0; r < G; ++r)
         SG_HIP(hipMemcpyAsync(w.y_rep + (size_t)r * B, y_dev, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    // per-step records (attack/FGSM.py:50-58: loss averaged, decision voted over ALL EOT repeats of the step): when the
+    // repeats of a step run as several passes (G < reps) every pass leaves its rows here and the last one reduces them
+    const bool want_rec = loss_trace_dev || decision_trace_dev;
+    if (want_rec && G < reps && w.eot_rows_cap < (size_t)reps * B) {
+        if ((rc = dev_alloc(ctx, w.allocs, &w.eot_loss_rows, (size_t)reps * B))) return rc;
+        if ((rc = dev_alloc(ctx, w.allocs, &w.eot_dec_rows, (size_t)reps * B))) return rc;
+        w.eot_rows_cap = (size_t)reps * B;
+    }
     for (int it = 0; it <= p->max_iter; ++it) {
         const bool last = it == p->max_iter;
         const int nrep = last ? 1 : reps;
@@ -893,14 +888,18 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
             // per-step records as the reference prints them (attack/FGSM.py:50-58): the loss averaged over the step's EOT
             // repeats and the decision voted over them (attack/utils.py:118-125).  A pass of several repeats records its
             // rows into the workspace and a small reduction writes the step's row; with more repeats than one pass holds
-            // (G < reps: activations past 2 GiB) the records cover the repeats of the step's first pass.
-            const bool rec = g0 == 0 && (loss_trace_dev || decision_trace_dev), direct = Gi == 1;
-            t.loss_trace = !rec ? nullptr : (direct && loss_trace_dev ? loss_trace_dev + (size_t)it * B : w.loss);
-            t.decision_trace = !rec ? nullptr : (direct && decision_trace_dev ? decision_trace_dev + (size_t)it * B : w.decisions);
+            // (G < reps: activations past 2 GiB, or SG_EOT_MAX_ROWS) the passes of the step collect their rows in repeat
+            // order and the reduction runs after the last one, over all `nrep` repeats.
+            const bool direct = nrep == 1, grouped = nrep > G;
+            float* lrows = grouped ? w.eot_loss_rows + (size_t)g0 * B : w.loss;
+            int64_t* drows = grouped ? w.eot_dec_rows + (size_t)g0 * B : w.decisions;
+            t.loss_trace = !want_rec ? nullptr : (direct && loss_trace_dev ? loss_trace_dev + (size_t)it * B : lrows);
+            t.decision_trace = !want_rec ? nullptr : (direct && decision_trace_dev ? decision_trace_dev + (size_t)it * B : drows);
             t.coef_rows = B;  // SG_LOSS_LINEAR: the caller's (B, S) table serves every repeat of an utterance
             SG_STAGE(SG_STAGE_TAIL, launch_tail(t, s));
-            if (rec && !direct)
-                SG_HIP(launch_eot_trace_reduce(w.loss, w.decisions, Gi, B, loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
+            if (want_rec && !direct && g0 + Gi >= nrep)
+                SG_HIP(launch_eot_trace_reduce(grouped ? w.eot_loss_rows : w.loss, grouped ? w.eot_dec_rows : w.decisions, nrep, B,
+                                               loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
                                                decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr, s));
             if (!last) {
                 const bool final_group = g0 + Gi >= nrep;
@@ -925,6 +924,8 @@ int sg_trace_begin(sg_ctx* ctx, int32_t max_records) {
     }
     ctx->trace_tag.assign((size_t)max_records, 0);
     ctx->trace_used = 0;
+    ctx->trace_open = false;
+    ctx->trace_dropped = 0;
     ctx->trace_on = true;
     return SG_OK;
 }
@@ -933,8 +934,11 @@ int sg_trace_end(sg_ctx* ctx, int32_t* tags_out, float* ms_out, int32_t capacity
     if (!ctx || !n_out) return SG_ERR_ARG;
     if (!ctx->trace_on) return fail(ctx, SG_ERR_STATE, "sg_trace_end without sg_trace_begin");
     ctx->trace_on = false;
+    ctx->trace_open = false;
     const int n = ctx->trace_used;
     *n_out = n;
+    if (ctx->trace_dropped)
+        return fail(ctx, SG_ERR_HIP, "stage trace: %d event record(s) failed, %d launch records kept", ctx->trace_dropped, n);
     if (n > 0) SG_HIP(hipEventSynchronize(ctx->trace_ev[2 * (n - 1) + 1]));
     for (int i = 0; i < n && i < capacity; ++i) {
         float ms = 0.f;

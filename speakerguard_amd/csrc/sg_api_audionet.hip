@@ -27,6 +27,13 @@ int an_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
                                              hipGetErrorString(e_), __FILE__, __LINE__);              \
     } while (0)
 
+#define AN_STAGE(tag, expr)           \
+    do {                              \
+        trace_mark(ctx, (tag), s, 0); \
+        AN_HIP(expr);                 \
+        trace_mark(ctx, (tag), s, 1); \
+    } while (0)
+
 template <typename T>
 int an_alloc(sg_ctx* ctx, std::vector<void*>& pool, T** out, size_t count) {
     void* p = nullptr;
@@ -233,7 +240,7 @@ int an_frontend_forward(sg_ctx* ctx, const float* x, const AnDims& d, hipStream_
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
     w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T;
-    AN_HIP(launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
+    AN_STAGE(SG_STAGE_AN_LOGMEL_FWD, launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
     return SG_OK;
 }
 
@@ -243,7 +250,7 @@ int an_net_forward(sg_ctx* ctx, const float* feats, int B, int Fnet, hipStream_t
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
     an_layer_frames(Fnet, w.Tin, w.Tout);
-    AN_HIP(launch_an_prefilter(feats, w.pre, B, Fnet, m.w25, m.pre_bias, 0, s));
+    AN_STAGE(SG_STAGE_AN_PREFILTER_FWD, launch_an_prefilter(feats, w.pre, B, Fnet, m.w25, m.pre_bias, 0, s));
     for (int l = 0; l < kAnConv; ++l) {
         ConvGemmArgs a{};
         a.A = an_layer_input(w, l);
@@ -264,8 +271,8 @@ int an_net_forward(sg_ctx* ctx, const float* feats, int B, int Fnet, hipStream_t
         a.total_chunks = 3 * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
         a.Wq = m.wfq[l];
-        AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, EPI_BIAS_RELU, 1, s));
-        if (kAnPool[l]) AN_HIP(launch_an_pool_fwd(w.act[l], w.pool[l], B, w.Tout[l], kAnCout[l], s));
+        AN_STAGE(SG_STAGE_AN_CONV_FWD + l, launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, EPI_BIAS_RELU, 1, s));
+        if (kAnPool[l]) AN_STAGE(SG_STAGE_AN_POOL_FWD, launch_an_pool_fwd(w.act[l], w.pool[l], B, w.Tout[l], kAnCout[l], s));
     }
     return SG_OK;
 }
@@ -306,11 +313,11 @@ int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t
         a.total_chunks = 3 * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
         a.Wq = m.wbq[l];
-        AN_HIP(launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, a.mask ? EPI_RELU_MASK : EPI_NONE, 1, s));
+        AN_STAGE(SG_STAGE_AN_CONV_BWD + l, launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, a.mask ? EPI_RELU_MASK : EPI_NONE, 1, s));
         if (in_pooled)
-            AN_HIP(launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], B, w.Tout[l - 1], kAnCout[l - 1], s));
+            AN_STAGE(SG_STAGE_AN_POOL_BWD, launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], B, w.Tout[l - 1], kAnCout[l - 1], s));
     }
-    AN_HIP(launch_an_prefilter(w.dpre, dfeats_out, B, Fnet, m.w25, 0.f, 1, s));
+    AN_STAGE(SG_STAGE_AN_PREFILTER_BWD, launch_an_prefilter(w.dpre, dfeats_out, B, Fnet, m.w25, 0.f, 1, s));
     return SG_OK;
 }
 
@@ -320,8 +327,8 @@ int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const flo
     AnWorkspace& w = ctx->an_ws;
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
-    AN_HIP(launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, dfeats, w.dframes, s));
-    AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step, grad_sign, s));
+    AN_STAGE(SG_STAGE_AN_LOGMEL_BWD, launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, dfeats, w.dframes, s));
+    AN_STAGE(SG_STAGE_AN_OVERLAP_ADD, launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step, grad_sign, s));
     return SG_OK;
 }
 
@@ -449,7 +456,7 @@ int sg_an_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, in
     if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
     AnWorkspace& w = ctx->an_ws;
     sg_loss_spec none{};
-    AN_HIP(launch_an_tail(w.act[kAnConv - 1], B, w.Tout[kAnConv - 1], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, nullptr,
+    AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[kAnConv - 1], B, w.Tout[kAnConv - 1], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, nullptr,
                           none, 0, emb_dev, scores_dev, decisions_dev, nullptr, nullptr, nullptr, nullptr, nullptr, s));
     return SG_OK;
 }
@@ -487,7 +494,7 @@ int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
     AnWorkspace& w = ctx->an_ws;
     const int L = kAnConv - 1;
-    AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, *loss,
+    AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, *loss,
                           grad_dev != nullptr, nullptr, scores_dev, decisions_dev, loss_dev, w.dact[L], nullptr, nullptr,
                           nullptr, s));
     if (grad_dev) return an_backward_net(ctx, x_dev, d, flag, grad_dev, nullptr, nullptr, nullptr, 0.f, 0, s);
@@ -509,7 +516,7 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
         const bool last = it == p->max_iter;
         d.keep_scale = it > 0;  // iterates stay in [-1, 1]
         if ((rc = an_forward_net(ctx, x_adv_dev, d, 0, s))) return rc;
-        AN_HIP(launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
+        AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
                               nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
                               w.dact[L], loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
                               decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr,
@@ -562,16 +569,18 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
         d.keep_scale = it > 0;  // iterates stay in [-1, 1]
         if ((rc = an_frontend_forward(ctx, x_adv_dev, d, s))) return rc;
         const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull;  // repeat r: + r * 0xC2B2AE3D27D4EB4F
+        trace_mark(ctx, SG_STAGE_AN_FECO_FWD, s, 0);
         rc = sg_feco_kmeans_compress(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, f->random_init, key, f->index_base, R,
                                      w.feco_ids, w.feco_out, w.feco_cnt, s);
         if (rc) return rc;
+        trace_mark(ctx, SG_STAGE_AN_FECO_FWD, s, 1);
         if ((rc = an_net_forward(ctx, w.feco_out, rows, k, s))) return rc;
         // per-step records as the reference prints them (attack/FGSM.py:50-58): the loss averaged over the step's EOT
         // repeats, the decision voted over them
         const bool direct = R == 1, rec = loss_trace_dev || decision_trace_dev;
         float* ltr = !rec ? nullptr : (direct && loss_trace_dev ? loss_trace_dev + (size_t)it * B : w.trace_l);
         int64_t* dtr = !rec ? nullptr : (direct && decision_trace_dev ? decision_trace_dev + (size_t)it * B : w.trace_d);
-        AN_HIP(launch_an_tail(w.act[L], rows, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, w.y_rep, p->loss, !last,
+        AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], rows, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, w.y_rep, p->loss, !last,
                               nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
                               w.dact[L], ltr, dtr, last ? success_dev : nullptr, s, B));
         if (rec && !direct)
@@ -579,7 +588,9 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
                                            decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr, s));
         if (last) break;
         if ((rc = an_net_backward(ctx, rows, k, w.dfeco, s))) return rc;
+        trace_mark(ctx, SG_STAGE_AN_FECO_BWD, s, 0);
         if ((rc = sg_feco_compress_backward_reps(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, R, w.dfeats, s))) return rc;
+        trace_mark(ctx, SG_STAGE_AN_FECO_BWD, s, 1);
         rc = an_frontend_backward(ctx, x_adv_dev, d, w.dfeats, nullptr, x_adv_dev, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
         if (rc) return rc;
     }

@@ -181,6 +181,9 @@ struct Workspace {
     int64_t* decisions = nullptr;      // [B]
     float* grad = nullptr;             // [B][T]
     int64_t* y_rep = nullptr;          // [B] labels repeated for EOT repeats batched into one pass
+    float* eot_loss_rows = nullptr;    // [reps * B] per-repeat records of a step whose repeats run as several passes
+    int64_t* eot_dec_rows = nullptr;
+    size_t eot_rows_cap = 0;
     std::vector<void*> allocs;
 };
 
@@ -211,12 +214,33 @@ struct sg_ctx {
     // Stage trace (sg_trace_begin / sg_trace_end): while on, every launch of the x-vector pass sequences is bracketed by a
     // pair of HIP events on the launch stream; a record = (stage tag, event before, event after).
     bool trace_on = false;
+    bool trace_open = false;   // the opening event of record trace_used was recorded, the closing one not yet
+    int trace_dropped = 0;     // records given up because an event record failed (reported by sg_trace_end)
     int trace_used = 0;
     std::vector<hipEvent_t> trace_ev;  // 2 per record
     std::vector<int> trace_tag;
 };
 
 namespace sg {
+
+// stage trace: event pair around one launch (no-op unless sg_trace_begin switched it on and records are left).  A
+// record whose opening or closing event could not be recorded is dropped -- its slot is reused by the next launch --
+// and counted; sg_trace_end reports the count instead of a later, unrelated-looking HIP error.  A launch error
+// between the two marks leaves the record open; the next opening mark simply overwrites it.
+inline void trace_mark(sg_ctx* ctx, int tag, hipStream_t s, int after) {
+    if (!ctx->trace_on || ctx->trace_used >= (int)ctx->trace_tag.size()) return;
+    if (!after) {
+        ctx->trace_tag[ctx->trace_used] = tag;
+        ctx->trace_open = hipEventRecord(ctx->trace_ev[2 * ctx->trace_used], s) == hipSuccess;
+        if (!ctx->trace_open) ++ctx->trace_dropped;
+    } else {
+        if (!ctx->trace_open || ctx->trace_tag[ctx->trace_used] != tag) return;
+        ctx->trace_open = false;
+        if (hipEventRecord(ctx->trace_ev[2 * ctx->trace_used + 1], s) == hipSuccess) ++ctx->trace_used;
+        else ++ctx->trace_dropped;
+    }
+}
+
 
 // ---------------------------------------------------------------- kernel launchers (k_*.hip)
 enum Epilogue { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_RELU_MASK = 2 };

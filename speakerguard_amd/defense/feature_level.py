@@ -43,9 +43,12 @@ class FeCoDefense:
         return mix64(self.seed ^ 0x4665436F, call)
 
     # ---- forward with saved state ------------------------------------------------------------------
-    def fwd(self, feat, seed=None, ids=None):
+    def fwd(self, feat, seed=None, ids=None, row_keys=None):
         """feat (B,F,D) -> (compressed (B,k,D) [or (1,k',D) with empty clusters dropped when B == 1], saved).
         `seed`: explicit generator key for this call of the randomised defense (tests replay the fused loop's keys).
+        `row_keys` = (index_base, row_base, rep_rows) as in sg_dither (speakerguard_hip.h): which global utterance and
+        which EOT repeat every row of `feat` is -- repeat r draws from key + r * 0xC2B2AE3D27D4EB4F, like repeat r of the
+        device loop (sg_an_pgd_run_feco); default: row b is utterance ``self.index_base + b``.
         `ids` (B,F) int32: cluster ids from elsewhere -- only the reference's step after the clustering runs
         (feature_level.py:204-216; tests/golden/feco_ref.npz pins it against the reference's own code)."""
         feat = feat.to(torch.float32).contiguous()
@@ -67,9 +70,19 @@ class FeCoDefense:
             if self.init == 'random':
                 key = self.call_seed(self.calls) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
             self.calls += 1
-            # clustering + cluster means (:204-216) in one launch
-            ctx.call("sg_feco_kmeans_compress", N._ptr(feat), B, F, D, k, self.max_iter, int(self.init == 'random'),
-                     C.c_uint64(key), int(self.index_base), 1, N._ptr(ids), N._ptr(out), N._ptr(counts), s)
+            # clustering + cluster means (:204-216) in one launch per EOT repeat the rows belong to (normally one)
+            index_base, row_base, rep_rows = row_keys if row_keys is not None else (self.index_base, 0, 0)
+            b0 = 0
+            while b0 < B:
+                g = row_base + b0
+                rep = g // rep_rows if rep_rows > 0 else 0
+                u = g - rep * rep_rows
+                nb = min(B - b0, rep_rows - u) if rep_rows > 0 else B
+                sl = slice(b0, b0 + nb)
+                ctx.call("sg_feco_kmeans_compress", N._ptr(feat[sl]), nb, F, D, k, self.max_iter, int(self.init == 'random'),
+                         C.c_uint64((key + rep * 0xC2B2AE3D27D4EB4F) & 0xFFFFFFFFFFFFFFFF), int(index_base + u), 1,
+                         N._ptr(ids[sl]), N._ptr(out[sl]), N._ptr(counts[sl]), s)
+                b0 += nb
         force = B > 1  # :33 force=feat.shape[0] > 1
         keep = None
         if not force and bool((counts == 0).any()):

@@ -23,13 +23,17 @@ def mix64(*vals):
 class EngineOps:
     """Mixin: expects ``self.ctx`` (N.Context) and ``self.device``.
 
-    Noise bookkeeping (dither of the MFCC front-end, NES queries): the reference draws from the process-global torch
-    RNG, which makes an utterance's noise depend on everything that ran before it.  Here every draw is keyed by
-    (user seed, attack call, restart, chunk base = GLOBAL index of the chunk's first utterance, pass number inside
-    the chunk) and, inside the kernels, by the row within the chunk -- so the noise an utterance sees does not depend
-    on how the batch is cut into per-GPU shards (shards are cut on chunk boundaries, speakerguard_amd/shard.py).
+    Noise bookkeeping (dither of the MFCC front-end, NES queries, FeCo's random start): the reference draws from the
+    process-global torch RNG, which makes an utterance's noise depend on everything that ran before it.  Here every
+    draw is keyed by (user seed, attack call, restart, pass number inside the chunk) and, inside the kernels, by the
+    GLOBAL index of the utterance (chunk base + row; an EOT repeat moves the key, not the index) -- so the noise an
+    utterance sees does not depend on how the batch is chunked or cut into per-GPU shards, wherever the cut falls
+    (round 4; rounds 2-3 hashed the chunk base into the key, which tied the invariance to chunk-aligned cuts).
     ``attack()`` calls ``begin_attack`` once, ``_run_batches`` calls ``begin_batch`` per chunk; without them every
     forward simply advances ``_draw`` (fresh noise per call, like the reference).
+
+    What a kernel needs to find "global utterance, repeat" from a row of the call (sg_dither, speakerguard_hip.h):
+    ``row_keys()`` = (index base of row 0, offset of this call's row 0 inside the full call, rows per EOT repeat).
     """
     _noise_epoch = 0   # attack() calls so far
     _batch_salt = 0    # restart number + 1 (0: none)
@@ -38,6 +42,8 @@ class EngineOps:
     _nes_draw = 0      # NES.forward calls since begin_batch
     _def_draw = 0      # calls of a randomised defense (FeCoDefense(init='random')) since begin_batch
     _row_base = 0      # position of this call's row 0 inside the full model call it is a slice of (shard.QueryShardedModel)
+    _row_scale = 1     # rows every utterance of the chunk contributes to the call (NES: its queries), set by the caller
+    _rep_rows = 0      # > 0: the full call's rows are EOT repeats of _rep_rows rows (adaptive_attack/EOT.py sets it)
 
     def begin_attack(self):
         self._noise_epoch += 1
@@ -46,12 +52,16 @@ class EngineOps:
         self._index_base, self._batch_salt, self._draw, self._nes_draw, self._def_draw = int(index_base), int(salt), 0, 0, 0
 
     def noise_seed(self, user_seed, draw):
-        return mix64(user_seed, self._noise_epoch, self._batch_salt, self._index_base, draw)
+        return mix64(user_seed, self._noise_epoch, self._batch_salt, draw)
+
+    def row_keys(self):
+        """(index_base, row_base, rep_rows) of the model call being made, see sg_dither."""
+        return int(self._index_base) * int(self._row_scale), int(self._row_base), int(self._rep_rows)
 
     def defense_seed(self, user_seed):
         """Generator key of the next call of a randomised defense sitting on this model (defended_model): keyed like the
-        dither -- (seed, attack call, restart, chunk base, call number inside the chunk) -- so that the clusterings an
-        utterance sees do not depend on the shard layout either."""
+        dither -- (seed, attack call, restart, call number inside the chunk) + global utterance index -- so that the clusterings an
+        utterance sees do not depend on the shard layout either (rows: ``row_keys()``)."""
         key = self.noise_seed(int(user_seed) ^ 0x4665436F, self._def_draw)
         self._def_draw += 1
         return key

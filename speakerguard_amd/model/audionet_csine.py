@@ -188,12 +188,12 @@ class audionet_csine(EngineOps):
         f.k = int(N.load().sg_an_num_frames(T) * feco.param)  # feature_level.py:184
         f.max_iter = int(feco.max_iter)
         f.random_init = int(feco.init == 'random')
-        # one key per fused call, from the model's noise bookkeeping (attack call, chunk base: shard-invariant); the
-        # passes inside derive theirs from it; rows are chunk-local like the dither's
+        # one key per fused call, from the model's noise bookkeeping (attack call, restart, call number); the passes
+        # inside derive theirs from it; a row is keyed by its utterance's GLOBAL index (chunk base + row)
         f.seed = self.defense_seed(feco.seed)
         feco.calls += 1
         self.last_fused_seed = int(f.seed)
-        f.index_base = int(feco.index_base)
+        f.index_base = int(feco.index_base) + self.row_keys()[0]
         success = torch.empty(B, device=self.device, dtype=torch.uint8)
         dec = torch.empty(B, device=self.device, dtype=torch.int64)
         scores = torch.empty(B, self.num_spks, device=self.device, dtype=torch.float32)

@@ -49,7 +49,7 @@ class defended_model:
         """``d.fwd(xx)``; a randomised defense (FeCoDefense(init='random')) takes its generator key from the base
         model's noise bookkeeping (attack call, chunk, call number) instead of its own call counter."""
         if getattr(d, 'init', None) == 'random' and hasattr(self.base_model, 'defense_seed'):
-            return d.fwd(xx, seed=self.base_model.defense_seed(d.seed))
+            return d.fwd(xx, seed=self.base_model.defense_seed(d.seed), row_keys=self.base_model.row_keys())
         return d.fwd(xx)
 
     def _apply(self, d, xx):

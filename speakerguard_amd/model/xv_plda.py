@@ -171,12 +171,13 @@ class xv_plda(EngineOps):
     def _dither(self, noise=None, seed=None):
         d = N.Dither()
         d.dither = self.dither
-        d.index_base = int(self._row_base)  # 0 unless this call scores a row slice of a larger call (shard.QueryShardedModel)
+        # global utterance index of row 0, offset inside the full call (shard.QueryShardedModel), rows per EOT repeat
+        d.index_base, d.row_base, d.rep_rows = self.row_keys()
         d.noise_dev = None if noise is None else noise.data_ptr()
         if seed is not None:  # explicit generator key (tests re-play the fused loop's per-pass seeds)
             d.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
             return d
-        d.seed = self.noise_seed(self.dither_seed, self._draw)  # chunk base is part of the seed, rows are chunk-local
+        d.seed = self.noise_seed(self.dither_seed, self._draw)
         self._draw += 1  # every forward draws fresh noise, like the reference's global RNG
         return d
 

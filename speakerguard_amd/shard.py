@@ -12,14 +12,26 @@ slices, one per rank, with NO collective on the data path.  The only exchanges a
 Batch-coupled details that are preserved by construction rather than by communication:
   * ``check_input_range`` (model/utils.py:11) decides the int16 rescale from the batch max/min; attack
     inputs are asserted to be in [-1, 1), so every shard takes the same branch;
-  * CW2's early stop uses the mean loss of the chunk it is processing (attack/CW2.py:96-100); shards
-    are cut on multiples of ``attacker.batch_size`` so chunks are the same ones the unsharded run uses;
+  * CW2's early stop uses the mean loss of the chunk it is processing (attack/CW2.py:96-100): with ``stop_early``
+    the cut goes INSIDE every chunk (each rank iterates its slice of the chunk) and the per-utterance losses of the
+    chunk are all-gathered at every early-stop test -- B floats every ``stop_early_iter`` iterations, the path's
+    one exchange inside a loop -- so every rank takes the mean over the same values in the same order as the
+    unsharded run and stops at the same iteration;
+  * FAKEBOB's plateau history leaks between the examples of a chunk (the reference's ``[[]] * n`` aliasing,
+    attack/FAKEBOB.py:56, reproduced on purpose), so its batch cut stays on multiples of ``batch_size``; the cut
+    that scales it is ``QueryShardedModel`` below;
+  * everything else (FGSM / PGD / CWinf, CW2 without early stop) has NO coupling inside a chunk: the batch is cut
+    with granule 1 -- N = 64 with ``batch_size=64`` on 8 ranks is 8 utterances per rank ("batch
+    64 sharded B/G per GPU"; reference attack/PGD.py:62-73 only chunks for memory) -- and a rank runs its shard in
+    chunks of ``min(batch_size, shard)``.  Results do not depend on the chunking: per-utterance arithmetic is
+    independent of batch composition (bit for bit on the engine), noise is keyed by the global utterance index;
   * random restarts draw the FULL (N,1,T) noise from the host RNG on every rank (seed all ranks
     alike) and slice it, so the noise an utterance sees does not depend on the shard layout;
-  * device-generated noise (MFCC dither, NES queries) is keyed by (seed, attack call, restart, GLOBAL index of
-    the chunk's first utterance, pass number within the chunk) and the row within the chunk
-    (model/_engine_ops.py): a rank passes its shard offset as ``attacker.index_offset``, so a sharded run
-    draws exactly the noise of the unsharded run (tests/test_gpu_xv.py::test_device_noise_is_shard_invariant).
+  * device-generated noise (MFCC dither, NES queries, FeCo's random start) is keyed by (seed, attack call, restart,
+    pass number within the chunk) and, inside the kernels, by the GLOBAL index of the utterance and the EOT repeat
+    (model/_engine_ops.py): a rank passes its shard offset as ``attacker.index_offset``, so a sharded run draws
+    exactly the noise of the unsharded run wherever the cut falls
+    (tests/test_gpu_xv.py::test_device_noise_is_shard_invariant).
 
 ``QueryShardedModel`` is the other cut (BASELINE.json configs[4]: "query batch sharded over 8 x MI355X"): the
 black-box attacks score n * (samples_per_draw + 1) perturbed copies of FEW utterances per iteration
@@ -111,6 +123,19 @@ class ShardedAttack:
             base.begin_attack()
         return x[lo:hi], []
 
+    def granule(self):
+        """Utterances that must stay together on one rank: 1 unless the attack couples the examples of a chunk
+        through something other than an exchangeable mean (``chunk_coupling == 'chunk'``: FAKEBOB)."""
+        a = self.attacker
+        if getattr(a, "chunk_coupling", None) == "chunk":
+            return max(1, getattr(a, "batch_size", 1))
+        return 1
+
+    def bounds(self, n):
+        """[start, end) of every rank's contiguous shard of a batch of n utterances."""
+        world, _ = self._world()
+        return shard_bounds(n, world, self.granule())
+
     def attack(self, x, y):
         """x (N,1,T), y (N,) identical on every rank -> (adver_x, success list of length N).
 
@@ -118,7 +143,9 @@ class ShardedAttack:
         of a 64 x 3 s batch is skipped); success flags are always global."""
         world, rank = self._world()
         n = x.shape[0]
-        bounds = shard_bounds(n, world, max(1, getattr(self.attacker, "batch_size", 1)))
+        if world > 1 and getattr(self.attacker, "chunk_coupling", None) == "mean":
+            return self._attack_mean_coupled(x, y)
+        bounds = self.bounds(n)
         lo, hi = bounds[rank]
         adv, succ = self._local_attack(x, y, lo, hi)
         if world == 1:
@@ -128,6 +155,49 @@ class ShardedAttack:
         if self.gather_audio:
             adv = self._gather_rows(adv.contiguous(), bounds, n)
         return adv, [bool(v) for v in all_flags.tolist()]
+
+    def _attack_mean_coupled(self, x, y):
+        """An attack whose chunks are coupled through a batch mean only (CW2 with ``stop_early``, attack/CW2.py:96-100):
+        every chunk of ``batch_size`` utterances is cut over the ranks; the attacker's ``batch_mean`` hook all-gathers
+        the chunk's per-utterance losses and takes the mean over the full chunk in the unsharded order, so all ranks
+        stop where the unsharded run stops.  A rank without utterances in a chunk (chunk smaller than the world)
+        re-runs utterance 0 of the chunk and drops the result: every rank makes the same sequence of exchanges."""
+        a = self.attacker
+        world, rank = self._world()
+        a._check_inputs(x, y)
+        a._begin_attack()
+        n = x.shape[0]
+        lower = torch.tensor(-1, device=x.device, dtype=x.dtype).expand_as(x)
+        upper = torch.tensor(1, device=x.device, dtype=x.dtype).expand_as(x)
+        bs = min(max(1, a.batch_size), n)
+        adver, success = [], []
+        try:
+            for batch_id, s in enumerate(range(0, n, bs)):
+                e = min(n, s + bs)
+                run, keep = row_slices(e - s, world)
+                lo, hi = s + run[rank][0], s + run[rank][1]
+
+                def mean_hook(loss, run=run, keep=keep):
+                    width = max(b - a_ for a_, b in run)
+                    pad = torch.zeros(width, dtype=loss.dtype, device=loss.device)
+                    pad[: loss.shape[0]] = loss
+                    parts = [torch.empty_like(pad) for _ in range(world)]
+                    dist.all_gather(parts, pad, group=self.group)
+                    return float(torch.cat([p[: b - a_] for p, (a_, b) in zip(parts, keep)]).mean().item())
+
+                a.batch_mean = mean_hook
+                a._begin_batch(lo)
+                adv_c, succ_c = a.attack_batch(x[lo:hi], y[lo:hi], lower[lo:hi], upper[lo:hi], batch_id)
+                mine = keep[rank][1] - keep[rank][0]  # 0: this rank only kept the exchanges company
+                flags = torch.tensor([bool(v) for v in succ_c][:mine], dtype=torch.uint8, device=x.device)
+                success += self._gather_rows(flags, keep, e - s).tolist()
+                adver.append(self._gather_rows(adv_c[:mine].contiguous(), keep, e - s) if self.gather_audio else adv_c[:mine])
+        finally:
+            a.batch_mean = None
+        base = getattr(getattr(a, "model", None), "base_model", getattr(a, "model", None))
+        if hasattr(base, "check_health"):
+            base.check_health()
+        return torch.cat(adver, 0), [bool(v) for v in success]
 
 
 def row_slices(n, world):

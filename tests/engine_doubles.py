@@ -19,13 +19,22 @@ def oracle_loss_from_spec(spec):
 class AutogradEngine:
     """Wraps any differentiable ``make_decision`` model (ToyModel, oracle XvPlda)."""
 
-    def __init__(self, model, flag=None):
+    def __init__(self, model, flag=None, per_row=False):
         self.model = model
         self.threshold = model.threshold
         self.flag = flag
+        # per_row: every utterance goes through the model as a batch of one, so that -- like on the HIP engine -- an
+        # utterance's result does not depend on what else is in the batch (CPU BLAS picks kernels by batch size)
+        self.per_row = per_row
+
+    def _md1(self, x):
+        return self.model.make_decision(x) if self.flag is None else self.model.make_decision(x, flag=self.flag)
 
     def _md(self, x):
-        return self.model.make_decision(x) if self.flag is None else self.model.make_decision(x, flag=self.flag)
+        if not self.per_row or x.shape[0] <= 1:
+            return self._md1(x)
+        outs = [self._md1(x[i:i + 1]) for i in range(x.shape[0])]
+        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 
     def make_decision(self, x):
         with torch.no_grad():

@@ -48,7 +48,7 @@ def test_struct_layouts_match_header(tmp_path):
     sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     for (cname, ctype), size in zip(pairs, sizes):
         assert ctypes.sizeof(ctype) == size, (cname, ctypes.sizeof(ctype), size)
-    assert ctypes.sizeof(_native.LossSpec) == 32 and ctypes.sizeof(_native.Dither) == 32
+    assert ctypes.sizeof(_native.LossSpec) == 32 and ctypes.sizeof(_native.Dither) == 48
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):

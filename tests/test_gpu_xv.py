@@ -150,7 +150,7 @@ def test_device_noise_streams_match_the_philox_restatement(xv_weights, hip_model
     seed = md.noise_seed(md.dither_seed, 0)
     own = md.compute_feat(quiet, flag=1)
     F = kaldi_mfcc.num_frames(T)
-    noise = torch.from_numpy(np.stack([philox.dither_noise(seed, b, F) for b in range(2)])).to(dev)
+    noise = torch.from_numpy(np.stack([philox.dither_noise(seed, 6 + b, F) for b in range(2)])).to(dev)  # chunk base + row
     fed = md.compute_feat(quiet, flag=1, dither_noise=noise.contiguous())
     silent = xv_plda.from_weights(xv_weights, device=dev, dither=0.0).compute_feat(quiet, flag=1)
     err = float((own - fed).abs().max())
@@ -159,7 +159,7 @@ def test_device_noise_streams_match_the_philox_restatement(xv_weights, hip_model
     md._draw = 0
     own4 = md.compute_feat(quiet, flag=1)
     md._row_base = 0
-    noise4 = torch.from_numpy(np.stack([philox.dither_noise(seed, 4 + b, F) for b in range(2)])).to(dev)
+    noise4 = torch.from_numpy(np.stack([philox.dither_noise(seed, 6 + 4 + b, F) for b in range(2)])).to(dev)
     err4 = float((own4 - md.compute_feat(quiet, flag=1, dither_noise=noise4.contiguous())).abs().max())
     assert err4 < 2e-4 and not torch.equal(own4, own)
     log("device noise vs Philox restatement: NES normals max |diff| %.2e; MFCC with own dither vs restated noise fed in %.2e"
@@ -492,16 +492,16 @@ def test_fused_eot_over_dither_equals_stepwise_replay(xv_weights, dev, monkeypat
     # the device loop runs the 4 repeats as one batch of 12 rows; when a pass cannot hold them all they go in groups with
     # the sum handed on (here forced: 2 + 2 repeats, then 1 + 1 + 1 + 1) -- same bits.  The per-step records are what the
     # reference prints (attack/FGSM.py:50-58): the loss averaged over the step's repeats, the decision voted over them
-    # (round 3; round 2 recorded the first repeat) -- with forced groups, over the repeats of the step's first pass.
+    # (round 3; round 2 recorded the first repeat) -- with forced groups too (round 4: the passes of a step collect their
+    # rows and the reduction runs over all repeats; round 3 covered the repeats of the step's first pass only).
     m._draw = 100  # same generator key for the three runs
     ref_tr = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
     for cap in (6, 3):
         monkeypatch.setenv("SG_EOT_MAX_ROWS", str(cap))
         m._draw = 100
         got = m.pgd_run(x, y, lower, upper, spec, 0.0004, iters, 1, eot_size=reps, eot_batch_size=2, trace=True)
-        for a, b in zip(got[:5], ref_tr[:5]):
+        for a, b in zip(got, ref_tr):  # adversarial audio, flags, decisions, scores, loss AND the per-step records
             assert torch.equal(a, b), cap
-        assert torch.equal(got[5][iters], ref_tr[5][iters]) and torch.equal(got[6][iters], ref_tr[6][iters])  # the final single pass
     monkeypatch.delenv("SG_EOT_MAX_ROWS")
     # the records of the un-grouped run against the replayed repeats (a fresh run with the first run's key)
     m2 = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=11)
@@ -872,6 +872,105 @@ def test_device_noise_is_shard_invariant(xv_weights, dev):
                                            samples_per_draw_batch_size=4, batch_size=2, verbose=0), m0)
     assert torch.equal(full[0], sharded[0]) and list(full[1]) == sharded[1]
     log("device noise (dither + NES) shard-invariant: halves == full batch bit for bit")
+
+
+def test_noise_does_not_depend_on_where_the_batch_is_cut(xv_weights, dev):
+    """Round 4: shards are cut with granule 1 (shard.py), so the noise an utterance sees must be a function of its GLOBAL
+    index and the EOT repeat only -- not of the chunk it happens to be attacked in.  One chunk of 5 against the cuts
+    (0,2) + (2,5) and 5 x 1, with the random dither of the reference's default front-end: the device loop
+    (sg_xv_pgd_run, repeats batched inside), the host-chained EOT loop (EOT.py:29 materialises the repeats: rows =
+    repeat * B + utterance, named to the kernel through sg_dither.rep_rows) and CW2 (one pass per iteration)."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.CW2 import CW2
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.xv_plda import xv_plda
+    x = torch.from_numpy(synth.make_waveforms(5, 16000, seed=33)).to(dev)
+    md = xv_plda.from_weights(xv_weights, device=dev, dither=1.0, dither_seed=9)
+    y = md.make_decision(x)[0]
+
+    class HostLoop(PGD):  # the step-by-step loop over EOT.forward instead of the device loop
+        def _can_fuse(self):
+            return False
+
+    makers = {
+        "device loop": lambda bs: PGD(md, epsilon=0.002, step_size=0.0005, max_iter=2, batch_size=bs, EOT_size=4, EOT_batch_size=2, verbose=0),
+        "host-chained EOT": lambda bs: HostLoop(md, epsilon=0.002, step_size=0.0005, max_iter=2, batch_size=bs, EOT_size=4, EOT_batch_size=2, verbose=0),
+        "CW2": lambda bs: CW2(md, initial_const=0.1, binary_search_steps=1, max_iter=3, stop_early=False, lr=2e-3, batch_size=bs, verbose=0),
+    }
+    for name, make in makers.items():
+        md._noise_epoch = 0
+        full = make(5).attack(x, y)
+        for cuts in (((0, 2), (2, 5)), tuple((i, i + 1) for i in range(5))):
+            parts = []
+            for lo, hi in cuts:
+                md._noise_epoch = 0
+                atk = make(5)
+                atk.index_offset = lo
+                parts.append(atk.attack(x[lo:hi], y[lo:hi]))
+            assert torch.equal(full[0], torch.cat([p[0] for p in parts], 0)), (name, cuts)
+            assert list(full[1]) == sum((list(p[1]) for p in parts), []), (name, cuts)
+        md._noise_epoch = 0
+        chunked = make(2).attack(x, y)  # the same attack in chunks of 2, 2, 1
+        assert torch.equal(full[0], chunked[0]) and list(full[1]) == list(chunked[1]), name
+        md._noise_epoch = 0
+        moved = make(5)
+        moved.index_offset = 1  # ... and the index matters: the same audio attacked as utterances 1.. moves differently
+        assert not torch.equal(moved.attack(x[:2], y[:2])[0], full[0][:2]), name
+    log("device noise: one chunk of 5 == cuts (0,2)+(2,5) == 5 x 1 == chunks of 2 bit for bit (device loop, host-chained EOT, CW2)")
+
+
+class _OneRankOf(object):
+    """speakerguard_amd.shard.ShardedAttack as rank `rank` of `world` sees it, without a process group: the exchange is
+    replaced by writing this rank's rows into the full-size result (the gloo tests cover the exchange itself)."""
+
+    def __new__(cls, attacker, world, rank):
+        from speakerguard_amd.shard import ShardedAttack
+
+        class One(ShardedAttack):
+            def _world(self):
+                return world, rank
+
+            def _gather_rows(self, local, bounds, n):
+                out = torch.zeros((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+                s, e = bounds[rank]
+                out[s:e] = local[: e - s]
+                return out
+        return One(attacker, gather_audio=True)
+
+
+def test_sharded_attack_cuts_the_metrics_batch_over_eight_ranks(xv_weights, dev):
+    """`ShardedAttack(PGD(batch_size=64)).attack(x64, y64)` on 8 (and 3) ranks -- every rank gets
+    64 / world utterances, runs them as ONE device loop, and the ranks' results put together are the single-GPU
+    result bit for bit (flags, audio), with the reference's default dither on and EOT 2."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.xv_plda import xv_plda
+    from speakerguard_amd.shard import shard_bounds
+    x = torch.from_numpy(synth.make_waveforms(64, 48000, seed=1234)).to(dev)
+    for dither in (0.0, 1.0):
+        md = xv_plda.from_weights(xv_weights, device=dev, dither=dither, dither_seed=4)
+        y = md.make_decision(x)[0]
+        make = lambda: PGD(md, epsilon=0.0005, step_size=0.0002, max_iter=3, batch_size=64, EOT_size=2 if dither else 1,
+                           EOT_batch_size=2 if dither else 1, verbose=0)
+        md._noise_epoch = 0
+        ref_adv, ref_succ = make().attack(x, y)
+        for world in (8, 3):
+            adv, flags, seen = torch.zeros_like(ref_adv), np.zeros(64, bool), []
+            for rank in range(world):
+                md._noise_epoch = 0
+                atk = make()
+                sizes = []
+                inner = atk.attack_batch
+                atk.attack_batch = lambda xb, *a, inner=inner, sizes=sizes: (sizes.append(int(xb.shape[0])), inner(xb, *a))[1]
+                a, f = _OneRankOf(atk, world, rank).attack(x, y)
+                adv += a
+                flags |= np.asarray(f)
+                seen.append(sizes)
+            assert [sum(c) for c in seen] == [e - s for s, e in shard_bounds(64, world)] and all(len(c) == 1 for c in seen), seen
+            assert torch.equal(adv, ref_adv) and flags.tolist() == [bool(v) for v in ref_succ], (dither, world)
+        assert 0 < sum(ref_succ) < 64, "both outcomes: %d of 64" % sum(ref_succ)
+    log("ShardedAttack(PGD(batch_size=64)) on 8 / 3 emulated ranks: 8 (22/21/21) utterances per rank, one chunk each, "
+        "== the single-GPU attack bit for bit, dither 0 and dither 1 + EOT 2 (%d of 64 fooled)" % sum(ref_succ))
 
 
 def test_query_sharded_model_call_is_the_unsharded_call(xv_weights, dev):

@@ -20,7 +20,12 @@ def _make(kind):
     toy = ToyModel().eval()
     for p in toy.parameters():
         p.requires_grad_(False)
-    model = AutogradEngine(toy)
+    model = AutogradEngine(toy, per_row=True)  # an utterance's arithmetic must not depend on its batch, as on the engine
+    if kind == "pgd64":  # the metric's shape: ONE chunk of 64 ("batch 64 sharded B/G per GPU")
+        return PGD(model, epsilon=0.01, step_size=0.002, max_iter=4, batch_size=64, verbose=0)
+    if kind == "cw2_64":  # one chunk whose early stop is a mean over utterances that sit on different ranks
+        return CW2(model, initial_const=0.5, binary_search_steps=2, max_iter=12, stop_early=True, stop_early_iter=3,
+                   lr=5e-3, batch_size=64, verbose=0)
     if kind == "pgd":
         return PGD(model, epsilon=0.01, step_size=0.002, max_iter=6, batch_size=2, verbose=0)
     if kind == "pgd_rand":
@@ -29,24 +34,47 @@ def _make(kind):
                lr=5e-3, batch_size=2, verbose=0)
 
 
-def _data():
-    x = toy_inputs(B=6, T=800, seed=5)
+def _data(n=6):
+    x = toy_inputs(B=n, T=800, seed=5)
     toy = ToyModel().eval()
     with torch.no_grad():
         y = toy.make_decision(x)[0]
     return x, y
 
 
-def _worker(rank, world, port, kind, out):
+class _Recording:
+    """Attacker proxy that notes which utterances this rank was handed (chunk by chunk)."""
+
+    def __init__(self, attacker):
+        object.__setattr__(self, "_a", attacker)
+        object.__setattr__(self, "seen", [])
+        inner = attacker.attack_batch
+
+        def attack_batch(x, y, lower, upper, batch_id):
+            self.seen.append(int(x.shape[0]))
+            return inner(x, y, lower, upper, batch_id)
+        attacker.attack_batch = attack_batch
+
+    def __getattr__(self, name):
+        return getattr(self._a, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._a, name, value)
+
+
+def _worker(rank, world, port, kind, out, n=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    x, y = _data()
+    x, y = _data(n)
     np.random.seed(77)
-    adv, succ = ShardedAttack(_make(kind)).attack(x, y)
+    rec = _Recording(_make(kind))
+    adv, succ = ShardedAttack(rec).attack(x, y)
+    chunks = [None] * world
+    dist.all_gather_object(chunks, rec.seen)
     if rank == 0:
-        torch.save({"adv": adv, "succ": succ}, out)
+        torch.save({"adv": adv, "succ": succ, "chunks": chunks}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,6 +103,34 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         got = torch.load(out)
         assert got["succ"] == list(ref_succ), kind
         assert torch.equal(got["adv"], ref_adv), kind
+
+
+def test_metric_configuration_is_cut_over_all_ranks(tmp_path):
+    """N = 64 with batch_size = 64 (what INTEGRATION.md tells users to pass, and BASELINE.json's metric) on 8 and on 3
+    ranks: every rank attacks its 64 / world utterances as ONE chunk, and the result is the unsharded one bit for
+    bit.  Round 3 cut on multiples of batch_size, which handed rank 0 the whole batch."""
+    assert ShardedAttack(_make("pgd64")).granule() == 1 and ShardedAttack(_make("cw2_64")).granule() == 1
+    x, y = _data(64)
+    for kind, worlds in (("pgd64", (8, 3)), ("cw2_64", (3,))):
+        np.random.seed(77)
+        ref_adv, ref_succ = _make(kind).attack(x, y)
+        for world in worlds:
+            out = str(tmp_path / ("%s_%d.pt" % (kind, world)))
+            mp.spawn(_worker, args=(world, _free_port(), kind, out, 64), nprocs=world, join=True)
+            got = torch.load(out)
+            sizes = [e - s for s, e in shard_bounds(64, world)]
+            assert [sum(c) for c in got["chunks"]] == sizes and max(sizes) - min(sizes) <= 1, (kind, world, got["chunks"])
+            assert all(len(c) == 1 for c in got["chunks"]), "a rank's shard runs as one chunk of min(batch_size, shard)"
+            assert got["succ"] == list(ref_succ) and len(got["succ"]) == 64, (kind, world)
+            assert torch.equal(got["adv"], ref_adv), (kind, world)
+        assert any(ref_succ) and not all(ref_succ), "both outcomes of the success predicate: %s" % kind
+
+
+def test_fakebob_keeps_its_chunks_together():
+    """FAKEBOB's plateau history aliases over the examples of a chunk (attack/FAKEBOB.py:56): the batch cut stays on
+    chunk boundaries; what scales it is QueryShardedModel (below)."""
+    assert ShardedAttack(FAKEBOB(_toy_engine(), batch_size=4, verbose=0)).granule() == 4
+    assert shard_bounds(10, 2, 4) == [(0, 8), (8, 10)]
 
 
 # ---- query sharding (BASELINE.json configs[4]): the rows of every model call split over the ranks --------------
