@@ -251,7 +251,7 @@ def main():
         """Resident inputs + the attack closure of one partition.  sharded: ShardedAttack cuts the batch over the ranks and
         all-gathers the flags itself; otherwise the rank attacks all of (x, y) and the flags are gathered here -- inside
         the timed region either way."""
-        x = torch.from_numpy(np.ascontiguousarray(x_host)).to(dev).unsqueeze(1)
+        x = torch.from_numpy(np.ascontiguousarray(x_host)).to(dev)
         y = torch.from_numpy(np.ascontiguousarray(y_host)).to(dev)
 
         def attack(k, gather=True):

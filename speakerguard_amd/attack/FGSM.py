@@ -150,7 +150,8 @@ class FGSM(Attack):
 
     def _check_inputs(self, x, y):
         lower, upper = -1, 1
-        assert lower <= x.max() < upper, 'generating adversarial examples should be done in [-1, 1) float domain'
+        peak = float(x.max())  # one device round trip (the reference's chained comparison on the tensor makes two)
+        assert lower <= peak < upper, 'generating adversarial examples should be done in [-1, 1) float domain'
         n_audios, n_channels, _ = x.size()
         assert n_channels == 1, 'Only Support Mono Audio'
         assert y.shape[0] == n_audios, 'The number of x and y should be equal'

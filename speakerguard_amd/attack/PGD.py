@@ -27,7 +27,7 @@ class PGD(FGSM):
         self._begin_attack()
         upper = torch.clamp(x + self.epsilon, max=1)   # PGD.py:48-49
         lower = torch.clamp(x - self.epsilon, min=-1)
-        x_ori = x.clone()
+        x_ori = x.clone() if self.num_random_init > 0 else x  # only the restarts overwrite x (PGD.py:58-61)
         best_success_rate = -1
         best_success = None
         best_adver_x = None

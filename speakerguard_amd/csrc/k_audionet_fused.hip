@@ -1,0 +1,520 @@
+// The AudioNet CNN of one pass as TWO launches instead of ~22 ("whole-CNN-per-utterance fused
+// fwd/bwd, channels <= 128: LDS-resident"):
+//   an_cnn_fwd_kernel   5x5 pre-filter -> conv2..conv8 (+ folded BatchNorm, ReLU, MaxPool)     model/audionet_csine.py:176-207
+//   an_cnn_bwd_kernel   d loss/d conv8 pre-activation -> d loss/d features (what autograd derives for the same lines)
+//
+// One block (8 waves, one per CU: the two activation buffers fill the LDS) per (utterance, time slice).  A layer's input sits
+// in LDS -- written there by the previous layer's epilogue, never read back from memory --, its weights stream from the L2
+// (k4-packed: a lane's W operand of a k-group is one coalesced 16-byte load, the whole stack is 0.6 MB and stays
+// L2-resident), its output goes to the other LDS buffer and, for the backward pass's masks, to memory once.  The time
+// axis of an utterance is cut into S slices so that B x S blocks fill the chip at small batches (64 utterances: 4
+// slices); a slice recomputes the halo its receptive field reaches into (1-2 frames per layer, doubled by every pool
+// below), writes only the rows it owns, and S = 1 from 256 utterances up.
+//
+// ARITHMETIC: every output element is the same float32 fmaf chain as in the per-layer kernels (k_conv_gemm.hip,
+// restated in oracle/conv_chain.c): taps ascending, chunks of 32 channels ascending, k-groups of 8 ascending, inside a
+// group 0, 4, 1, 5, 2, 6, 3, 7 (v_mfma_f32_32x32x2_f32 is a sequential fused multiply-add over its two k values); bias,
+// ReLU, pooling, masks as in their epilogues and in an_pool_*_kernel.  So this path is BIT-IDENTICAL to the per-layer
+// launch sequence it replaces (tests/test_gpu_audionet.py compares the two; SG_AN_FUSED=0 selects the old sequence), and
+// a slice's halo rows equal its neighbour's own rows bit for bit: the result does not depend on S.
+//
+// LDS image of an activation tile [rows][C], C in {32, 64, 128}: row-major, the 16-byte slots of a row permuted so that
+// the 16 lanes a ds_read_b128 is served for -- 16 consecutive rows, same channel group -- hit 16 different slots:
+//   C = 32  (128-byte rows: consecutive rows alternate between the two halves of the 64 banks): slot ^ ((row >> 1) & 7)
+//   C >= 64 (rows a multiple of 256 bytes: every row starts at bank 0): slot16 ^ (row & 15) inside each 64-channel piece
+#include "sg_internal.h"
+
+namespace sg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFzThreads = 512, kFzWaves = 8;
+
+__host__ __device__ constexpr int fz_min(int a, int b) { return a < b ? a : b; }
+__host__ __device__ constexpr int fz_max(int a, int b) { return a > b ? a : b; }
+
+template <int C>
+__device__ __forceinline__ int fz_off(int R, int c) {
+    if constexpr (C == 32) return R * 32 + ((((c >> 2) ^ (R >> 1)) & 7) << 2) + (c & 3);
+    else return R * C + (c & ~63) + ((((c >> 2) ^ R) & 15) << 2) + (c & 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Slices.  c0 .. c1: the slice's rows of conv8's output; every other tensor is cut at c * (product of the pool strides
+// above it), the last slice taking the ragged rest -- "own" ranges: what the slice writes to memory (forward) / the rows of
+// d features it produces (backward).  The ranges it has to COMPUTE follow from the taps and pools in between.
+struct AnSlice {
+    int olo[kAnConv], ohi[kAnConv];  // forward: rows of act[l] to compute | backward: rows of d act[l] needed
+    int wlo[kAnConv], whi[kAnConv];  // own rows of act[l]
+    int plo, phi, wplo, wphi;        // the same for the pre-filter output / its gradient
+    int flo, fhi;                    // forward: feature rows to read | backward: own rows of d features
+};
+
+__host__ __device__ inline void an_slice_own(const int* Tout, int Fnet, int S, int s, AnSlice& r) {
+    const int T8 = Tout[kAnConv - 1];
+    const int c0 = (int)((long long)s * T8 / S), c1 = (int)((long long)(s + 1) * T8 / S);
+    const bool last = s == S - 1;
+    int m = 1;
+    for (int l = kAnConv - 1; l >= 0; --l) {
+        if (kAnPool[l]) m *= 2;
+        r.wlo[l] = fz_min(c0 * m, Tout[l]);
+        r.whi[l] = last ? Tout[l] : fz_min(c1 * m, Tout[l]);
+    }
+    r.wplo = fz_min(c0 * m, Fnet);
+    r.wphi = last ? Fnet : fz_min(c1 * m, Fnet);
+}
+
+__host__ __device__ inline void an_slice_fwd(const int* Tin, const int* Tout, int Fnet, int S, int s, AnSlice& r) {
+    an_slice_own(Tout, Fnet, S, s, r);
+    int lo = r.wlo[kAnConv - 1], hi = r.whi[kAnConv - 1];
+    for (int l = kAnConv - 1; l >= 0; --l) {
+        r.olo[l] = lo;
+        r.ohi[l] = hi;
+        const int ilo = fz_max(0, lo - kAnPad[l]), ihi = fz_min(Tin[l], hi - kAnPad[l] + 2);  // valid input rows of conv l
+        if (l > 0) {
+            const int nlo = kAnPool[l - 1] ? 2 * ilo : ilo, nhi = kAnPool[l - 1] ? fz_min(2 * ihi, Tout[l - 1]) : ihi;
+            lo = fz_min(nlo, r.wlo[l - 1]);
+            hi = fz_max(nhi, r.whi[l - 1]);
+        } else {
+            r.plo = fz_min(ilo, r.wplo);
+            r.phi = fz_max(ihi, r.wphi);
+            r.flo = fz_max(0, r.plo - 2);
+            r.fhi = fz_min(Fnet, r.phi + 2);
+        }
+    }
+}
+
+// backward: own rows of d features [flo, fhi) -> rows of d pre, then bottom-up the rows of d act[l] every data gradient
+// needs (d in[t] = sum_j W_j^T d out[t + pad - j]) and through the un-pooling (pooled row p <- rows 2p, 2p + 1)
+__host__ __device__ inline void an_slice_bwd(const int* Tin, const int* Tout, int Fnet, int S, int s, AnSlice& r) {
+    an_slice_own(Tout, Fnet, S, s, r);
+    r.flo = r.wplo;
+    r.fhi = r.wphi;
+    r.plo = fz_max(0, r.flo - 2);
+    r.phi = fz_min(Fnet, r.fhi + 2);
+    int lo = r.plo, hi = r.phi;  // rows of the INPUT of conv l whose gradient is needed
+    for (int l = 0; l < kAnConv; ++l) {
+        r.wlo[l] = lo;  // (re-used: rows of d input-of-l this slice produces)
+        r.whi[l] = hi;
+        r.olo[l] = fz_max(0, lo + kAnPad[l] - 2);
+        r.ohi[l] = fz_min(Tout[l], hi + kAnPad[l]);
+        if (l + 1 < kAnConv) {
+            lo = kAnPool[l] ? r.olo[l] / 2 : r.olo[l];
+            hi = kAnPool[l] ? fz_min((r.ohi[l] + 1) / 2, Tin[l + 1]) : r.ohi[l];
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// acc[mi] += the 32 x 32 output block (rows R0[mi] + lane % 32 of the LDS input for tap offset 0, columns n0 + lane % 32)
+// over 3 taps x K channels.  REV: tap j reads input row + (2 - j) (data gradient), else row + j.
+template <int K, int MI, bool REV>
+__device__ __forceinline__ void fz_mac(const float* __restrict__ in, const float4* __restrict__ wl, int ldw, const int (&R0)[MI],
+                                       f32x16 (&acc)[MI]) {
+    constexpr int NCH = 3 * K / 32, CPT = K / 32;  // chunks of 32 k values; per tap
+    const int lhi = (threadIdx.x & 63) >> 5;
+    float4 wc[4], wn[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) wc[kg] = wl[(size_t)(2 * kg) * ldw];
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        int Rj[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) Rj[mi] = R0[mi] + (REV ? 2 - j : j);
+#pragma unroll
+        for (int kc = 0; kc < CPT; ++kc) {
+            const int ch = j * CPT + kc;
+            // the next chunk's W operands are requested before this chunk's multiplications (past the end: the last chunk again)
+            const int nx = ch + 1 < NCH ? ch + 1 : ch;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) wn[kg] = wl[(size_t)(nx * 8 + 2 * kg) * ldw];
+            float4 a[4][MI];
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[kg][mi] = *reinterpret_cast<const float4*>(in + fz_off<K>(Rj[mi], kc * 32 + 8 * kg + 4 * lhi));
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const float4 w = wc[kg];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const float wb = st == 0 ? w.x : st == 1 ? w.y : st == 2 ? w.z : w.w;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const float4 x = a[kg][mi];
+                        const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wb, acc[mi], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) wc[kg] = wn[kg];
+        }
+    }
+}
+
+// A wave's share of a layer: output column block wn of N / 32, and a contiguous share of the m-tiles, in units of up to
+// three 32-row tiles (one W operand stream feeds all of them).  epi(mi-th tile's first row, acc) consumes a finished tile.
+template <int K, int N, bool REV, typename Epi>
+__device__ __forceinline__ void fz_layer(const float* __restrict__ in, const float* __restrict__ wq, int n_out, Epi&& epi) {
+    constexpr int NT = N / 32, G = kFzWaves / NT;
+    static_assert(NT >= 1 && NT <= kFzWaves && kFzWaves % NT == 0, "column blocks must divide the waves");
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wid % NT, wg = wid / NT;
+    const int mt = (n_out + 31) >> 5;
+    const int m_begin = wg * mt / G, m_end = (wg + 1) * mt / G;
+    const int n0 = wn * 32;
+    const float4* wl = reinterpret_cast<const float4*>(wq) + (size_t)lhi * N + n0 + l31;
+    for (int m = m_begin; m < m_end; m += 3) {
+        const int cnt = min(3, m_end - m);
+        // rows past the layer's last output row are computed on a clamped (valid) input row and dropped by the epilogue
+        if (cnt == 3) {
+            const int R0[3] = {min(m * 32 + l31, n_out - 1), min(m * 32 + 32 + l31, n_out - 1), min(m * 32 + 64 + l31, n_out - 1)};
+            f32x16 acc[3];
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+            fz_mac<K, 3, REV>(in, wl, N, R0, acc);
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) epi((m + mi) * 32, n0, acc[mi]);
+        } else if (cnt == 2) {
+            const int R0[2] = {min(m * 32 + l31, n_out - 1), min(m * 32 + 32 + l31, n_out - 1)};
+            f32x16 acc[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+            fz_mac<K, 2, REV>(in, wl, N, R0, acc);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) epi((m + mi) * 32, n0, acc[mi]);
+        } else {
+            const int R0[1] = {min(m * 32 + l31, n_out - 1)};
+            f32x16 acc[1];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] = 0.f;
+            fz_mac<K, 1, REV>(in, wl, N, R0, acc);
+            epi(m * 32, n0, acc[0]);
+        }
+    }
+}
+
+__device__ __forceinline__ void fz_zero(float* buf, int floats) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x * 4; i < floats; i += kFzThreads * 4) *reinterpret_cast<float4*>(buf + i) = z;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward layer L: input (Cin channels) in `in` -- LDS row 0 = virtual input row olo[L] - pad --, output to memory (own rows)
+// and, for the next layer, to `out` (LDS row 0 = virtual input row olo[L + 1] - pad[L + 1]; rows outside the valid range
+// stay zero: the convolution's zero padding)
+template <int L>
+__device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice& r, int row, const float* in, float* out) {
+    constexpr int CIN = kAnCin[L], COUT = kAnCout[L];
+    constexpr bool POOL = kAnPool[L], LAST = L == kAnConv - 1;
+    constexpr int CNEXT = LAST ? 32 : kAnCin[L + 1 < kAnConv ? L + 1 : L];
+    const int olo = r.olo[L], n_out = r.ohi[L] - r.olo[L], Tout = p.Tout[L];
+    int nbase = 0, nrows = 0;  // the next layer's LDS window in its virtual input rows
+    if constexpr (!LAST) {
+        nbase = r.olo[L + 1] - kAnPad[L + 1];
+        nrows = r.ohi[L + 1] - r.olo[L + 1] + 2;
+        fz_zero(out, nrows * CNEXT);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+    float* act = p.act[L] + (size_t)row * Tout * COUT;
+    float* pool = POOL ? p.pool[L] + (size_t)row * (Tout / 2) * COUT : nullptr;
+    const float* bias = p.bias[L];
+    const int wlo = r.wlo[L], whi = r.whi[L];
+    fz_layer<CIN, COUT, false>(in, p.wq[L], n_out, [&](int m0, int n0, const f32x16& acc) __attribute__((always_inline)) {
+        const int col = n0 + l31;
+        const float bv = bias[col];
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = fmaxf(acc[e] + bv, 0.f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;  // row relative to olo
+            const int t = olo + ro;
+            if (ro < n_out && t >= wlo && t < whi) act[(size_t)t * COUT + col] = v[e];
+            if constexpr (!POOL && !LAST) {
+                const int q = t - nbase;
+                if (ro < n_out && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = v[e];
+            }
+        }
+        if constexpr (POOL) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {  // rows t, t + 1 (olo is even): MaxPool1d(2)
+                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                const int t = olo + ro, pr = t >> 1;
+                if (ro + 1 < n_out && pr < Tout / 2) {
+                    const float pv = fmaxf(v[e], v[e + 1]);
+                    if (t >= wlo && t < whi) pool[(size_t)pr * COUT + col] = pv;
+                    const int q = pr - nbase;
+                    if (q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = pv;
+                }
+            }
+        }
+    });
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
+    float* bufA = fz_lds;
+    float* bufB = fz_lds + p.buf_floats;
+    const int row = blockIdx.y;
+    AnSlice r;
+    an_slice_fwd(p.Tin, p.Tout, p.Fnet, p.S, blockIdx.x, r);
+    // ---- 5x5 pre-filter: feature rows [flo, fhi) -> bufB (plain [rows][32]); pre rows [plo, phi) -> memory (own rows) and
+    //      bufA as conv2's input window
+    const int F = p.Fnet, nf = r.fhi - r.flo;
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.feats + ((size_t)row * F + r.flo) * 32);
+        for (int i = threadIdx.x; i < nf * 8; i += kFzThreads) reinterpret_cast<float4*>(bufB)[i] = src[i];
+    }
+    const int base0 = r.olo[0] - kAnPad[0], rows0 = r.ohi[0] - r.olo[0] + 2;
+    fz_zero(bufA, rows0 * 32);
+    __syncthreads();
+    {
+        float w[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) w[i] = p.w25[i];
+        float* pre = p.pre + (size_t)row * F * 32;
+        for (int idx = threadIdx.x; idx < (r.phi - r.plo) * 32; idx += kFzThreads) {
+            const int t = r.plo + (idx >> 5), m = idx & 31;
+            float acc = p.pre_bias;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {      // mel offset
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {  // time offset
+                    const int mm = m + i - 2, tt = t + j - 2;
+                    const bool ok = mm >= 0 && mm < kAnMel && tt >= 0 && tt < F;
+                    const float v = bufB[(min(max(tt, r.flo), r.fhi - 1) - r.flo) * 32 + min(max(mm, 0), kAnMel - 1)];
+                    acc += w[i * 5 + j] * (ok ? v : 0.f);
+                }
+            }
+            if (t >= r.wplo && t < r.wphi) pre[(size_t)t * 32 + m] = acc;
+            const int q = t - base0;
+            if (q >= 0 && q < rows0) bufA[fz_off<32>(q, m)] = acc;
+        }
+    }
+    __syncthreads();
+    fz_fwd_layer<0>(p, r, row, bufA, bufB);
+    fz_fwd_layer<1>(p, r, row, bufB, bufA);
+    fz_fwd_layer<2>(p, r, row, bufA, bufB);
+    fz_fwd_layer<3>(p, r, row, bufB, bufA);
+    fz_fwd_layer<4>(p, r, row, bufA, bufB);
+    fz_fwd_layer<5>(p, r, row, bufB, bufA);
+    fz_fwd_layer<6>(p, r, row, bufA, bufB);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward layer L: d act[L] (Cout channels) in `in` -- LDS row 0 = row olo[L] + pad - 2 ... i.e. the window of rows
+// [wlo[L] + pad - 2, whi[L] + pad) of d act[L], zero outside the tensor --; the data gradient gives d (input of conv L)
+// rows [wlo[L], whi[L]); un-pooled / masked with the forward activations it becomes d act[L - 1] in `out` (LDS window
+// of the next data gradient), or d pre for L = 0.
+template <int L>
+__device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice& r, int row, const float* in, float* out) {
+    constexpr int K = kAnCout[L], N = kAnCin[L];
+    constexpr bool FIRST = L == 0;
+    constexpr bool INPOOL = !FIRST && kAnPool[L > 0 ? L - 1 : 0];  // conv L reads the pooled output of block L - 1
+    const int ilo = r.wlo[L], n_out = r.whi[L] - r.wlo[L];          // rows of d input-of-L to produce
+    // next window: rows [wlo[L-1] + pad[L-1] - 2, ...) of d act[L - 1]; for L = 0: d pre rows [plo, phi) plain window
+    int nbase, nrows;
+    if constexpr (FIRST) {
+        nbase = r.plo;
+        nrows = r.phi - r.plo;
+    } else {
+        nbase = r.wlo[L - 1] + kAnPad[L - 1] - 2;
+        nrows = r.whi[L - 1] - r.wlo[L - 1] + 2;
+    }
+    fz_zero(out, nrows * N);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int Tprev = FIRST ? p.Fnet : p.Tout[L > 0 ? L - 1 : 0];
+    const float* aprev = FIRST ? nullptr : p.act[L > 0 ? L - 1 : 0] + (size_t)row * Tprev * N;
+    fz_layer<K, N, true>(in, p.wq[L], n_out, [&](int m0, int n0, const f32x16& acc) __attribute__((always_inline)) {
+        const int col = n0 + l31;
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                const int q = ilo + ro - nbase;
+                if (ro < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = acc[e];
+            }
+        } else if constexpr (INPOOL) {
+            // pooled row pr <- rows 2 pr (first maximum wins a tie, like torch) / 2 pr + 1 of act[L - 1], ReLU mask applied
+            float a0[16], a1[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pr = min(ilo + m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi, Tprev / 2 - 1);
+                a0[e] = aprev[(size_t)(2 * pr) * N + col];
+                a1[e] = aprev[(size_t)(2 * pr + 1) * N + col];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                const int pr = ilo + ro;
+                if (ro < n_out && pr < Tprev / 2) {
+                    const bool first = !(a1[e] > a0[e]);
+                    const float g0 = (first && a0[e] > 0.f) ? acc[e] : 0.f, g1 = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
+                    const int q = 2 * pr - nbase;
+                    if (q >= 0 && q < nrows) out[fz_off<N>(q, col)] = g0;
+                    if (q + 1 >= 0 && q + 1 < nrows) out[fz_off<N>(q + 1, col)] = g1;
+                }
+            }
+        } else {
+            float mk[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mk[e] = aprev[(size_t)min(ilo + m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi, Tprev - 1) * N + col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                const int q = ilo + ro - nbase;
+                if (ro < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = mk[e] > 0.f ? acc[e] : 0.f;
+            }
+        }
+    });
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
+    float* bufA = fz_lds;
+    float* bufB = fz_lds + p.buf_floats;
+    const int row = blockIdx.y;
+    AnSlice r;
+    an_slice_bwd(p.Tin, p.Tout, p.Fnet, p.S, blockIdx.x, r);
+    // ---- d act[6] window from memory: rows [wlo[6] + pad - 2, whi[6] + pad) of (T8, 32), zero outside
+    {
+        constexpr int L = kAnConv - 1;
+        const int T8 = p.Tout[L], base = r.wlo[L] + kAnPad[L] - 2, rows = r.whi[L] - r.wlo[L] + 2;
+        fz_zero(bufA, rows * 32);
+        __syncthreads();
+        const float* src = p.dtop + (size_t)row * T8 * 32;
+        for (int idx = threadIdx.x; idx < rows * 32; idx += kFzThreads) {
+            const int q = idx >> 5, c = idx & 31, t = base + q;
+            if (t >= 0 && t < T8) bufA[fz_off<32>(q, c)] = src[(size_t)t * 32 + c];
+        }
+        __syncthreads();
+    }
+    fz_bwd_layer<6>(p, r, row, bufA, bufB);
+    fz_bwd_layer<5>(p, r, row, bufB, bufA);
+    fz_bwd_layer<4>(p, r, row, bufA, bufB);
+    fz_bwd_layer<3>(p, r, row, bufB, bufA);
+    fz_bwd_layer<2>(p, r, row, bufA, bufB);
+    fz_bwd_layer<1>(p, r, row, bufB, bufA);
+    fz_bwd_layer<0>(p, r, row, bufA, bufB);
+    // ---- transposed 5x5 pre-filter: d pre rows [plo, phi) in bufB (swizzled [rows][32]) -> own rows of d features
+    {
+        float w[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) w[i] = p.w25[i];
+        const int F = p.Fnet, np = r.phi - r.plo;
+        float* dst = p.dfeats + (size_t)row * F * 32;
+        for (int idx = threadIdx.x; idx < (r.fhi - r.flo) * 32; idx += kFzThreads) {
+            const int t = r.flo + (idx >> 5), m = idx & 31;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int mm = m - i + 2, tt = t - j + 2;
+                    const bool ok = mm >= 0 && mm < kAnMel && tt >= 0 && tt < F;
+                    const int q = min(max(tt - r.plo, 0), np - 1);
+                    const float v = bufB[fz_off<32>(q, min(max(mm, 0), kAnMel - 1))];
+                    acc += w[i * 5 + j] * (ok ? v : 0.f);
+                }
+            }
+            dst[(size_t)t * 32 + m] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host side: slices per utterance and LDS demand.
+static int fz_plan(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus, int* S_out, int* buf_floats_out) {
+    const int T8 = Tout[kAnConv - 1];
+    if (T8 < 1) return -1;
+    const int cus = num_cus > 0 ? num_cus : 256;
+    auto demand = [&](int S) {
+        int need = 0;
+        for (int s = 0; s < S; ++s) {
+            AnSlice f, b;
+            an_slice_fwd(Tin, Tout, Fnet, S, s, f);
+            an_slice_bwd(Tin, Tout, Fnet, S, s, b);
+            need = std::max(need, (f.fhi - f.flo) * 32);
+            need = std::max(need, (b.phi - b.plo) * 32);
+            for (int l = 0; l < kAnConv; ++l) {
+                need = std::max(need, (f.ohi[l] - f.olo[l] + 2) * kAnCin[l]);   // forward input window of conv l
+                need = std::max(need, (b.whi[l] - b.wlo[l] + 2) * kAnCout[l]);  // backward: d act[l] window
+            }
+        }
+        return (need + 3) & ~3;
+    };
+    // cost model: rounds of blocks on the chip x rows a block works on (its share + ~4 rows of halo, in conv8 rows)
+    int best = 0;
+    double best_cost = 0.0;
+    const int smax = std::min(T8, 16);
+    constexpr int kLdsBudget = 160 * 1024 - 512;
+    for (int S = 1; S <= smax; ++S) {
+        if ((size_t)demand(S) * 2 * sizeof(float) > (size_t)kLdsBudget) continue;
+        const long blocks = (long)rows * S;
+        const double cost = (double)((blocks + cus - 1) / cus) * ((double)T8 / S + 4.0);
+        if (!best || cost < best_cost - 1e-9) {
+            best = S;
+            best_cost = cost;
+        }
+    }
+    if (!best) return -1;  // even the finest cut does not fit (very long utterances): the per-layer path takes over
+    *S_out = best;
+    *buf_floats_out = demand(best);
+    return 0;
+}
+
+bool an_fused_supported(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus) {
+    int S, bf;
+    return fz_plan(Tin, Tout, Fnet, rows, num_cus, &S, &bf) == 0;
+}
+
+hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backward, int force_slices, hipStream_t s) {
+    int S = 0, bf = 0;
+    if (fz_plan(a.Tin, a.Tout, a.Fnet, rows, num_cus, &S, &bf) != 0) return hipErrorNotSupported;
+    if (force_slices > 0) {  // tests: the result must not depend on the cut
+        const int keep = S;
+        S = std::min(force_slices, a.Tout[kAnConv - 1]);
+        int need = 0;
+        for (int sl = 0; sl < S; ++sl) {
+            AnSlice f, b;
+            an_slice_fwd(a.Tin, a.Tout, a.Fnet, S, sl, f);
+            an_slice_bwd(a.Tin, a.Tout, a.Fnet, S, sl, b);
+            need = std::max(need, std::max((f.fhi - f.flo) * 32, (b.phi - b.plo) * 32));
+            for (int l = 0; l < kAnConv; ++l)
+                need = std::max(need, std::max((f.ohi[l] - f.olo[l] + 2) * kAnCin[l], (b.whi[l] - b.wlo[l] + 2) * kAnCout[l]));
+        }
+        bf = (need + 3) & ~3;
+        if ((size_t)bf * 2 * sizeof(float) > 160 * 1024 - 512) {
+            S = keep;
+            if (fz_plan(a.Tin, a.Tout, a.Fnet, rows, num_cus, &S, &bf) != 0) return hipErrorNotSupported;
+        }
+    }
+    a.S = S;
+    a.buf_floats = bf;
+    const size_t lds = (size_t)bf * 2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(an_cnn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(an_cnn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (backward) hipLaunchKernelGGL(an_cnn_bwd_kernel, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    else hipLaunchKernelGGL(an_cnn_fwd_kernel, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace sg

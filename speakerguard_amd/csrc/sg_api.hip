@@ -472,6 +472,7 @@ void sg_destroy(sg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     free_pool(ctx->ws.allocs);
+    free_pool(ctx->an_ws.allocs);  // (leaked until round 4: found by the sanitizer build's leak check, `make asan`)
     free_pool(ctx->xv.allocs);
     free_pool(ctx->model_allocs);
     if (ctx->err_host) (void)hipHostFree(ctx->err_host);
@@ -727,8 +728,13 @@ int sg_xv_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t c
     if (channels) *channels = kCoutPad[l];
     if (out_dev) {
         if (capacity_floats <= 0) return fail(ctx, SG_ERR_ARG, "capacity must be positive");
-        SG_HIP(hipMemcpyAsync(out_dev, w.act[l], (size_t)capacity_floats * sizeof(float), hipMemcpyDeviceToDevice,
-                              (hipStream_t)stream));
+        // never read past the activation buffer: a caller's capacity may exceed what the workspace holds (found by the
+        // sanitizer build, `make asan`)
+        int cap_fl[kLayers];
+        layer_frames(w.F, cap_fl);
+        const size_t held = (size_t)w.B * (size_t)(cap_fl[l] > 0 ? cap_fl[l] : 1) * kCoutPad[l];
+        const size_t n = std::min<size_t>((size_t)capacity_floats, held);
+        SG_HIP(hipMemcpyAsync(out_dev, w.act[l], n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return SG_OK;
 }
@@ -740,6 +746,7 @@ int sg_xv_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     int rc = check_dims(ctx, B, T_or_F, flag, &d);
     if (rc) return rc;
     if (!x_dev || !y_dev || !loss) return fail(ctx, SG_ERR_ARG, "x, y and loss are required");
+    if (loss->loss == SG_LOSS_LINEAR && !loss->coef_dev) return fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
     hipStream_t s = (hipStream_t)stream;
     if ((rc = run_frontend(ctx, x_dev, d, flag, dither, grad_dev != nullptr, s))) return rc;
     if ((rc = run_tdnn_forward(ctx, d, s))) return rc;
@@ -822,6 +829,7 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p) return fail(ctx, SG_ERR_ARG, "NULL argument");
     if (B < 1 || T < kWin) return fail(ctx, SG_ERR_ARG, "need B >= 1 and a waveform of at least one 25 ms window");
     if (p->max_iter < 0) return fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
+    if (p->loss.loss == SG_LOSS_LINEAR && !p->loss.coef_dev) return fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
     const int eot_size = p->eot_size > 0 ? p->eot_size : 1, eot_bs = p->eot_batch_size > 0 ? p->eot_batch_size : 1;
     if (eot_size % eot_bs) return fail(ctx, SG_ERR_ARG, "EOT size should be divisible by EOT batch size");
     // Expectation over the front-end's random dither (adaptive_attack/EOT.py:16-54; the reference hard-codes

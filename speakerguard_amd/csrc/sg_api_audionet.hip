@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "sg_internal.h"
 
@@ -246,10 +247,47 @@ int an_frontend_forward(sg_ctx* ctx, const float* x, const AnDims& d, hipStream_
 
 // features (B, Fnet, 32) -> conv stack; Fnet is the frame count the network sees (the front-end's, or the number of
 // FeCo clusters when the defense sits between front-end and network)
+// SG_AN_FUSED=0: the per-layer launch sequence of rounds 1-3 (the fused kernels' bit-exact counterpart: tests compare the
+// two); SG_AN_SLICES=n: n time slices per utterance instead of the planner's choice.  Read per call (tests flip them).
+bool an_use_fused(sg_ctx* ctx, int rows, int Fnet) {
+    const char* e = getenv("SG_AN_FUSED");
+    if (e && atoi(e) == 0) return false;
+    const AnWorkspace& w = ctx->an_ws;
+    return an_fused_supported(w.Tin, w.Tout, Fnet, rows, ctx->num_cus);
+}
+int an_forced_slices() {
+    const char* e = getenv("SG_AN_SLICES");
+    return e ? atoi(e) : 0;
+}
+AnFusedArgs an_fused_args(sg_ctx* ctx, int Fnet) {
+    AnWorkspace& w = ctx->an_ws;
+    const AnModel& m = ctx->an;
+    AnFusedArgs a{};
+    a.pre = w.pre;
+    for (int l = 0; l < kAnConv; ++l) {
+        a.act[l] = w.act[l];
+        a.pool[l] = w.pool[l];
+        a.bias[l] = m.bias[l];
+        a.Tin[l] = w.Tin[l];
+        a.Tout[l] = w.Tout[l];
+    }
+    a.w25 = m.w25;
+    a.pre_bias = m.pre_bias;
+    a.Fnet = Fnet;
+    return a;
+}
+
 int an_net_forward(sg_ctx* ctx, const float* feats, int B, int Fnet, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
     an_layer_frames(Fnet, w.Tin, w.Tout);
+    if (an_use_fused(ctx, B, Fnet)) {
+        AnFusedArgs a = an_fused_args(ctx, Fnet);
+        a.feats = feats;
+        for (int l = 0; l < kAnConv; ++l) a.wq[l] = m.wfq[l];
+        AN_STAGE(SG_STAGE_AN_FUSED_FWD, launch_an_cnn_fused(a, B, ctx->num_cus, false, an_forced_slices(), s));
+        return SG_OK;
+    }
     AN_STAGE(SG_STAGE_AN_PREFILTER_FWD, launch_an_prefilter(feats, w.pre, B, Fnet, m.w25, m.pre_bias, 0, s));
     for (int l = 0; l < kAnConv; ++l) {
         ConvGemmArgs a{};
@@ -270,7 +308,7 @@ int an_net_forward(sg_ctx* ctx, const float* feats, int B, int Fnet, hipStream_t
         a.tap_base = -kAnPad[l];
         a.total_chunks = 3 * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
-        a.Wq = m.wfq[l];
+        a.Wq = a.N % 128 == 0 ? m.wfq[l] : nullptr;
         AN_STAGE(SG_STAGE_AN_CONV_FWD + l, launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, EPI_BIAS_RELU, 1, s));
         if (kAnPool[l]) AN_STAGE(SG_STAGE_AN_POOL_FWD, launch_an_pool_fwd(w.act[l], w.pool[l], B, w.Tout[l], kAnCout[l], s));
     }
@@ -291,6 +329,14 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
 int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
+    if (an_use_fused(ctx, B, Fnet)) {
+        AnFusedArgs a = an_fused_args(ctx, Fnet);
+        a.dtop = w.dact[kAnConv - 1];
+        a.dfeats = dfeats_out;
+        for (int l = 0; l < kAnConv; ++l) a.wq[l] = m.wbq[l];
+        AN_STAGE(SG_STAGE_AN_FUSED_BWD, launch_an_cnn_fused(a, B, ctx->num_cus, true, an_forced_slices(), s));
+        return SG_OK;
+    }
     for (int l = kAnConv - 1; l >= 0; --l) {
         // data gradient of conv l: reads dact[l] (B, Tout, Cout), writes the gradient of its input
         const bool in_pooled = l > 0 && kAnPool[l - 1];
@@ -312,7 +358,7 @@ int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t
         a.tap_base = kAnPad[l];  // d in[t] = sum_j W_j^T d out[t + pad - j]
         a.total_chunks = 3 * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
-        a.Wq = m.wbq[l];
+        a.Wq = a.N % 128 == 0 ? m.wbq[l] : nullptr;
         AN_STAGE(SG_STAGE_AN_CONV_BWD + l, launch_conv_gemm(a, a.N % 128 == 0 ? 2 : 1, a.mask ? EPI_RELU_MASK : EPI_NONE, 1, s));
         if (in_pooled)
             AN_STAGE(SG_STAGE_AN_POOL_BWD, launch_an_pool_bwd(w.act[l - 1], w.dpool[l - 1], w.dact[l - 1], B, w.Tout[l - 1], kAnCout[l - 1], s));
@@ -393,8 +439,10 @@ int sg_an_load(sg_ctx* ctx, const sg_an_weights* w) {
                 for (int n = 0; n < N; ++n) q[((size_t)(k / 4) * N + n) * 4 + (k & 3)] = w[(size_t)k * N + n];
             return q;
         };
-        if (cout % 128 == 0) rc |= an_upload(ctx, pool, &m.wfq[l], packed(wf, 3 * cin, cout));
-        if (cin % 128 == 0) rc |= an_upload(ctx, pool, &m.wbq[l], packed(wb, 3 * cout, cin));
+        // (every layer: the fused CNN kernels take all their weights k4-packed; the per-layer sequence uses the packed copy
+        // where its quad-fed tile kernel applies, N % 128 == 0)
+        rc |= an_upload(ctx, pool, &m.wfq[l], packed(wf, 3 * cin, cout));
+        rc |= an_upload(ctx, pool, &m.wbq[l], packed(wb, 3 * cout, cin));
         rc |= an_upload(ctx, pool, &m.bias[l], bias);
     }
     rc |= an_upload(ctx, pool, &m.fc_w, std::vector<float>(w->fc_weight, w->fc_weight + (size_t)w->num_class * 32));
@@ -478,7 +526,9 @@ int sg_an_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t c
     if (channels) *channels = ch;
     if (out_dev) {
         if (capacity_floats <= 0) return an_fail(ctx, SG_ERR_ARG, "capacity must be positive");
-        AN_HIP(hipMemcpyAsync(out_dev, src, (size_t)capacity_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        const size_t held = (size_t)w.B * (size_t)(rows > 0 ? rows : 1) * ch;  // never read past what the workspace holds
+        const size_t n = (size_t)capacity_floats < held ? (size_t)capacity_floats : held;
+        AN_HIP(hipMemcpyAsync(out_dev, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return SG_OK;
 }
@@ -490,6 +540,7 @@ int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     int rc = an_check(ctx, B, T_or_F, flag, &d);
     if (rc) return rc;
     if (!x_dev || !y_dev || !loss) return an_fail(ctx, SG_ERR_ARG, "x, y and loss are required");
+    if (loss->loss == SG_LOSS_LINEAR && !loss->coef_dev) return an_fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
     hipStream_t s = (hipStream_t)stream;
     if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
     AnWorkspace& w = ctx->an_ws;
@@ -509,6 +560,7 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     if (rc) return rc;
     if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p) return an_fail(ctx, SG_ERR_ARG, "NULL argument");
     if (p->max_iter < 0) return an_fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
+    if (p->loss.loss == SG_LOSS_LINEAR && !p->loss.coef_dev) return an_fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
     hipStream_t s = (hipStream_t)stream;
     AnWorkspace& w = ctx->an_ws;
     const int L = kAnConv - 1;
@@ -536,6 +588,7 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
     if (!ctx) return SG_ERR_ARG;
     if (!x_adv_dev || !y_dev || !lower_dev || !upper_dev || !p || !f) return an_fail(ctx, SG_ERR_ARG, "NULL argument");
     if (p->max_iter < 0) return an_fail(ctx, SG_ERR_ARG, "max_iter must be >= 0");
+    if (p->loss.loss == SG_LOSS_LINEAR && !p->loss.coef_dev) return an_fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
     // defense/feature_level.py:33: with a single utterance the reference DROPS empty clusters (variable frame count);
     // that case stays on the host-chained path (model/defended_model.py)
     if (B < 2) return an_fail(ctx, SG_ERR_ARG, "the fused FeCo loop needs a batch of at least 2 utterances");

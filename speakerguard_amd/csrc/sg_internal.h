@@ -327,6 +327,27 @@ hipError_t launch_loss_eval(const float* scores, const int64_t* y, int B, int S,
 hipError_t launch_eot_trace_reduce(const float* loss_rows, const int64_t* dec_rows, int R, int B, float* loss_out,
                                    int64_t* dec_out, hipStream_t s);
 
+// the AudioNet CNN of one pass in one launch per direction (k_audionet_fused.hip)
+struct AnFusedArgs {
+    // forward
+    const float* feats;        // (rows, Fnet, 32)
+    float* pre;                // (rows, Fnet, 32)
+    float* act[kAnConv];       // (rows, Tout, Cout) ReLU outputs
+    float* pool[kAnConv];      // (rows, Tout / 2, Cout) where the block has a MaxPool
+    const float* wq[kAnConv];  // k4-packed weights of the direction: [3 K / 4][N][4]
+    const float* bias[kAnConv];
+    const float* w25;
+    float pre_bias;
+    // backward
+    const float* dtop;         // (rows, Tout[6], 32) d loss / d conv8 pre-activation
+    float* dfeats;             // (rows, Fnet, 32)
+    int Fnet, S, buf_floats;
+    int Tin[kAnConv], Tout[kAnConv];
+};
+// false: the utterance is too long for the LDS-resident form even in its finest cut (the per-layer sequence runs)
+bool an_fused_supported(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus);
+// force_slices > 0: that many time slices per utterance instead of the planner's choice (tests: same bits for any cut)
+hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backward, int force_slices, hipStream_t s);
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 hipStream_t s);
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,

@@ -74,6 +74,21 @@ class EngineOps:
         stream-K hand-off wait that timed out).  No synchronisation: call it once the results were awaited."""
         self.ctx.call("sg_health")
 
+    def trace_stages(self, fn, max_records=4096):
+        """Run fn() with the library's stage trace on (sg_trace_begin / sg_trace_end: a HIP-event pair around every launch
+        of the pass sequences, on the launch stream) and return [(stage name, milliseconds)] in launch order.  Measurement
+        aid (bench.py `roofline`); the events cost a few microseconds per launch, so trace a run of its own."""
+        self.ctx.call("sg_trace_begin", int(max_records))
+        try:
+            fn()
+        finally:
+            tags = (C.c_int32 * max_records)()
+            ms = (C.c_float * max_records)()
+            n = C.c_int32()
+            self.ctx.call("sg_trace_end", tags, ms, int(max_records), C.byref(n))
+        k = min(n.value, max_records)
+        return [(N.STAGE_NAMES.get(tags[i], str(tags[i])), float(ms[i])) for i in range(k)]
+
     def pgd_update(self, x, grad, lower, upper, step_size, grad_sign):
         """x <- min(max(x + step*sign(grad)*grad_sign, lower), upper) in place (attack/FGSM.py:65,68)."""
         self.ctx.call("sg_pgd_update", N._ptr(x), N._ptr(grad), N._ptr(lower), N._ptr(upper), x.numel(),

@@ -379,18 +379,4 @@ class xv_plda(EngineOps):
         self.ctx.call("sg_xv_time_layer", layer, B, T, iters, C.byref(ms), C.byref(fl), C.byref(rows), self._stream())
         return ms.value, fl.value, rows.value
 
-    def trace_stages(self, fn, max_records=4096):
-        """Run fn() with the library's stage trace on (sg_trace_begin / sg_trace_end: a HIP-event pair around every launch
-        of the pass sequences, on the launch stream) and return [(stage name, milliseconds)] in launch order.  Measurement
-        aid (bench.py `roofline`); the events cost a few microseconds per launch, so trace a run of its own."""
-        self.ctx.call("sg_trace_begin", int(max_records))
-        try:
-            fn()
-        finally:
-            tags = (C.c_int32 * max_records)()
-            ms = (C.c_float * max_records)()
-            n = C.c_int32()
-            self.ctx.call("sg_trace_end", tags, ms, int(max_records), C.byref(n))
-        k = min(n.value, max_records)
-        return [(N.STAGE_NAMES.get(tags[i], str(tags[i])), float(ms[i])) for i in range(k)]
 

@@ -258,3 +258,58 @@ def test_logmel_backward_reusing_the_forward_pass(hip, dev):
     g_other = bwd(other, 1)
     assert torch.equal(g_other, bwd(other, 0))
     assert not torch.allclose(g_other, g_plain)
+
+
+@pytest.mark.parametrize("B,T", [(3, 48000), (2, 20011), (64, 48000), (1, 16000), (5, 65000)])
+def test_fused_cnn_equals_the_per_layer_sequence_bit_for_bit(hip, dev, monkeypatch, B, T):
+    """Round 4: the AudioNet CNN of a pass as ONE launch per direction (k_audionet_fused.hip: LDS-resident
+    activations, time slices with recomputed halos) against the ~22 per-layer launches of rounds 1-3 (SG_AN_FUSED=0), which
+    stay in the library as its counterpart.  Same fmaf chain per output element: every activation, the logits, the
+    decisions, the loss and d loss/d waveform and d loss/d log-mel must be EQUAL, for the planner's cut and for forced cuts
+    into 1 / 2 / 3 / 5 / 7 time slices (the result does not depend on the cut, i.e. on the batch size either)."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    x = torch.from_numpy(synth.make_waveforms(B, T, seed=60 + B)).to(dev)
+    y = (torch.arange(B, device=dev) * 7) % 251
+    ce = SEC4SR_CrossEntropy()
+
+    def run():
+        dec, sc, ls, g = hip.loss_grad(x, y, ce)
+        acts = [hip.read_activation(i, B).clone() for i in range(1, 9)]
+        feats = hip.compute_feat(x)
+        d1, s1, l1, g1 = hip.loss_grad(feats, y, ce, flag=1)
+        return [dec, sc, ls, g, d1, s1, l1, g1] + acts
+
+    monkeypatch.setenv("SG_AN_FUSED", "0")
+    ref = run()
+    monkeypatch.setenv("SG_AN_FUSED", "1")
+    names = ["decisions", "scores", "loss", "d/d wav", "decisions(feat)", "scores(feat)", "loss(feat)", "d/d log-mel"] + ["layer %d" % i for i in range(1, 9)]
+    for slices in (0, 1, 2, 3, 5, 7):
+        if slices:
+            monkeypatch.setenv("SG_AN_SLICES", str(slices))
+        got = run()
+        for n, a, b in zip(names, got, ref):
+            assert a.shape == b.shape, (n, slices)
+            assert torch.equal(a, b), "%s differs with %s slices: max |diff| %.3e" % (n, slices or "planned", (a.float() - b.float()).abs().max().item())
+    monkeypatch.delenv("SG_AN_SLICES")
+    assert float(ref[3].abs().max()) > 0
+    log("audionet fused CNN (B=%d, T=%d): forward activations, logits, loss, d/d wav, d/d log-mel equal the per-layer sequence bit for bit "
+        "(planned cut and 1/2/3/5/7 slices)" % (B, T))
+
+
+def test_fused_cnn_is_the_path_that_runs(hip, dev, monkeypatch):
+    """The stage trace names what ran: one fused launch per direction and no per-layer contraction with the default
+    setting; the per-layer tags with SG_AN_FUSED=0."""
+    from speakerguard_amd import _native as N
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    x = torch.from_numpy(synth.make_waveforms(4, 48000, seed=77)).to(dev)
+    y = torch.zeros(4, dtype=torch.int64, device=dev)
+    for fused in (1, 0):
+        monkeypatch.setenv("SG_AN_FUSED", str(fused))
+        recs = hip.trace_stages(lambda: hip.loss_grad(x, y, SEC4SR_CrossEntropy()), max_records=256)
+        tags = [t for t, _ in recs]
+        if fused:
+            assert tags.count("an_cnn_fwd") == 1 and tags.count("an_cnn_bwd") == 1 and not any(t.startswith("an_conv") for t in tags), tags
+        else:
+            assert "an_cnn_fwd" not in tags and sum(t.startswith("an_conv") for t in tags) == 14, tags

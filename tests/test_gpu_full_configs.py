@@ -244,3 +244,148 @@ def test_pgd_random_restarts_on_the_engine(hip_model, oracle_model):
     _compare("PGD-4 with 3 random restarts x 8 x 2 s", x, adv, succ, oadv, osucc,
              lambda a: hip_model.make_decision(a)[0], lambda a: oracle_model.make_decision(a)[0], eps, K, want_mixed=False)
     log("  success counts of the three restarts on the engine: %s (returned: restart %d)" % ([r[0] for r in rates], best))
+
+
+# ---- round 4: the metric's EXACT shapes inside the driver-run suite ("Next round" item 6) -----------------------
+def test_config1_exact_metric_pgd20(hip_model, oracle_model):
+    """BASELINE.json's metric as written and as bench.py times it: PGD-**20**, eps 0.002, step 0.0004, cross-entropy,
+    untargeted, labels arange % 10, 64 utterances x 3 s, dither off -- HIP device loop vs the oracle (rounds 2-3 ran this
+    shape as a one-off outside the suite; the suite had PGD-5).  Every utterance is fooled at these parameters on both
+    sides, so the mixed-outcome assertion is off here (the two PGD-5 tests above carry it)."""
+    from oracle import attacks as oatk
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    eps, step, K, B = 0.002, 0.0004, 20, 64
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=1234))
+    y = torch.arange(B) % 10
+    adv, succ = PGD(hip_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0).attack(x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.PGD(oracle_model, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B).attack(x, y)
+    _compare("configs[1] EXACT: PGD-20 x 64 x 3 s, eps 0.002", x, adv, succ, oadv, osucc,
+             lambda a: hip_model.make_decision(a)[0], lambda a: oracle_model.make_decision(a)[0], eps, K, want_mixed=False)
+    # the same audio scored by both models: the scores themselves agree (the trajectories end at different points of the
+    # eps-ball -- sign() feeds round-off back -- so scores on OWN audio are not comparable, DESIGN.md section 2)
+    with torch.no_grad():
+        osc = oracle_model.make_decision(adv.cpu())[1]
+    hsc = hip_model.make_decision(adv)[1].cpu()
+    assert (hsc - osc).abs().max().item() < 2e-2 * max(1.0, osc.abs().max().item() / 100.0)
+
+
+def test_config1_full_size_with_the_reference_default_dither(xv_weights):
+    """The reference's front-end as it ships: dither = 1.0 (xv_plda.py:119).  PGD-5 x 64 x 3 s through the device loop
+    with the engine's own in-kernel noise (Philox keyed by global utterance, frame, sample and pass) against the oracle
+    fed THE SAME noise as explicit tensors (oracle/philox.py restates the streams; the generator is pinned by the
+    Random123 vectors): flags and ids equal, perturbation within the stated tolerance -- the full-size case with
+    dither != 0 the round-3 review found missing."""
+    from oracle import attacks as oatk
+    from oracle import kaldi_mfcc, philox
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.xv_plda import xv_plda
+    eps, step, K, B, T = 0.0005, 0.0001, 5, 64, 48000
+    hip = xv_plda.from_weights(xv_weights, device=DEV, dither=1.0, dither_seed=21)
+    ora = XvPlda(xv_weights, faithful=False, freeze=True)
+    F = kaldi_mfcc.num_frames(T)
+    x = torch.from_numpy(synth.make_waveforms(B, T, seed=1234))
+    y = hip_clean = None
+    quiet = xv_plda.from_weights(xv_weights, device=DEV, dither=0.0)
+    y = quiet.make_decision(x.to(DEV))[0].cpu()  # labels: the clean decisions of the noise-free model
+
+    atk = PGD(hip, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0)
+    adv, succ = atk.attack(x.to(DEV), y.to(DEV))
+    base = hip.last_fused_seed  # generator key of the fused call; pass `it` uses fused_pass_seed(base, it)
+
+    class Dithered:
+        """the oracle with the engine's noise of pass number `calls` handed in as a tensor"""
+        threshold = ora.threshold
+        calls = 0
+
+        def make_decision(self, xx):
+            key = xv_plda.fused_pass_seed(base, self.calls)
+            type(self).calls += 1
+            noise = torch.from_numpy(np.stack([philox.dither_noise(key, b, F) for b in range(xx.shape[0])]))
+            return ora.make_decision(xx, dither_noise=noise)
+
+    oadv, osucc = oatk.PGD(Dithered(), task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B).attack(x, y)
+    assert Dithered.calls == K + 1
+    # decisions on the adversarial audio are taken with the noise-free models on both sides (a fresh draw would differ)
+    _compare("configs[1] with dither 1.0 (reference default): PGD-5 x 64 x 3 s", x, adv, succ, oadv, osucc,
+             lambda a: quiet.make_decision(a)[0], lambda a: ora.make_decision(a)[0], eps, K)
+    # ... and the dither matters at this size: the noise-free trajectory is a different one
+    adv0, _ = PGD(quiet, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0).attack(x.to(DEV), y.to(DEV))
+    moved = float(((adv0 - adv).abs() > 1e-7).float().mean())
+    log("  dither 1.0 vs dither 0 on the device: %.2f %% of the samples end elsewhere" % (100 * moved))
+    assert moved > 0.001
+
+
+def test_config2_cw2_sv_batch32_at_three_seconds(xv_weights):
+    """configs[2] at its own size: CW2 (L2, Adam) targeted on the SV task, 32 utterances x 3 s, one search step x 10
+    iterations, against the oracle loop (round 3 met the oracle at 1 s and checked 3 s by properties only)."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.CW2 import CW2
+    from speakerguard_amd.model.xv_plda import xv_plda
+    w = dict(xv_weights)
+    w["enroll"] = xv_weights["enroll"][:1].copy()  # SV: one enrolled speaker
+    x = torch.from_numpy(synth.make_waveforms(32, 48000, seed=35))
+    probe = xv_plda.from_weights(w, device=DEV, dither=0.0)
+    clean = probe.make_decision(x.to(DEV))[1][:, 0].cpu()
+    thr = float(clean.sort().values[20]) + 0.5  # 21 voices start rejected; the threshold is within reach of some of them
+    om, hm = XvPlda(w, threshold=thr, faithful=False, freeze=True), xv_plda.from_weights(w, threshold=thr, device=DEV, dither=0.0)
+    y = torch.zeros(32, dtype=torch.long)
+    kw = dict(task="SV", targeted=True, confidence=0.0, initial_const=1e-2, binary_search_steps=1, max_iter=10,
+              stop_early=True, stop_early_iter=5, lr=2e-3, batch_size=32)
+    oadv, osucc = oatk.CW2(om, **kw).attack(x.clone(), y)
+    adv, succ = CW2(hm, verbose=0, **kw).attack(x.to(DEV), y.to(DEV))
+    d = (adv.cpu() - oadv).abs().numpy()
+    l2h, l2o = (adv.cpu() - x).flatten(1).norm(dim=1), (oadv - x).flatten(1).norm(dim=1)
+    log("configs[2] CW2 targeted SV x 32 x 3 s, 1 search step x 10 iterations: success HIP %d/32 oracle %d/32 (equal per utterance: %s); "
+        "max |x_adv - oracle| %.3e, differing (> 2e-4) %.4f %%; L2 of the perturbation %.4f vs %.4f"
+        % (sum(succ), sum(osucc), [bool(a) for a in succ] == [bool(a) for a in osucc], d.max(), 100 * (d > 2e-4).mean(),
+           float(l2h.mean()), float(l2o.mean())))
+    assert [bool(a) for a in succ] == [bool(a) for a in osucc]
+    assert 0 < sum(succ) < 32, "both outcomes: %d/32" % sum(succ)
+    assert hm.make_decision(adv)[0].cpu().tolist() == om.make_decision(oadv)[0].tolist()
+    # Adam's first update is ~ lr * sign(g): a round-off-level gradient entry moves by +-lr on either side
+    assert (d > 2e-4).mean() < 2e-3 and d.max() <= 2 * 2e-3 * 10 + 1e-6
+    assert abs(float(l2h.mean()) - float(l2o.mean())) < 0.02 * float(l2o.mean())
+
+
+def test_config4_fakebob_twenty_iterations_with_early_stop(xv_weights):
+    """configs[4] for 20 iterations (round 3 ran 4 of the ~196 a 10k-query budget allows): FAKEBOB OSI targeted, 50 + 1
+    queries per voice and iteration, two voices, shared seeded NES noise -- one voice crosses the threshold during the run and
+    leaves the batch through the early-stop branch (attack/FAKEBOB.py:85-90,125-168), the other keeps being queried."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.FAKEBOB import FAKEBOB
+    from speakerguard_amd.model.xv_plda import xv_plda
+    eps, iters = 0.002, 20
+    x = torch.from_numpy(synth.make_waveforms(64, 48000, seed=1234))[[4, 5]]
+    probe = xv_plda.from_weights(xv_weights, device=DEV, dither=0.0)
+    s0 = probe.make_decision(x.to(DEV))[1].cpu()
+    yt = s0.argmax(1)
+    top = s0.max(1).values
+    th = float(top.max()) + 1.5  # both start rejected; the nearer one is 1.5 below the threshold
+    hm = xv_plda.from_weights(xv_weights, threshold=th, device=DEV, dither=0.0)
+    om = XvPlda(xv_weights, threshold=th, faithful=False, freeze=True)
+    assert hm.make_decision(x.to(DEV))[0].cpu().tolist() == [-1, -1]
+    kw = dict(task="OSI", targeted=True, threshold=th, epsilon=eps, max_iter=iters, max_lr=0.001, min_lr=1e-6, samples_per_draw=50,
+              samples_per_draw_batch_size=50, sigma=0.001, stop_early=True, stop_early_iter=100, batch_size=2)
+    g = torch.Generator().manual_seed(9)
+    draws_o = []
+    oadv, osucc = oatk.FAKEBOB(om, noise_fn=lambda shape: (draws_o.append(shape[0]), torch.randn(shape, generator=g))[1], **kw).attack(x.clone(), yt)
+    g2 = torch.Generator().manual_seed(9)
+    draws_h = []
+    adv, succ = FAKEBOB(hm, verbose=0, noise_fn=lambda shape: (draws_h.append(shape[0]), torch.randn(shape, generator=g2))[1], **kw).attack(
+        x.to(DEV), yt.to(DEV))
+
+    def odec(a):
+        with torch.no_grad():
+            return om.make_decision(a)[0]
+    log("configs[4] FAKEBOB OSI targeted S=50 x 2 x 3 s, %d iterations: voices queried per iteration HIP %s oracle %s" % (iters, draws_h, draws_o))
+    assert draws_h == draws_o, "the batch shrinks at the same iteration on both sides"
+    assert len(draws_h) >= 8 and draws_h[0] == 2 and draws_h[-1] == 1, "an early-stop hit during the run, the other voice goes on: %s" % draws_h
+    _compare("configs[4] FAKEBOB OSI targeted S=50 x 2 x 3 s, 20 iterations", x, adv, succ, oadv, osucc,
+             lambda a: hm.make_decision(a)[0], odec, eps, iters)
