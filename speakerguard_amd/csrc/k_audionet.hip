@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256) void an_prefilter_kernel(const float* __restri
             // 25 serial L2 round trips per output (56 us per launch at batch 512 for 20 MB of data).
             const bool ok = mm >= 0 && mm < kAnMel && tt >= 0 && tt < T;
             const float v = x[(size_t)min(max(tt, 0), T - 1) * kAnMel + min(max(mm, 0), kAnMel - 1)];
-            acc += w25[i * 5 + j] * (ok ? v : 0.f);
+            // an explicit fused multiply-add: left to -ffp-contract the compiler fused the main body of a loop and not its
+            // remainder (k_audionet_fused.hip must reproduce these bits whatever shape its loops take)
+            acc = fmaf(w25[i * 5 + j], ok ? v : 0.f, acc);
         }
     }
     out[(size_t)b * T * kAnMel + idx] = acc;

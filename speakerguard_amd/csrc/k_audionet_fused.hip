@@ -22,6 +22,10 @@
 // the 16 lanes a ds_read_b128 is served for -- 16 consecutive rows, same channel group -- hit 16 different slots:
 //   C = 32  (128-byte rows: consecutive rows alternate between the two halves of the 64 banks): slot ^ ((row >> 1) & 7)
 //   C >= 64 (rows a multiple of 256 bytes: every row starts at bank 0): slot16 ^ (row & 15) inside each 64-channel piece
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "sg_internal.h"
 
 namespace sg {
@@ -113,43 +117,44 @@ template <int K, int MI, bool REV>
 __device__ __forceinline__ void fz_mac(const float* __restrict__ in, const float4* __restrict__ wl, int ldw, const int (&R0)[MI],
                                        f32x16 (&acc)[MI]) {
     constexpr int NCH = 3 * K / 32, CPT = K / 32;  // chunks of 32 k values; per tap
+    // W ring: chunk c's four 16-byte operands sit in slot c % D, requested D chunks before their use -- with one 32-row
+    // tile per wave (the sliced form at small batches) a chunk is 16 MFMAs = 0.43 us, and an L2 / Infinity-Cache round
+    // trip under load is 1-2 us: a ring one chunk deep ran at the load latency (94 us per launch at 64 utterances, 63
+    // chunks x 1.5 us).  The loops are fully unrolled (3 .. 12 chunks), so every slot is a compile-time register.
+    constexpr int D = MI == 3 ? 3 : MI == 2 ? 4 : 6;
+    constexpr int DD = D < NCH ? D : NCH;
     const int lhi = (threadIdx.x & 63) >> 5;
-    float4 wc[4], wn[4];
+    float4 wr[DD][4];
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) wc[kg] = wl[(size_t)(2 * kg) * ldw];
-#pragma unroll 1
-    for (int j = 0; j < 3; ++j) {
-        int Rj[MI];
+    for (int d = 0; d < DD; ++d)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) Rj[mi] = R0[mi] + (REV ? 2 - j : j);
+        for (int kg = 0; kg < 4; ++kg) wr[d][kg] = wl[(size_t)(d * 8 + 2 * kg) * ldw];
 #pragma unroll
-        for (int kc = 0; kc < CPT; ++kc) {
-            const int ch = j * CPT + kc;
-            // the next chunk's W operands are requested before this chunk's multiplications (past the end: the last chunk again)
-            const int nx = ch + 1 < NCH ? ch + 1 : ch;
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int j = ch / CPT, kc = ch % CPT;
+        float4 a[4][MI];
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) wn[kg] = wl[(size_t)(nx * 8 + 2 * kg) * ldw];
-            float4 a[4][MI];
+        for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg)
+            for (int mi = 0; mi < MI; ++mi)
+                a[kg][mi] = *reinterpret_cast<const float4*>(in + fz_off<K>(R0[mi] + (REV ? 2 - j : j), kc * 32 + 8 * kg + 4 * lhi));
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[kg][mi] = *reinterpret_cast<const float4*>(in + fz_off<K>(Rj[mi], kc * 32 + 8 * kg + 4 * lhi));
+        for (int kg = 0; kg < 4; ++kg) {
+            const float4 w = wr[ch % DD][kg];
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                const float4 w = wc[kg];
+            for (int st = 0; st < 4; ++st) {
+                const float wb = st == 0 ? w.x : st == 1 ? w.y : st == 2 ? w.z : w.w;
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const float wb = st == 0 ? w.x : st == 1 ? w.y : st == 2 ? w.z : w.w;
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const float4 x = a[kg][mi];
-                        const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wb, acc[mi], 0, 0, 0);
-                    }
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float4 x = a[kg][mi];
+                    const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wb, acc[mi], 0, 0, 0);
                 }
             }
+        }
+        if (ch + DD < NCH) {
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) wc[kg] = wn[kg];
+            for (int kg = 0; kg < 4; ++kg) wr[ch % DD][kg] = wl[(size_t)((ch + DD) * 8 + 2 * kg) * ldw];
         }
     }
 }
@@ -261,54 +266,75 @@ __device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice
     __syncthreads();
 }
 
+#define FZ_STAMP(i)                                                                                           \
+    if (p.trace && threadIdx.x == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64();
+
 __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float fz_lds[];
     float* bufA = fz_lds;
     float* bufB = fz_lds + p.buf_floats;
     const int row = blockIdx.y;
+    FZ_STAMP(0)
     AnSlice r;
     an_slice_fwd(p.Tin, p.Tout, p.Fnet, p.S, blockIdx.x, r);
     // ---- 5x5 pre-filter: feature rows [flo, fhi) -> bufB (plain [rows][32]); pre rows [plo, phi) -> memory (own rows) and
     //      bufA as conv2's input window
-    const int F = p.Fnet, nf = r.fhi - r.flo;
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.feats + ((size_t)row * F + r.flo) * 32);
-        for (int i = threadIdx.x; i < nf * 8; i += kFzThreads) reinterpret_cast<float4*>(bufB)[i] = src[i];
-    }
+    // The feature rows are staged with a ZERO border (two rows above and below the pre rows, two columns left and right:
+    // [rows + 4][36]) so that the 25 taps are unconditional LDS reads -- a tap outside the image multiplies a staged zero,
+    // which adds exactly what the guarded form `w * (ok ? v : 0)` of an_prefilter_kernel adds (the first version clamped
+    // and selected per tap: 15 us of a 180 us block at 300 frames).
+    const int F = p.Fnet, np = r.phi - r.plo;
+    constexpr int PW = kAnMel + 4;
+    fz_zero(bufB, ((np + 4) * PW + 3) & ~3);
     const int base0 = r.olo[0] - kAnPad[0], rows0 = r.ohi[0] - r.olo[0] + 2;
     fz_zero(bufA, rows0 * 32);
+    __syncthreads();
+    {
+        // staged row q <-> feature row plo - 2 + q; rows outside [flo, fhi) = outside the image stay zero
+        const float* src = p.feats + (size_t)row * F * 32;
+        for (int i = threadIdx.x; i < (r.fhi - r.flo) * 8; i += kFzThreads) {
+            const int t = r.flo + (i >> 3), c4 = (i & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)t * 32 + c4);
+            float* d = bufB + (t - (r.plo - 2)) * PW + 2 + c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
     __syncthreads();
     {
         float w[25];
 #pragma unroll
         for (int i = 0; i < 25; ++i) w[i] = p.w25[i];
         float* pre = p.pre + (size_t)row * F * 32;
-        for (int idx = threadIdx.x; idx < (r.phi - r.plo) * 32; idx += kFzThreads) {
-            const int t = r.plo + (idx >> 5), m = idx & 31;
+        for (int idx = threadIdx.x; idx < np * 32; idx += kFzThreads) {
+            const int q0 = idx >> 5, m = idx & 31, t = r.plo + q0;
+            const float* wnd = bufB + q0 * PW + m;  // tap (i, j) = staged[q0 + j][m + i]
             float acc = p.pre_bias;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {      // mel offset
+            for (int i = 0; i < 5; ++i)      // mel offset
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {  // time offset
-                    const int mm = m + i - 2, tt = t + j - 2;
-                    const bool ok = mm >= 0 && mm < kAnMel && tt >= 0 && tt < F;
-                    const float v = bufB[(min(max(tt, r.flo), r.fhi - 1) - r.flo) * 32 + min(max(mm, 0), kAnMel - 1)];
-                    acc += w[i * 5 + j] * (ok ? v : 0.f);
-                }
-            }
+                for (int j = 0; j < 5; ++j)  // time offset
+                    acc = fmaf(w[i * 5 + j], wnd[j * PW + i], acc);  // explicit, like an_prefilter_kernel
             if (t >= r.wplo && t < r.wphi) pre[(size_t)t * 32 + m] = acc;
             const int q = t - base0;
             if (q >= 0 && q < rows0) bufA[fz_off<32>(q, m)] = acc;
         }
     }
     __syncthreads();
+    FZ_STAMP(1)
     fz_fwd_layer<0>(p, r, row, bufA, bufB);
+    FZ_STAMP(2)
     fz_fwd_layer<1>(p, r, row, bufB, bufA);
+    FZ_STAMP(3)
     fz_fwd_layer<2>(p, r, row, bufA, bufB);
+    FZ_STAMP(4)
     fz_fwd_layer<3>(p, r, row, bufB, bufA);
+    FZ_STAMP(5)
     fz_fwd_layer<4>(p, r, row, bufA, bufB);
+    FZ_STAMP(6)
     fz_fwd_layer<5>(p, r, row, bufB, bufA);
+    FZ_STAMP(7)
     fz_fwd_layer<6>(p, r, row, bufA, bufB);
+    FZ_STAMP(8)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -331,7 +357,8 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
         nbase = r.wlo[L - 1] + kAnPad[L - 1] - 2;
         nrows = r.whi[L - 1] - r.wlo[L - 1] + 2;
     }
-    fz_zero(out, nrows * N);
+    constexpr int PW = kAnMel + 4;  // L = 0: d pre goes to a zero-bordered plain image [rows + 4][36] (see the forward pre-filter)
+    fz_zero(out, FIRST ? ((nrows + 4) * PW + 3) & ~3 : nrows * N);
     __syncthreads();
     const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
     const int Tprev = FIRST ? p.Fnet : p.Tout[L > 0 ? L - 1 : 0];
@@ -343,7 +370,7 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
             for (int e = 0; e < 16; ++e) {
                 const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 const int q = ilo + ro - nbase;
-                if (ro < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = acc[e];
+                if (ro < n_out && q >= 0 && q < nrows) out[(q + 2) * PW + 2 + col] = acc[e];
             }
         } else if constexpr (INPOOL) {
             // pooled row pr <- rows 2 pr (first maximum wins a tie, like torch) / 2 pr + 1 of act[L - 1], ReLU mask applied
@@ -386,6 +413,7 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p
     float* bufA = fz_lds;
     float* bufB = fz_lds + p.buf_floats;
     const int row = blockIdx.y;
+    FZ_STAMP(0)
     AnSlice r;
     an_slice_bwd(p.Tin, p.Tout, p.Fnet, p.S, blockIdx.x, r);
     // ---- d act[6] window from memory: rows [wlo[6] + pad - 2, whi[6] + pad) of (T8, 32), zero outside
@@ -401,37 +429,42 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p
         }
         __syncthreads();
     }
+    FZ_STAMP(1)
     fz_bwd_layer<6>(p, r, row, bufA, bufB);
+    FZ_STAMP(2)
     fz_bwd_layer<5>(p, r, row, bufB, bufA);
+    FZ_STAMP(3)
     fz_bwd_layer<4>(p, r, row, bufA, bufB);
+    FZ_STAMP(4)
     fz_bwd_layer<3>(p, r, row, bufB, bufA);
+    FZ_STAMP(5)
     fz_bwd_layer<2>(p, r, row, bufA, bufB);
+    FZ_STAMP(6)
     fz_bwd_layer<1>(p, r, row, bufB, bufA);
+    FZ_STAMP(7)
     fz_bwd_layer<0>(p, r, row, bufA, bufB);
-    // ---- transposed 5x5 pre-filter: d pre rows [plo, phi) in bufB (swizzled [rows][32]) -> own rows of d features
+    FZ_STAMP(8)
+    // ---- transposed 5x5 pre-filter: d pre rows [plo, phi) in bufB (zero-bordered plain image) -> own rows of d features
     {
         float w[25];
 #pragma unroll
         for (int i = 0; i < 25; ++i) w[i] = p.w25[i];
-        const int F = p.Fnet, np = r.phi - r.plo;
+        constexpr int PW = kAnMel + 4;
+        const int F = p.Fnet;
         float* dst = p.dfeats + (size_t)row * F * 32;
         for (int idx = threadIdx.x; idx < (r.fhi - r.flo) * 32; idx += kFzThreads) {
             const int t = r.flo + (idx >> 5), m = idx & 31;
+            // d pre[t - j + 2][m - i + 2] = staged[(t - j + 2) - plo + 2][(m - i + 2) + 2]
+            const float* wnd = bufB + (t - r.plo + 4) * PW + m + 4;
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const int mm = m - i + 2, tt = t - j + 2;
-                    const bool ok = mm >= 0 && mm < kAnMel && tt >= 0 && tt < F;
-                    const int q = min(max(tt - r.plo, 0), np - 1);
-                    const float v = bufB[fz_off<32>(q, min(max(mm, 0), kAnMel - 1))];
-                    acc += w[i * 5 + j] * (ok ? v : 0.f);
-                }
-            }
+                for (int j = 0; j < 5; ++j) acc = fmaf(w[i * 5 + j], wnd[-j * PW - i], acc);
             dst[(size_t)t * 32 + m] = acc;
         }
     }
+    FZ_STAMP(9)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -446,8 +479,8 @@ static int fz_plan(const int* Tin, const int* Tout, int Fnet, int rows, int num_
             AnSlice f, b;
             an_slice_fwd(Tin, Tout, Fnet, S, s, f);
             an_slice_bwd(Tin, Tout, Fnet, S, s, b);
-            need = std::max(need, (f.fhi - f.flo) * 32);
-            need = std::max(need, (b.phi - b.plo) * 32);
+            need = std::max(need, (f.phi - f.plo + 4) * (kAnMel + 4) + 4);  // zero-bordered staging of the pre-filter's input
+            need = std::max(need, (b.phi - b.plo + 4) * (kAnMel + 4) + 4);  // ... and of its transpose
             for (int l = 0; l < kAnConv; ++l) {
                 need = std::max(need, (f.ohi[l] - f.olo[l] + 2) * kAnCin[l]);   // forward input window of conv l
                 need = std::max(need, (b.whi[l] - b.wlo[l] + 2) * kAnCout[l]);  // backward: d act[l] window
@@ -491,7 +524,7 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
             AnSlice f, b;
             an_slice_fwd(a.Tin, a.Tout, a.Fnet, S, sl, f);
             an_slice_bwd(a.Tin, a.Tout, a.Fnet, S, sl, b);
-            need = std::max(need, std::max((f.fhi - f.flo) * 32, (b.phi - b.plo) * 32));
+            need = std::max(need, std::max((f.phi - f.plo + 4) * (kAnMel + 4) + 4, (b.phi - b.plo + 4) * (kAnMel + 4) + 4));
             for (int l = 0; l < kAnConv; ++l)
                 need = std::max(need, std::max((f.ohi[l] - f.olo[l] + 2) * kAnCin[l], (b.whi[l] - b.wlo[l] + 2) * kAnCout[l]));
         }
@@ -512,8 +545,32 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    static const char* trace_file = getenv("SG_AN_TRACE");  // tuning aid: dump the per-block stage timestamps of every launch
+    static unsigned long long* trace_dev = nullptr;
+    static size_t trace_cap = 0;
+    const size_t nblk = (size_t)S * rows;
+    if (trace_file && trace_cap < nblk) {
+        if (trace_dev) (void)hipFree(trace_dev);
+        (void)hipMalloc(reinterpret_cast<void**>(&trace_dev), nblk * 16 * 8);
+        trace_cap = nblk;
+    }
+    a.trace = trace_file ? trace_dev : nullptr;
+    if (a.trace) (void)hipMemsetAsync(a.trace, 0, nblk * 16 * 8, s);
     if (backward) hipLaunchKernelGGL(an_cnn_bwd_kernel, dim3(S, rows), dim3(kFzThreads), lds, s, a);
     else hipLaunchKernelGGL(an_cnn_fwd_kernel, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    if (a.trace) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(nblk * 16);
+        (void)hipMemcpy(h.data(), a.trace, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(trace_file, "a")) {
+            fprintf(f, "%s S=%d rows=%d\n", backward ? "bwd" : "fwd", S, rows);
+            for (size_t b = 0; b < nblk; ++b) {
+                for (int i = 0; i < 10; ++i) fprintf(f, "%llu ", h[b * 16 + i]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -343,6 +343,7 @@ struct AnFusedArgs {
     float* dfeats;             // (rows, Fnet, 32)
     int Fnet, S, buf_floats;
     int Tin[kAnConv], Tout[kAnConv];
+    unsigned long long* trace;  // tuning aid (SG_AN_TRACE): per block 16 timestamps (100 MHz) at the stage boundaries, or null
 };
 // false: the utterance is too long for the LDS-resident form even in its finest cut (the per-layer sequence runs)
 bool an_fused_supported(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus);

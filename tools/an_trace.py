@@ -1,0 +1,42 @@
+"""Stage times inside the fused AudioNet CNN kernels (SG_AN_TRACE: per-block timestamps at the stage boundaries, 100 MHz).
+    python tools/an_trace.py B"""
+import os, sys, statistics
+TRACE = "/tmp/an_trace.txt"
+os.environ["SG_AN_TRACE"] = TRACE
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speakerguard_amd import synth
+from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+from speakerguard_amd.model.audionet_csine import audionet_csine
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+m = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)
+x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=5)).to(dev)
+feats = m.compute_feat(x)
+y = m.make_decision(x)[0]
+for _ in range(3):
+    if os.path.exists(TRACE):
+        os.remove(TRACE)
+    m.loss_grad(feats, y, SEC4SR_CrossEntropy(), flag=1)
+names = {"fwd": ["prefilter", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8"],
+         "bwd": ["load", "d conv8", "d conv7", "d conv6", "d conv5", "d conv4", "d conv3", "d conv2", "prefilter^T"]}
+kind, rows = None, []
+def report():
+    if not rows:
+        return
+    t0 = min(r[0] for r in rows)
+    n = len(names[kind])
+    print("%s: %d blocks, launch span %.1f us (first start to last end)" % (kind, len(rows), (max(r[n] for r in rows) - t0) / 100.0))
+    for i, nm in enumerate(names[kind]):
+        d = [(r[i + 1] - r[i]) / 100.0 for r in rows]
+        print("   %-12s median %.2f us  max %.2f us" % (nm, statistics.median(d), max(d)))
+    tot = [(r[n] - r[0]) / 100.0 for r in rows]
+    st = [(r[0] - t0) / 100.0 for r in rows]
+    print("   block total  median %.2f us  max %.2f us; block start offsets: median %.1f us, max %.1f us" % (statistics.median(tot), max(tot), statistics.median(st), max(st)))
+for line in open(TRACE):
+    if line[0] in "fb":
+        report()
+        kind, rows = line.split()[0], []
+    else:
+        rows.append([int(v) for v in line.split()])
+report()
