@@ -357,8 +357,8 @@ int sg_trace_end(sg_ctx* ctx, int32_t* tags_out, float* ms_out, int32_t capacity
  * (mask shaped like C).  kernel: 0 = what the TDNN layers get (stream-K with 16-wave 256x128 quad-fed blocks when
  * the shape qualifies, one 16x16 block per wave on the 16x16x4 MFMA when there are at most 2800 such blocks, else one
  * quad-fed 64x128 block per tile), 1 = one b32-fed 64x128 block per tile, 2 = stream-K with the b32-fed 8-wave kernel,
- * (6 / 7 / 8 / 9 = stream-K with the roles split between waves, 128- / 64- / 32- / 256-row tiles, an error when the shape does
- * not qualify),
+ * (6 / 7 / 8 / 9 = stream-K with the roles split between waves, 128- / 64- / 32- / 256-row tiles, 10 = 128-row tiles as four
+ * 64x64 computing waves; an error when the shape does not qualify),
  * 3 = stream-K with 8-wave 128x128 quad-fed blocks, 4 = one quad-fed 64x128 block per tile, 5 = one 16x16 block per
  * wave.  All choices give bit-identical results: the float32 fmaf chain restated in oracle/conv_chain.c. */
 int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c_dev, const float* bias_dev,

@@ -266,7 +266,8 @@ struct ConvGemmArgs {
     unsigned long long* trace;  // tuning aid (SG_SK_TRACE): per-worker phase timestamps, 16 slots each, or null
     int force;          // 0 auto, 1 one b32-fed block per tile, 2 stream-K b32-fed 8-wave, 3 stream-K quad-fed 8-wave,
                         // 4 one quad-fed block per tile, 5 one 16 x 16 block per wave, 6 / 7 / 8 / 9 stream-K with the roles split
-                        // between waves, 128- / 64- / 32- / 256-row tiles (parity tests)
+                        // between waves, 128- / 64- / 32- / 256-row tiles, 10 = 128-row tiles as four 64 x 64 computing waves
+                        // (kind 9) (parity tests)
     int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier;
                         // 8 = fault injection: stream-K hand-off flags are never published (health-word test);
                         // 16 = A/B: agent-scope release / acquire fences around the stream-K hand-off (results stay right)
