@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-points", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    # test hooks (tests/test_gpu_multiproc.py runs the N > 1 code path as two ranks on the ONE GPU of the test box)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--one-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -228,7 +231,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.one_gpu:
+            local = 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -122,3 +122,34 @@ def test_rccl_backend_runs_the_exchange_on_device_tensors(tmp_path):
     assert got["qsucc"] == list(ref_qsucc) and torch.equal(got["qadv"], ref_qadv.cpu())
     assert got["flags"].tolist() == [int(v) for v in ref_succ] and got["flags"].dtype == torch.uint8
     assert got["k"] == 2 and got["dt"] >= 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_n2_code_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end -- the launcher contract, ShardedAttack(PGD(batch_size=64)) as the strong partition,
+    the weak partition, MAX-over-ranks timing, the one JSON line from rank 0 -- as two ranks over gloo that share the test
+    box's one GPU (hidden --backend / --one-gpu hooks; RCCL needs a GPU per rank: the driver's SCALE run).  Two steps, and
+    SG_STREAMK=0: two processes must not both run chip-wide persistent kernels with intra-launch hand-offs on one GPU."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SG_STREAMK="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "2",
+           "--backend", "gloo", "--one-gpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 128
+    ss = line["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["batch_per_gpu"] == 32 and "ShardedAttack" in ss["note"]
+    assert line["value_metric_partition"] == ss["value"] and 0 <= ss["success_count"] <= 64
+    assert line["success_count"] <= 128 and line["roofline"]["frac"] > 0

@@ -1,0 +1,12 @@
+#!/bin/bash
+# rocprofv3 --pmc passes of the fused AudioNet CNN kernels (round 4), one counter group per pass, --kernel-trace only.
+#   gpurun -- 'bash tools/pmc_an_fused.sh gpurun_out/pmc_an 512'  then  python tools/pmc_kernel.py gpurun_out/pmc_an an_cnn_fwd_kernel
+out=${1:-gpurun_out/pmc_an}
+B=${2:-512}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    tag=$(echo $grp | cut -d' ' -f1)
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/$tag" -- python3 tools/audionet_profile.py $B > "$out.$tag.log" 2>&1
+done
