@@ -113,56 +113,103 @@ __host__ __device__ inline void an_slice_bwd(const int* Tin, const int* Tout, in
 // ---------------------------------------------------------------------------------------------------------------
 // acc[mi] += the 32 x 32 output block (rows R0[mi] + lane % 32 of the LDS input for tap offset 0, columns n0 + lane % 32)
 // over 3 taps x K channels.  REV: tap j reads input row + (2 - j) (data gradient), else row + j.
-template <int K, int MI, bool REV>
+template <int K, int MI, bool REV, bool RING>
 __device__ __forceinline__ void fz_mac(const float* __restrict__ in, const float4* __restrict__ wl, int ldw, const int (&R0)[MI],
                                        f32x16 (&acc)[MI]) {
     constexpr int NCH = 3 * K / 32, CPT = K / 32;  // chunks of 32 k values; per tap
-    // W ring: chunk c's four 16-byte operands sit in slot c % D, requested D chunks before their use -- with one 32-row
-    // tile per wave (the sliced form at small batches) a chunk is 16 MFMAs = 0.43 us, and an L2 / Infinity-Cache round
-    // trip under load is 1-2 us: a ring one chunk deep ran at the load latency (94 us per launch at 64 utterances, 63
-    // chunks x 1.5 us).  The loops are fully unrolled (3 .. 12 chunks), so every slot is a compile-time register.
-    constexpr int D = MI == 3 ? 3 : MI == 2 ? 4 : 6;
-    constexpr int DD = D < NCH ? D : NCH;
     const int lhi = (threadIdx.x & 63) >> 5;
-    float4 wr[DD][4];
+    if constexpr (RING) {
+        // Small slices (one 32-row tile per wave): a chunk is 16 MFMAs = 0.43 us, an L2 round trip under load 1-2 us, so
+        // the W operands of chunk c sit in slot c % D of a register ring and are requested D chunks ahead; loops fully
+        // unrolled (3 .. 12 chunks), every slot a compile-time register.  A/B on one box at 64 utterances (S = 4): 175 us
+        // per pass pair against 191 with the one-chunk-ahead form below.  It takes ~240 registers (hipcc hoists the LDS
+        // addresses of all chunks), which is why this variant of the kernels keeps the compact, fully checked epilogue.
+        constexpr int D = MI == 3 ? 3 : MI == 2 ? 4 : 6;
+        constexpr int DD = D < NCH ? D : NCH;
+        float4 wr[DD][4];
 #pragma unroll
-    for (int d = 0; d < DD; ++d)
+        for (int d = 0; d < DD; ++d)
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) wr[d][kg] = wl[(size_t)(d * 8 + 2 * kg) * ldw];
+            for (int kg = 0; kg < 4; ++kg) wr[d][kg] = wl[(size_t)(d * 8 + 2 * kg) * ldw];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int j = ch / CPT, kc = ch % CPT;
-        float4 a[4][MI];
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int j = ch / CPT, kc = ch % CPT;
+            float4 a[4][MI];
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg)
+            for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a[kg][mi] = *reinterpret_cast<const float4*>(in + fz_off<K>(R0[mi] + (REV ? 2 - j : j), kc * 32 + 8 * kg + 4 * lhi));
+                for (int mi = 0; mi < MI; ++mi)
+                    a[kg][mi] = *reinterpret_cast<const float4*>(in + fz_off<K>(R0[mi] + (REV ? 2 - j : j), kc * 32 + 8 * kg + 4 * lhi));
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const float4 w = wr[ch % DD][kg];
+            for (int kg = 0; kg < 4; ++kg) {
+                const float4 w = wr[ch % DD][kg];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const float wb = st == 0 ? w.x : st == 1 ? w.y : st == 2 ? w.z : w.w;
+                for (int st = 0; st < 4; ++st) {
+                    const float wb = st == 0 ? w.x : st == 1 ? w.y : st == 2 ? w.z : w.w;
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float4 x = a[kg][mi];
-                    const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wb, acc[mi], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const float4 x = a[kg][mi];
+                        const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wb, acc[mi], 0, 0, 0);
+                    }
                 }
             }
-        }
-        if (ch + DD < NCH) {
+            if (ch + DD < NCH) {
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) wr[ch % DD][kg] = wl[(size_t)((ch + DD) * 8 + 2 * kg) * ldw];
+                for (int kg = 0; kg < 4; ++kg) wr[ch % DD][kg] = wl[(size_t)((ch + DD) * 8 + 2 * kg) * ldw];
+            }
+        }
+    } else {
+        // Two or three tiles per wave (whole utterances, or halves): a chunk is 32-48 MFMAs per wave, the next chunk's four
+        // 16-byte W pieces requested before this chunk's multiplications are in time, and the ~130 registers of this form
+        // leave room for the epilogue's straight paths (A/B at 512 utterances: 685 us per pass pair against 720).
+        float4 wc[4], wn[4];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) wc[kg] = wl[(size_t)(2 * kg) * ldw];
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+            int Rj[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) Rj[mi] = R0[mi] + (REV ? 2 - j : j);
+#pragma unroll
+            for (int kc = 0; kc < CPT; ++kc) {
+                const int ch = j * CPT + kc;
+                const int nx = ch + 1 < NCH ? ch + 1 : ch;  // past the end: the last chunk again (valid memory, never multiplied)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) wn[kg] = wl[(size_t)(nx * 8 + 2 * kg) * ldw];
+                float4 a[4][MI];
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) a[kg][mi] = *reinterpret_cast<const float4*>(in + fz_off<K>(Rj[mi], kc * 32 + 8 * kg + 4 * lhi));
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float4 w = wc[kg];
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const float wb = st == 0 ? w.x : st == 1 ? w.y : st == 2 ? w.z : w.w;
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const float4 x = a[kg][mi];
+                            const float xa = st == 0 ? x.x : st == 1 ? x.y : st == 2 ? x.z : x.w;
+                            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wb, acc[mi], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) wc[kg] = wn[kg];
+            }
         }
     }
 }
 
 // A wave's share of a layer: output column block wn of N / 32, and a contiguous share of the m-tiles, in units of up to
 // three 32-row tiles (one W operand stream feeds all of them).  epi(mi-th tile's first row, acc) consumes a finished tile.
-template <int K, int N, bool REV, typename Epi>
-__device__ __forceinline__ void fz_layer(const float* __restrict__ in, const float* __restrict__ wq, int n_out, Epi&& epi) {
+// pre(n0) runs before the unit's multiplications and its result is handed to epi: what the epilogue needs from memory (the
+// bias of the wave's columns) is requested there, so that its latency -- 1-2 us from the L2, once per unit, 4.7 us per
+// epilogue with the ReLU outputs' stores behind it in the first version -- passes under the MFMAs.
+template <int K, int N, bool REV, bool SMALL, typename Pre, typename Epi>
+__device__ __forceinline__ void fz_layer(const float* __restrict__ in, const float* __restrict__ wq, int n_out, Pre&& pre, Epi&& epi) {
     constexpr int NT = N / 32, G = kFzWaves / NT;
     static_assert(NT >= 1 && NT <= kFzWaves && kFzWaves % NT == 0, "column blocks must divide the waves");
     const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
@@ -182,9 +229,10 @@ __device__ __forceinline__ void fz_layer(const float* __restrict__ in, const flo
             for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
-            fz_mac<K, 3, REV>(in, wl, N, R0, acc);
+            const auto pv = pre(n0);
+            fz_mac<K, 3, REV, SMALL>(in, wl, N, R0, acc);
 #pragma unroll
-            for (int mi = 0; mi < 3; ++mi) epi((m + mi) * 32, n0, acc[mi]);
+            for (int mi = 0; mi < 3; ++mi) epi((m + mi) * 32, n0, acc[mi], pv);
         } else if (cnt == 2) {
             const int R0[2] = {min(m * 32 + l31, n_out - 1), min(m * 32 + 32 + l31, n_out - 1)};
             f32x16 acc[2];
@@ -192,19 +240,24 @@ __device__ __forceinline__ void fz_layer(const float* __restrict__ in, const flo
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
-            fz_mac<K, 2, REV>(in, wl, N, R0, acc);
+            const auto pv = pre(n0);
+            fz_mac<K, 2, REV, SMALL>(in, wl, N, R0, acc);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) epi((m + mi) * 32, n0, acc[mi]);
+            for (int mi = 0; mi < 2; ++mi) epi((m + mi) * 32, n0, acc[mi], pv);
         } else {
             const int R0[1] = {min(m * 32 + l31, n_out - 1)};
             f32x16 acc[1];
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[0][e] = 0.f;
-            fz_mac<K, 1, REV>(in, wl, N, R0, acc);
-            epi(m * 32, n0, acc[0]);
+            const auto pv = pre(n0);
+            fz_mac<K, 1, REV, SMALL>(in, wl, N, R0, acc);
+            epi(m * 32, n0, acc[0], pv);
         }
     }
 }
+
+#define FZ_STAMP(i)                                                                                           \
+    if (p.trace && threadIdx.x == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64();
 
 __device__ __forceinline__ void fz_zero(float* buf, int floats) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -215,7 +268,7 @@ __device__ __forceinline__ void fz_zero(float* buf, int floats) {
 // forward layer L: input (Cin channels) in `in` -- LDS row 0 = virtual input row olo[L] - pad --, output to memory (own rows)
 // and, for the next layer, to `out` (LDS row 0 = virtual input row olo[L + 1] - pad[L + 1]; rows outside the valid range
 // stay zero: the convolution's zero padding)
-template <int L>
+template <int L, bool SMALL>
 __device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice& r, int row, const float* in, float* out) {
     constexpr int CIN = kAnCin[L], COUT = kAnCout[L];
     constexpr bool POOL = kAnPool[L], LAST = L == kAnConv - 1;
@@ -228,47 +281,79 @@ __device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice
         fz_zero(out, nrows * CNEXT);
     }
     __syncthreads();
+    if constexpr (L == 2) { FZ_STAMP(10) }
     const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
     float* act = p.act[L] + (size_t)row * Tout * COUT;
     float* pool = POOL ? p.pool[L] + (size_t)row * (Tout / 2) * COUT : nullptr;
     const float* bias = p.bias[L];
-    const int wlo = r.wlo[L], whi = r.whi[L];
-    fz_layer<CIN, COUT, false>(in, p.wq[L], n_out, [&](int m0, int n0, const f32x16& acc) __attribute__((always_inline)) {
+    // Epilogue cost is instruction count: the wave that shares the SIMD is still multiplying, and every VALU / branch
+    // instruction here takes matrix-pipe issue slots from it (the first version -- per-element bounds checks, 64-bit
+    // addresses, own-row tests: ~560 instructions per tile -- took 4.6 us per tile next to 10.4 us of MFMAs).  So: a tile
+    // whose 32 rows are all valid and all inside the next layer's window (wave-uniform tests) takes the straight path --
+    // one 32-bit offset per lane, compile-time row strides --, only ragged tiles check per element; and every computed
+    // row goes to memory, halo rows included (they equal the neighbour slice's own rows bit for bit), which drops the
+    // own-row tests.
+    constexpr int RO[16] = {0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27};
+    fz_layer<CIN, COUT, false, SMALL>(in, p.wq[L], n_out, [&](int n0) __attribute__((always_inline)) { return bias[n0 + l31]; },
+                               [&](int m0, int n0, const f32x16& acc, float bv) __attribute__((always_inline)) {
+        if constexpr (L == 2) { FZ_STAMP(11) }
         const int col = n0 + l31;
-        const float bv = bias[col];
         float v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = fmaxf(acc[e] + bv, 0.f);
+        const int r0 = m0 + 4 * lhi;  // the lane's first row, relative to olo
+        const bool full = !SMALL && m0 + 32 <= n_out;  // (SMALL: the compact, fully checked form only -- see fz_mac)
+        const unsigned g0 = (unsigned)((olo + r0) * COUT + col);
+        if (full) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;  // row relative to olo
-            const int t = olo + ro;
-            if (ro < n_out && t >= wlo && t < whi) act[(size_t)t * COUT + col] = v[e];
-            if constexpr (!POOL && !LAST) {
-                const int q = t - nbase;
-                if (ro < n_out && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = v[e];
+            for (int e = 0; e < 16; ++e) act[g0 + RO[e] * COUT] = v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (r0 + RO[e] < n_out) act[g0 + RO[e] * COUT] = v[e];
+        }
+        if constexpr (!POOL && !LAST) {
+            const int q0 = olo + r0 - nbase, qt = olo + m0 - nbase;  // lane's / tile's first row in the next window
+            if (full && qt >= 0 && qt + 32 <= nrows) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) out[fz_off<CNEXT>(q0 + RO[e], col)] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int q = q0 + RO[e];
+                    if (r0 + RO[e] < n_out && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = v[e];
+                }
             }
         }
-        if constexpr (POOL) {
+        if constexpr (POOL) {  // rows t, t + 1 (olo and RO[e] are even for even e): MaxPool1d(2)
+            const int p0 = (olo + r0) >> 1, pt = (olo + m0) >> 1;  // lane's / tile's first pooled row
+            const unsigned gp0 = (unsigned)(p0 * COUT + col);
+            const bool pfull = full && pt + 16 <= Tout / 2;
+            if (pfull) {
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) {  // rows t, t + 1 (olo is even): MaxPool1d(2)
-                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                const int t = olo + ro, pr = t >> 1;
-                if (ro + 1 < n_out && pr < Tout / 2) {
-                    const float pv = fmaxf(v[e], v[e + 1]);
-                    if (t >= wlo && t < whi) pool[(size_t)pr * COUT + col] = pv;
-                    const int q = pr - nbase;
-                    if (q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = pv;
+                for (int e = 0; e < 16; e += 2) pool[gp0 + (RO[e] >> 1) * COUT] = fmaxf(v[e], v[e + 1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2)
+                    if (r0 + RO[e] + 1 < n_out && p0 + (RO[e] >> 1) < Tout / 2) pool[gp0 + (RO[e] >> 1) * COUT] = fmaxf(v[e], v[e + 1]);
+            }
+            if (pfull && pt - nbase >= 0 && pt - nbase + 16 <= nrows) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) out[fz_off<CNEXT>(p0 - nbase + (RO[e] >> 1), col)] = fmaxf(v[e], v[e + 1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int pr = p0 + (RO[e] >> 1), q = pr - nbase;
+                    if (r0 + RO[e] + 1 < n_out && pr < Tout / 2 && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = fmaxf(v[e], v[e + 1]);
                 }
             }
         }
     });
+    if constexpr (L == 2) { FZ_STAMP(12) }
     __syncthreads();
 }
 
-#define FZ_STAMP(i)                                                                                           \
-    if (p.trace && threadIdx.x == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64();
-
+template <bool SMALL>
 __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float fz_lds[];
     float* bufA = fz_lds;
@@ -321,19 +406,19 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p
     }
     __syncthreads();
     FZ_STAMP(1)
-    fz_fwd_layer<0>(p, r, row, bufA, bufB);
+    fz_fwd_layer<0, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(2)
-    fz_fwd_layer<1>(p, r, row, bufB, bufA);
+    fz_fwd_layer<1, SMALL>(p, r, row, bufB, bufA);
     FZ_STAMP(3)
-    fz_fwd_layer<2>(p, r, row, bufA, bufB);
+    fz_fwd_layer<2, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(4)
-    fz_fwd_layer<3>(p, r, row, bufB, bufA);
+    fz_fwd_layer<3, SMALL>(p, r, row, bufB, bufA);
     FZ_STAMP(5)
-    fz_fwd_layer<4>(p, r, row, bufA, bufB);
+    fz_fwd_layer<4, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(6)
-    fz_fwd_layer<5>(p, r, row, bufB, bufA);
+    fz_fwd_layer<5, SMALL>(p, r, row, bufB, bufA);
     FZ_STAMP(7)
-    fz_fwd_layer<6>(p, r, row, bufA, bufB);
+    fz_fwd_layer<6, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(8)
 }
 
@@ -342,7 +427,7 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p
 // [wlo[L] + pad - 2, whi[L] + pad) of d act[L], zero outside the tensor --; the data gradient gives d (input of conv L)
 // rows [wlo[L], whi[L]); un-pooled / masked with the forward activations it becomes d act[L - 1] in `out` (LDS window
 // of the next data gradient), or d pre for L = 0.
-template <int L>
+template <int L, bool SMALL>
 __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice& r, int row, const float* in, float* out) {
     constexpr int K = kAnCout[L], N = kAnCin[L];
     constexpr bool FIRST = L == 0;
@@ -363,51 +448,81 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
     const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
     const int Tprev = FIRST ? p.Fnet : p.Tout[L > 0 ? L - 1 : 0];
     const float* aprev = FIRST ? nullptr : p.act[L > 0 ? L - 1 : 0] + (size_t)row * Tprev * N;
-    fz_layer<K, N, true>(in, p.wq[L], n_out, [&](int m0, int n0, const f32x16& acc) __attribute__((always_inline)) {
+    // (epilogue structure as in the forward layer: wave-uniform straight path for whole tiles inside the next window, 32-bit
+    // offsets, per-element checks only on ragged tiles)
+    constexpr int RO[16] = {0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27};
+    fz_layer<K, N, true, SMALL>(in, p.wq[L], n_out, [](int) __attribute__((always_inline)) { return 0; },
+                         [&](int m0, int n0, const f32x16& acc, int) __attribute__((always_inline)) {
         const int col = n0 + l31;
+        const int r0 = m0 + 4 * lhi;          // the lane's first row, relative to ilo
+        const bool full = !SMALL && m0 + 32 <= n_out;  // all 32 rows of the tile are rows of d input-of-L to produce (SMALL: checked form only)
         if constexpr (FIRST) {
+            const int q0 = ilo + r0 - nbase;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                const int q = ilo + ro - nbase;
-                if (ro < n_out && q >= 0 && q < nrows) out[(q + 2) * PW + 2 + col] = acc[e];
+                const int q = q0 + RO[e];
+                if (r0 + RO[e] < n_out && q >= 0 && q < nrows) out[(q + 2) * PW + 2 + col] = acc[e];
             }
         } else if constexpr (INPOOL) {
             // pooled row pr <- rows 2 pr (first maximum wins a tie, like torch) / 2 pr + 1 of act[L - 1], ReLU mask applied
+            const int pr0 = ilo + r0, q0 = 2 * pr0 - nbase, qt = 2 * (ilo + m0) - nbase;
             float a0[16], a1[16];
+            if (full && ilo + m0 + 32 <= Tprev / 2 && qt >= 0 && qt + 64 <= nrows) {
+                const unsigned g0 = (unsigned)(2 * pr0 * N + col);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int pr = min(ilo + m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi, Tprev / 2 - 1);
-                a0[e] = aprev[(size_t)(2 * pr) * N + col];
-                a1[e] = aprev[(size_t)(2 * pr + 1) * N + col];
-            }
+                for (int e = 0; e < 16; ++e) {
+                    a0[e] = aprev[g0 + 2 * RO[e] * N];
+                    a1[e] = aprev[g0 + (2 * RO[e] + 1) * N];
+                }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                const int pr = ilo + ro;
-                if (ro < n_out && pr < Tprev / 2) {
+                for (int e = 0; e < 16; ++e) {
                     const bool first = !(a1[e] > a0[e]);
-                    const float g0 = (first && a0[e] > 0.f) ? acc[e] : 0.f, g1 = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
-                    const int q = 2 * pr - nbase;
-                    if (q >= 0 && q < nrows) out[fz_off<N>(q, col)] = g0;
-                    if (q + 1 >= 0 && q + 1 < nrows) out[fz_off<N>(q + 1, col)] = g1;
+                    out[fz_off<N>(q0 + 2 * RO[e], col)] = (first && a0[e] > 0.f) ? acc[e] : 0.f;
+                    out[fz_off<N>(q0 + 2 * RO[e] + 1, col)] = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int pr = min(pr0 + RO[e], Tprev / 2 - 1);
+                    a0[e] = aprev[(unsigned)(2 * pr * N + col)];
+                    a1[e] = aprev[(unsigned)((2 * pr + 1) * N + col)];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int pr = pr0 + RO[e];
+                    if (r0 + RO[e] < n_out && pr < Tprev / 2) {
+                        const bool first = !(a1[e] > a0[e]);
+                        const float g0 = (first && a0[e] > 0.f) ? acc[e] : 0.f, g1 = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
+                        const int q = 2 * pr - nbase;
+                        if (q >= 0 && q < nrows) out[fz_off<N>(q, col)] = g0;
+                        if (q + 1 >= 0 && q + 1 < nrows) out[fz_off<N>(q + 1, col)] = g1;
+                    }
                 }
             }
         } else {
+            const int t0 = ilo + r0, q0 = t0 - nbase, qt = ilo + m0 - nbase;
             float mk[16];
+            if (full && ilo + m0 + 32 <= Tprev && qt >= 0 && qt + 32 <= nrows) {
+                const unsigned g0 = (unsigned)(t0 * N + col);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mk[e] = aprev[(size_t)min(ilo + m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi, Tprev - 1) * N + col];
+                for (int e = 0; e < 16; ++e) mk[e] = aprev[g0 + RO[e] * N];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ro = m0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                const int q = ilo + ro - nbase;
-                if (ro < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = mk[e] > 0.f ? acc[e] : 0.f;
+                for (int e = 0; e < 16; ++e) out[fz_off<N>(q0 + RO[e], col)] = mk[e] > 0.f ? acc[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mk[e] = aprev[(unsigned)(min(t0 + RO[e], Tprev - 1) * N + col)];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int q = q0 + RO[e];
+                    if (r0 + RO[e] < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = mk[e] > 0.f ? acc[e] : 0.f;
+                }
             }
         }
     });
     __syncthreads();
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float fz_lds[];
     float* bufA = fz_lds;
@@ -430,19 +545,19 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p
         __syncthreads();
     }
     FZ_STAMP(1)
-    fz_bwd_layer<6>(p, r, row, bufA, bufB);
+    fz_bwd_layer<6, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(2)
-    fz_bwd_layer<5>(p, r, row, bufB, bufA);
+    fz_bwd_layer<5, SMALL>(p, r, row, bufB, bufA);
     FZ_STAMP(3)
-    fz_bwd_layer<4>(p, r, row, bufA, bufB);
+    fz_bwd_layer<4, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(4)
-    fz_bwd_layer<3>(p, r, row, bufB, bufA);
+    fz_bwd_layer<3, SMALL>(p, r, row, bufB, bufA);
     FZ_STAMP(5)
-    fz_bwd_layer<2>(p, r, row, bufA, bufB);
+    fz_bwd_layer<2, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(6)
-    fz_bwd_layer<1>(p, r, row, bufB, bufA);
+    fz_bwd_layer<1, SMALL>(p, r, row, bufB, bufA);
     FZ_STAMP(7)
-    fz_bwd_layer<0>(p, r, row, bufA, bufB);
+    fz_bwd_layer<0, SMALL>(p, r, row, bufA, bufB);
     FZ_STAMP(8)
     // ---- transposed 5x5 pre-filter: d pre rows [plo, phi) in bufB (zero-bordered plain image) -> own rows of d features
     {
@@ -539,12 +654,17 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
     const size_t lds = (size_t)bf * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(an_cnn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(an_cnn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        const void* fns[4] = {reinterpret_cast<const void*>(an_cnn_fwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_fwd_kernel<true>),
+                              reinterpret_cast<const void*>(an_cnn_bwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true>)};
+        for (const void* fn : fns) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
+    // two builds of each kernel (fz_mac): small slices -- three or more per utterance, one 32-row tile per wave -- take the
+    // deep W ring, whole / half utterances the compact multiply loop with the straight-path epilogues.  Same bits.
+    const bool small = S >= 3;
     static const char* trace_file = getenv("SG_AN_TRACE");  // tuning aid: dump the per-block stage timestamps of every launch
     static unsigned long long* trace_dev = nullptr;
     static size_t trace_cap = 0;
@@ -556,8 +676,13 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
     }
     a.trace = trace_file ? trace_dev : nullptr;
     if (a.trace) (void)hipMemsetAsync(a.trace, 0, nblk * 16 * 8, s);
-    if (backward) hipLaunchKernelGGL(an_cnn_bwd_kernel, dim3(S, rows), dim3(kFzThreads), lds, s, a);
-    else hipLaunchKernelGGL(an_cnn_fwd_kernel, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    if (backward) {
+        if (small) hipLaunchKernelGGL(an_cnn_bwd_kernel<true>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+        else hipLaunchKernelGGL(an_cnn_bwd_kernel<false>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    } else {
+        if (small) hipLaunchKernelGGL(an_cnn_fwd_kernel<true>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+        else hipLaunchKernelGGL(an_cnn_fwd_kernel<false>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    }
     if (a.trace) {
         (void)hipStreamSynchronize(s);
         std::vector<unsigned long long> h(nblk * 16);
@@ -565,7 +690,7 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
         if (FILE* f = fopen(trace_file, "a")) {
             fprintf(f, "%s S=%d rows=%d\n", backward ? "bwd" : "fwd", S, rows);
             for (size_t b = 0; b < nblk; ++b) {
-                for (int i = 0; i < 10; ++i) fprintf(f, "%llu ", h[b * 16 + i]);
+                for (int i = 0; i < 13; ++i) fprintf(f, "%llu ", h[b * 16 + i]);
                 fprintf(f, "\n");
             }
             fclose(f);

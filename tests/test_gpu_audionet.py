@@ -313,3 +313,36 @@ def test_fused_cnn_is_the_path_that_runs(hip, dev, monkeypatch):
             assert tags.count("an_cnn_fwd") == 1 and tags.count("an_cnn_bwd") == 1 and not any(t.startswith("an_conv") for t in tags), tags
         else:
             assert "an_cnn_fwd" not in tags and sum(t.startswith("an_conv") for t in tags) == 14, tags
+
+
+def test_fused_cnn_random_shapes(hip, dev, monkeypatch):
+    """Shapes the planner was not tuned on: random utterance lengths from just above the shortest the stack accepts (conv8
+    needs 3 frames: 24 log-mel frames) to 9 s, batches 1..7, random forced cuts -- fused kernels == per-layer sequence, bit
+    for bit, forward and gradient; and an utterance too long for the LDS-resident form falls back to the per-layer path."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    rs = np.random.RandomState(404)
+    ce = SEC4SR_CrossEntropy()
+    shapes = [(1, 160 * 23 + 1), (2, 160 * 24 + 7)] + [(int(rs.randint(1, 8)), int(rs.randint(4000, 144000))) for _ in range(10)]
+    for B, T in shapes:
+        x = torch.from_numpy(synth.make_waveforms(B, T, seed=int(rs.randint(1 << 20)))).to(dev)
+        y = torch.from_numpy(rs.randint(0, 251, size=B)).to(dev)
+        monkeypatch.setenv("SG_AN_FUSED", "0")
+        monkeypatch.delenv("SG_AN_SLICES", raising=False)
+        ref = hip.loss_grad(x, y, ce)
+        ref_act = [hip.read_activation(i, B).clone() for i in (1, 2, 5, 8)]
+        monkeypatch.setenv("SG_AN_FUSED", "1")
+        for slices in (0, int(rs.randint(1, 12))):
+            if slices:
+                monkeypatch.setenv("SG_AN_SLICES", str(slices))
+            got = hip.loss_grad(x, y, ce)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), (B, T, slices)
+            for i, b in zip((1, 2, 5, 8), ref_act):
+                assert torch.equal(hip.read_activation(i, B), b), (B, T, slices, i)
+    monkeypatch.delenv("SG_AN_SLICES", raising=False)
+    # 3 minutes of audio: 18 000 frames do not fit the LDS-resident form even in 16 slices -> the per-layer sequence runs
+    x = torch.from_numpy(synth.make_waveforms(1, 16000 * 180, seed=5)).to(dev)
+    tags = [t for t, _ in hip.trace_stages(lambda: hip.make_decision(x), max_records=64)]
+    assert "an_cnn_fwd" not in tags and any(t.startswith("an_conv") for t in tags), tags
+    log("audionet fused CNN: %d random shapes (B 1..7, 0.25..9 s, random cuts) equal the per-layer sequence bit for bit; 180 s falls back" % len(shapes))

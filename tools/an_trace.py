@@ -30,6 +30,11 @@ def report():
     for i, nm in enumerate(names[kind]):
         d = [(r[i + 1] - r[i]) / 100.0 for r in rows]
         print("   %-12s median %.2f us  max %.2f us" % (nm, statistics.median(d), max(d)))
+    if kind == "fwd" and any(r[10] for r in rows):
+        for nm, a, b in (("conv4: zero + barrier", 3, 10), ("conv4: wave 0 until its (last) epilogue starts", 10, 11), ("conv4: wave 0's last epilogue", 11, 12), ("conv4: final barrier", 12, 4)):
+            d = [(r[b] - r[a]) / 100.0 for r in rows if r[10] and r[11] and r[12]]
+            if d:
+                print("      %-48s median %.2f us  max %.2f us" % (nm, statistics.median(d), max(d)))
     tot = [(r[n] - r[0]) / 100.0 for r in rows]
     st = [(r[0] - t0) / 100.0 for r in rows]
     print("   block total  median %.2f us  max %.2f us; block start offsets: median %.1f us, max %.1f us" % (statistics.median(tot), max(tot), statistics.median(st), max(st)))
