@@ -270,6 +270,20 @@ int main() {
         EXPECT(sg_an_forward(ctx, fe.data(), B, Fa, 1, dec.data(), sc.data(), em.data(), nullptr) == SG_OK);
         EXPECT(sg_an_forward(ctx, fe.data(), B, 20, 1, dec.data(), sc.data(), em.data(), nullptr) == SG_ERR_ARG);  // too few frames for conv8
         EXPECT(sg_an_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+        {   // the fused CNN kernels' planner (time slices, LDS demand) for forced cuts, and the per-layer sequence it replaces
+            const long l1 = hipdouble_launches();
+            setenv("SG_AN_SLICES", "7", 1);
+            EXPECT(sg_an_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+            setenv("SG_AN_SLICES", "1000", 1);  // more slices than conv8 has rows: clamped
+            EXPECT(sg_an_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+            unsetenv("SG_AN_SLICES");
+            const long fused = hipdouble_launches() - l1;
+            setenv("SG_AN_FUSED", "0", 1);
+            const long l2 = hipdouble_launches();
+            EXPECT(sg_an_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+            unsetenv("SG_AN_FUSED");
+            EXPECT(hipdouble_launches() - l2 > fused / 2 + 10);  // ~28 launches per pass pair against ~8
+        }
         EXPECT(sg_an_logmel_backward(ctx, x.data(), B, T, fe.data(), grad.data(), 1, nullptr) == SG_OK);
         pp = sg_pgd_params{};
         pp.step_size = 4e-4f; pp.max_iter = 2; pp.grad_sign = 1; pp.eot_size = 2; pp.eot_batch_size = 1;
