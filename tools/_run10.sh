@@ -13,3 +13,9 @@ python bench.py > gpurun_out/r04f/r04_bench_line.json 2> gpurun_out/r04f/bench.e
 python tools/batch_sweep.py > gpurun_out/r04f/r04_batch_sweep.txt 2>&1
 rm -rf gpurun_out/r04f/an64 gpurun_out/r04f/an512 gpurun_out/r04f/anfeco
 tail -3 gpurun_out/r04f/r04_audionet_cnn_bench.txt; head -c 300 gpurun_out/r04f/r04_bench_line.json
+mkdir -p gpurun_out/r04p2
+bash tools/pmc_an_fused.sh gpurun_out/r04p2/pmc_an512 512
+bash tools/pmc_an_fused.sh gpurun_out/r04p2/pmc_an64 64
+for b in 512 64; do for k in an_cnn_fwd_kernel an_cnn_bwd_kernel; do python tools/pmc_kernel.py gpurun_out/r04p2/pmc_an$b $k > gpurun_out/r04f/r04_pmc_${k}_b$b.json; done; done
+rm -rf gpurun_out/r04p2
+grep -h "mfma_busy_fraction" gpurun_out/r04f/r04_pmc_*.json
