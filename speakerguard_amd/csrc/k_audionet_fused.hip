@@ -24,6 +24,7 @@
 //   C >= 64 (rows a multiple of 256 bytes: every row starts at bank 0): slot16 ^ (row & 15) inside each 64-channel piece
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "sg_internal.h"
@@ -203,9 +204,59 @@ __device__ __forceinline__ void fz_mac(const float* __restrict__ in, const float
     }
 }
 
+// The same contraction on 16 x 16 output blocks (v_mfma_f32_16x16x4_f32), for layers so thin that 32 x 32 blocks leave
+// most of the block's waves without work (small time slices: conv6..conv8 of a quarter utterance have 1-4 such blocks for
+// 8 waves; a single utterance cut into 16 slices is thin everywhere).  Four times as many units, each with a quarter of
+// the dependent-MFMA chain: the k values an instruction consumes are its four 16-lane groups in order, so feeding lane
+// group g the k values (0, 4, 1, 5)[g] and then (2, 6, 3, 7)[g] of a k-group reproduces the order -- and the bits -- of the
+// 32 x 32 x 2 form (tools/native/mfma_order.hip; conv_gemm_s16_kernel does the same for the TDNN at batch 1-4).  Lane
+// (i = lane % 16, g = lane / 16): A row R0 = tile row i, 16-byte piece 2 kg + (g & 1) of the k-group, components g >> 1 and
+// 2 + (g >> 1); W column i of the block, the same piece and components.  W ring six chunks deep (a chunk is 8 MFMAs).
+// Measured (one box, tools/audionet_cnn_bench.py / tools/an_trace.py): 245 -> 235 us per pass pair at 128 rows (S = 2, the
+// configs[3] shard with EOT 2), no change at 64 rows (S = 4) and for a single utterance (S = 16: 52 us per launch either
+// way).  Why not more: a 16-column block streams the same W rows as a 32-column one for half the outputs, and lane groups
+// g and g + 2 fetch the same 16-byte pieces -- four times the W bytes per output through the CU's L1 (786 KB per layer and
+// block at K = 384: 5 us at 64 B/clk, against 1.8 us for the shorter MFMA chain it buys); requesting all of a unit's W up
+// front instead of six chunks ahead changed nothing.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int K, bool REV>
+__device__ __forceinline__ void fz_mac16(const float* __restrict__ in, const float4* __restrict__ wl, int ldw, int R0, f32x4v& acc) {
+    constexpr int NCH = 3 * K / 32, CPT = K / 32;
+    const int g = (threadIdx.x & 63) >> 4, g1 = g & 1;
+    const bool hi = (g >> 1) != 0;
+    constexpr int D = NCH < 6 ? NCH : 6;
+    float4 wr[D][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) wr[d][kg] = wl[(size_t)(d * 8 + 2 * kg) * ldw];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int j = ch / CPT, kc = ch % CPT;
+        float4 a[4];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) a[kg] = *reinterpret_cast<const float4*>(in + fz_off<K>(R0 + (REV ? 2 - j : j), kc * 32 + 8 * kg + 4 * g1));
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const float4 w = wr[ch % D][kg], x = a[kg];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? x.y : x.x, hi ? w.y : w.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? x.w : x.z, hi ? w.w : w.z, acc, 0, 0, 0);
+        }
+        if (ch + D < NCH) {
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) wr[ch % D][kg] = wl[(size_t)((ch + D) * 8 + 2 * kg) * ldw];
+        }
+    }
+}
+
+// row of accumulator element e inside its tile: 32 x 32 blocks (16 values per lane) / 16 x 16 blocks (4 values per lane)
+template <int NV>
+__device__ __forceinline__ constexpr int fz_ro(int e) { return NV == 16 ? (e & 3) + 8 * (e >> 2) : e; }
+
 // A wave's share of a layer: output column block wn of N / 32, and a contiguous share of the m-tiles, in units of up to
-// three 32-row tiles (one W operand stream feeds all of them).  epi(mi-th tile's first row, acc) consumes a finished tile.
-// pre(n0) runs before the unit's multiplications and its result is handed to epi: what the epilogue needs from memory (the
+// three 32-row tiles (one W operand stream feeds all of them).  epi(values per lane, tile's first row, tile height, the
+// lane's first row, the lane's column, accumulator, pre's value) consumes a finished tile (rows relative to the layer's first).
+// pre(column) runs before the unit's multiplications and its result is handed to epi: what the epilogue needs from memory (the
 // bias of the wave's columns) is requested there, so that its latency -- 1-2 us from the L2, once per unit, 4.7 us per
 // epilogue with the ReLU outputs' stores behind it in the first version -- passes under the MFMAs.
 template <int K, int N, bool REV, bool SMALL, typename Pre, typename Epi>
@@ -214,11 +265,28 @@ __device__ __forceinline__ void fz_layer(const float* __restrict__ in, const flo
     static_assert(NT >= 1 && NT <= kFzWaves && kFzWaves % NT == 0, "column blocks must divide the waves");
     const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wn = wid % NT, wg = wid / NT;
     const int mt = (n_out + 31) >> 5;
+    if (mt * NT * 2 <= kFzWaves) {
+        // thin layer: at most half of the waves would get a 32 x 32 block -> 16 x 16 blocks, dealt round-robin
+        constexpr int NT16 = N / 16;
+        const int l15 = lane & 15, g = lane >> 4;
+        const int units = ((n_out + 15) >> 4) * NT16;
+        for (int u = wid; u < units; u += kFzWaves) {
+            const int m16 = u / NT16, n16 = u - m16 * NT16;
+            const int col = n16 * 16 + l15;
+            const float4* wl = reinterpret_cast<const float4*>(wq) + (size_t)(g & 1) * N + col;
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+            const auto pv = pre(col);
+            fz_mac16<K, REV>(in, wl, N, min(m16 * 16 + l15, n_out - 1), acc);
+            epi(std::integral_constant<int, 4>{}, m16 * 16, 16, m16 * 16 + 4 * g, col, acc, pv);
+        }
+        return;
+    }
+    const int wn = wid % NT, wg = wid / NT;
     const int m_begin = wg * mt / G, m_end = (wg + 1) * mt / G;
-    const int n0 = wn * 32;
+    const int n0 = wn * 32, col = n0 + l31;
     const float4* wl = reinterpret_cast<const float4*>(wq) + (size_t)lhi * N + n0 + l31;
+    constexpr std::integral_constant<int, 16> t16{};
     for (int m = m_begin; m < m_end; m += 3) {
         const int cnt = min(3, m_end - m);
         // rows past the layer's last output row are computed on a clamped (valid) input row and dropped by the epilogue
@@ -229,10 +297,10 @@ __device__ __forceinline__ void fz_layer(const float* __restrict__ in, const flo
             for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
-            const auto pv = pre(n0);
+            const auto pv = pre(col);
             fz_mac<K, 3, REV, SMALL>(in, wl, N, R0, acc);
 #pragma unroll
-            for (int mi = 0; mi < 3; ++mi) epi((m + mi) * 32, n0, acc[mi], pv);
+            for (int mi = 0; mi < 3; ++mi) epi(t16, (m + mi) * 32, 32, (m + mi) * 32 + 4 * lhi, col, acc[mi], pv);
         } else if (cnt == 2) {
             const int R0[2] = {min(m * 32 + l31, n_out - 1), min(m * 32 + 32 + l31, n_out - 1)};
             f32x16 acc[2];
@@ -240,18 +308,18 @@ __device__ __forceinline__ void fz_layer(const float* __restrict__ in, const flo
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
-            const auto pv = pre(n0);
+            const auto pv = pre(col);
             fz_mac<K, 2, REV, SMALL>(in, wl, N, R0, acc);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) epi((m + mi) * 32, n0, acc[mi], pv);
+            for (int mi = 0; mi < 2; ++mi) epi(t16, (m + mi) * 32, 32, (m + mi) * 32 + 4 * lhi, col, acc[mi], pv);
         } else {
             const int R0[1] = {min(m * 32 + l31, n_out - 1)};
             f32x16 acc[1];
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[0][e] = 0.f;
-            const auto pv = pre(n0);
+            const auto pv = pre(col);
             fz_mac<K, 1, REV, SMALL>(in, wl, N, R0, acc);
-            epi(m * 32, n0, acc[0], pv);
+            epi(t16, m * 32, 32, m * 32 + 4 * lhi, col, acc[0], pv);
         }
     }
 }
@@ -282,7 +350,6 @@ __device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice
     }
     __syncthreads();
     if constexpr (L == 2) { FZ_STAMP(10) }
-    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
     float* act = p.act[L] + (size_t)row * Tout * COUT;
     float* pool = POOL ? p.pool[L] + (size_t)row * (Tout / 2) * COUT : nullptr;
     const float* bias = p.bias[L];
@@ -293,58 +360,58 @@ __device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice
     // one 32-bit offset per lane, compile-time row strides --, only ragged tiles check per element; and every computed
     // row goes to memory, halo rows included (they equal the neighbour slice's own rows bit for bit), which drops the
     // own-row tests.
-    constexpr int RO[16] = {0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27};
-    fz_layer<CIN, COUT, false, SMALL>(in, p.wq[L], n_out, [&](int n0) __attribute__((always_inline)) { return bias[n0 + l31]; },
-                               [&](int m0, int n0, const f32x16& acc, float bv) __attribute__((always_inline)) {
+    fz_layer<CIN, COUT, false, SMALL>(in, p.wq[L], n_out, [&](int col) __attribute__((always_inline)) { return bias[col]; },
+                               [&](auto nvt, int m0, int th, int r0, int col, const auto& acc, float bv) __attribute__((always_inline)) {
+        // nvt: accumulator values per lane (16: a 32 x 32 block, 4: a 16 x 16 block); m0 / th: the tile's first row and
+        // height; r0: the lane's first row (rows relative to olo), its values are rows r0 + fz_ro(e)
+        constexpr int NV = decltype(nvt)::value;
         if constexpr (L == 2) { FZ_STAMP(11) }
-        const int col = n0 + l31;
-        float v[16];
+        float v[NV];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = fmaxf(acc[e] + bv, 0.f);
-        const int r0 = m0 + 4 * lhi;  // the lane's first row, relative to olo
-        const bool full = !SMALL && m0 + 32 <= n_out;  // (SMALL: the compact, fully checked form only -- see fz_mac)
+        for (int e = 0; e < NV; ++e) v[e] = fmaxf(acc[e] + bv, 0.f);
+        const bool full = !SMALL && m0 + th <= n_out;  // (SMALL: the compact, fully checked form only -- see fz_mac)
         const unsigned g0 = (unsigned)((olo + r0) * COUT + col);
         if (full) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) act[g0 + RO[e] * COUT] = v[e];
+            for (int e = 0; e < NV; ++e) act[g0 + fz_ro<NV>(e) * COUT] = v[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (r0 + RO[e] < n_out) act[g0 + RO[e] * COUT] = v[e];
+            for (int e = 0; e < NV; ++e)
+                if (r0 + fz_ro<NV>(e) < n_out) act[g0 + fz_ro<NV>(e) * COUT] = v[e];
         }
         if constexpr (!POOL && !LAST) {
             const int q0 = olo + r0 - nbase, qt = olo + m0 - nbase;  // lane's / tile's first row in the next window
-            if (full && qt >= 0 && qt + 32 <= nrows) {
+            if (full && qt >= 0 && qt + th <= nrows) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) out[fz_off<CNEXT>(q0 + RO[e], col)] = v[e];
+                for (int e = 0; e < NV; ++e) out[fz_off<CNEXT>(q0 + fz_ro<NV>(e), col)] = v[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int q = q0 + RO[e];
-                    if (r0 + RO[e] < n_out && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = v[e];
+                for (int e = 0; e < NV; ++e) {
+                    const int q = q0 + fz_ro<NV>(e);
+                    if (r0 + fz_ro<NV>(e) < n_out && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = v[e];
                 }
             }
         }
-        if constexpr (POOL) {  // rows t, t + 1 (olo and RO[e] are even for even e): MaxPool1d(2)
+        if constexpr (POOL) {  // rows t, t + 1 (olo, r0 and fz_ro(e) are even for even e): MaxPool1d(2)
             const int p0 = (olo + r0) >> 1, pt = (olo + m0) >> 1;  // lane's / tile's first pooled row
             const unsigned gp0 = (unsigned)(p0 * COUT + col);
-            const bool pfull = full && pt + 16 <= Tout / 2;
+            const bool pfull = full && pt + th / 2 <= Tout / 2;
             if (pfull) {
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) pool[gp0 + (RO[e] >> 1) * COUT] = fmaxf(v[e], v[e + 1]);
+                for (int e = 0; e < NV; e += 2) pool[gp0 + (fz_ro<NV>(e) >> 1) * COUT] = fmaxf(v[e], v[e + 1]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; e += 2)
-                    if (r0 + RO[e] + 1 < n_out && p0 + (RO[e] >> 1) < Tout / 2) pool[gp0 + (RO[e] >> 1) * COUT] = fmaxf(v[e], v[e + 1]);
+                for (int e = 0; e < NV; e += 2)
+                    if (r0 + fz_ro<NV>(e) + 1 < n_out && p0 + (fz_ro<NV>(e) >> 1) < Tout / 2) pool[gp0 + (fz_ro<NV>(e) >> 1) * COUT] = fmaxf(v[e], v[e + 1]);
             }
-            if (pfull && pt - nbase >= 0 && pt - nbase + 16 <= nrows) {
+            if (pfull && pt - nbase >= 0 && pt - nbase + th / 2 <= nrows) {
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) out[fz_off<CNEXT>(p0 - nbase + (RO[e] >> 1), col)] = fmaxf(v[e], v[e + 1]);
+                for (int e = 0; e < NV; e += 2) out[fz_off<CNEXT>(p0 - nbase + (fz_ro<NV>(e) >> 1), col)] = fmaxf(v[e], v[e + 1]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const int pr = p0 + (RO[e] >> 1), q = pr - nbase;
-                    if (r0 + RO[e] + 1 < n_out && pr < Tout / 2 && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = fmaxf(v[e], v[e + 1]);
+                for (int e = 0; e < NV; e += 2) {
+                    const int pr = p0 + (fz_ro<NV>(e) >> 1), q = pr - nbase;
+                    if (r0 + fz_ro<NV>(e) + 1 < n_out && pr < Tout / 2 && q >= 0 && q < nrows) out[fz_off<CNEXT>(q, col)] = fmaxf(v[e], v[e + 1]);
                 }
             }
         }
@@ -445,52 +512,49 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
     constexpr int PW = kAnMel + 4;  // L = 0: d pre goes to a zero-bordered plain image [rows + 4][36] (see the forward pre-filter)
     fz_zero(out, FIRST ? ((nrows + 4) * PW + 3) & ~3 : nrows * N);
     __syncthreads();
-    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
     const int Tprev = FIRST ? p.Fnet : p.Tout[L > 0 ? L - 1 : 0];
     const float* aprev = FIRST ? nullptr : p.act[L > 0 ? L - 1 : 0] + (size_t)row * Tprev * N;
     // (epilogue structure as in the forward layer: wave-uniform straight path for whole tiles inside the next window, 32-bit
     // offsets, per-element checks only on ragged tiles)
-    constexpr int RO[16] = {0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27};
     fz_layer<K, N, true, SMALL>(in, p.wq[L], n_out, [](int) __attribute__((always_inline)) { return 0; },
-                         [&](int m0, int n0, const f32x16& acc, int) __attribute__((always_inline)) {
-        const int col = n0 + l31;
-        const int r0 = m0 + 4 * lhi;          // the lane's first row, relative to ilo
-        const bool full = !SMALL && m0 + 32 <= n_out;  // all 32 rows of the tile are rows of d input-of-L to produce (SMALL: checked form only)
+                         [&](auto nvt, int m0, int th, int r0, int col, const auto& acc, int) __attribute__((always_inline)) {
+        constexpr int NV = decltype(nvt)::value;  // (interface: see the forward layer)
+        const bool full = !SMALL && m0 + th <= n_out;  // all rows of the tile are rows of d input-of-L to produce (SMALL: checked form only)
         if constexpr (FIRST) {
             const int q0 = ilo + r0 - nbase;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int q = q0 + RO[e];
-                if (r0 + RO[e] < n_out && q >= 0 && q < nrows) out[(q + 2) * PW + 2 + col] = acc[e];
+            for (int e = 0; e < NV; ++e) {
+                const int q = q0 + fz_ro<NV>(e);
+                if (r0 + fz_ro<NV>(e) < n_out && q >= 0 && q < nrows) out[(q + 2) * PW + 2 + col] = acc[e];
             }
         } else if constexpr (INPOOL) {
             // pooled row pr <- rows 2 pr (first maximum wins a tie, like torch) / 2 pr + 1 of act[L - 1], ReLU mask applied
             const int pr0 = ilo + r0, q0 = 2 * pr0 - nbase, qt = 2 * (ilo + m0) - nbase;
-            float a0[16], a1[16];
-            if (full && ilo + m0 + 32 <= Tprev / 2 && qt >= 0 && qt + 64 <= nrows) {
+            float a0[NV], a1[NV];
+            if (full && ilo + m0 + th <= Tprev / 2 && qt >= 0 && qt + 2 * th <= nrows) {
                 const unsigned g0 = (unsigned)(2 * pr0 * N + col);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    a0[e] = aprev[g0 + 2 * RO[e] * N];
-                    a1[e] = aprev[g0 + (2 * RO[e] + 1) * N];
+                for (int e = 0; e < NV; ++e) {
+                    a0[e] = aprev[g0 + 2 * fz_ro<NV>(e) * N];
+                    a1[e] = aprev[g0 + (2 * fz_ro<NV>(e) + 1) * N];
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                for (int e = 0; e < NV; ++e) {
                     const bool first = !(a1[e] > a0[e]);
-                    out[fz_off<N>(q0 + 2 * RO[e], col)] = (first && a0[e] > 0.f) ? acc[e] : 0.f;
-                    out[fz_off<N>(q0 + 2 * RO[e] + 1, col)] = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
+                    out[fz_off<N>(q0 + 2 * fz_ro<NV>(e), col)] = (first && a0[e] > 0.f) ? acc[e] : 0.f;
+                    out[fz_off<N>(q0 + 2 * fz_ro<NV>(e) + 1, col)] = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int pr = min(pr0 + RO[e], Tprev / 2 - 1);
+                for (int e = 0; e < NV; ++e) {
+                    const int pr = min(pr0 + fz_ro<NV>(e), Tprev / 2 - 1);
                     a0[e] = aprev[(unsigned)(2 * pr * N + col)];
                     a1[e] = aprev[(unsigned)((2 * pr + 1) * N + col)];
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int pr = pr0 + RO[e];
-                    if (r0 + RO[e] < n_out && pr < Tprev / 2) {
+                for (int e = 0; e < NV; ++e) {
+                    const int pr = pr0 + fz_ro<NV>(e);
+                    if (r0 + fz_ro<NV>(e) < n_out && pr < Tprev / 2) {
                         const bool first = !(a1[e] > a0[e]);
                         const float g0 = (first && a0[e] > 0.f) ? acc[e] : 0.f, g1 = (!first && a1[e] > 0.f) ? acc[e] : 0.f;
                         const int q = 2 * pr - nbase;
@@ -501,20 +565,20 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
             }
         } else {
             const int t0 = ilo + r0, q0 = t0 - nbase, qt = ilo + m0 - nbase;
-            float mk[16];
-            if (full && ilo + m0 + 32 <= Tprev && qt >= 0 && qt + 32 <= nrows) {
+            float mk[NV];
+            if (full && ilo + m0 + th <= Tprev && qt >= 0 && qt + th <= nrows) {
                 const unsigned g0 = (unsigned)(t0 * N + col);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mk[e] = aprev[g0 + RO[e] * N];
+                for (int e = 0; e < NV; ++e) mk[e] = aprev[g0 + fz_ro<NV>(e) * N];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) out[fz_off<N>(q0 + RO[e], col)] = mk[e] > 0.f ? acc[e] : 0.f;
+                for (int e = 0; e < NV; ++e) out[fz_off<N>(q0 + fz_ro<NV>(e), col)] = mk[e] > 0.f ? acc[e] : 0.f;
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mk[e] = aprev[(unsigned)(min(t0 + RO[e], Tprev - 1) * N + col)];
+                for (int e = 0; e < NV; ++e) mk[e] = aprev[(unsigned)(min(t0 + fz_ro<NV>(e), Tprev - 1) * N + col)];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int q = q0 + RO[e];
-                    if (r0 + RO[e] < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = mk[e] > 0.f ? acc[e] : 0.f;
+                for (int e = 0; e < NV; ++e) {
+                    const int q = q0 + fz_ro<NV>(e);
+                    if (r0 + fz_ro<NV>(e) < n_out && q >= 0 && q < nrows) out[fz_off<N>(q, col)] = mk[e] > 0.f ? acc[e] : 0.f;
                 }
             }
         }
