@@ -4,6 +4,9 @@
 //   MaxPool1d(2) forward / un-pool + ReLU mask      :77,94,111
 //   max over time, Linear, decision, loss, backward :205-211,246-257 + attack/utils.py losses
 // Activations are channel-last (B, T, C) like everywhere else in the library.
+#include <cstdio>
+#include <cstdlib>
+
 #include "loss_device.h"
 #include "sg_internal.h"
 #include "fft512.h"
@@ -407,7 +410,10 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
                                                       float* __restrict__ emb_out, float* __restrict__ scores_out,
                                                       int64_t* __restrict__ dec_out, float* __restrict__ loss_out,
                                                       float* __restrict__ dact8, float* __restrict__ loss_trace,
-                                                      int64_t* __restrict__ dec_trace, uint8_t* __restrict__ success, int coef_rows) {
+                                                      int64_t* __restrict__ dec_trace, uint8_t* __restrict__ success, int coef_rows,
+                                                      unsigned long long* __restrict__ trace) {
+#define ATSTAMP(i) if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[i] = __builtin_amdgcn_s_memrealtime();
+    ATSTAMP(0)
     __shared__ float emb[32];
     __shared__ int arg[32];
     __shared__ float sc[kLossMaxS], dsc[kLossMaxS];
@@ -442,6 +448,7 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    ATSTAMP(1)
     for (int s = tid; s < S; s += 256) {
         float acc = 0.f;
 #pragma unroll
@@ -452,6 +459,7 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         if (scores_out) scores_out[(size_t)b * S + s] = acc;
     }
     __syncthreads();
+    ATSTAMP(2)
     {
         __shared__ float ex[kLossMaxS];
         __shared__ float bc[4];
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    ATSTAMP(3)
     if (!want_grad || !dact8) return;
     {   // d emb[c] = sum_s dsc[s] fc_w[s][c]: 8 class-strided partial sums per channel, combined in a fixed order,
         // loads unguarded (a guarded load in this loop serialised 251 L2 round trips per utterance)
@@ -484,11 +493,14 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    ATSTAMP(4)
     // gradient wrt the pre-activation of conv8: only the arg-max frame of each channel, if it is > 0
     for (int i = tid; i < T8 * 32; i += 256) {
         const int t = i >> 5, c = i & 31;
         dact8[(size_t)b * T8 * 32 + i] = (t == arg[c] && emb[c] > 0.f) ? demb[c] : 0.f;
     }
+    ATSTAMP(5)
+#undef ATSTAMP
 }
 
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
@@ -532,8 +544,19 @@ hipError_t launch_an_tail(const float* act8, int B, int T8, const float* fc_w, c
                           int64_t* decisions, float* loss, float* dact8, float* loss_trace, int64_t* dec_trace,
                           uint8_t* success, hipStream_t s, int coef_rows) {
     if (S < 1 || S > kLossMaxS) return hipErrorInvalidValue;
+    // tuning aid: SG_AN_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
+    static const bool tr_on = getenv("SG_AN_TAIL_TRACE") != nullptr;
+    static unsigned long long* tr_dev = nullptr;
+    if (tr_on && !tr_dev) (void)hipMalloc(reinterpret_cast<void**>(&tr_dev), 8 * 8);
     hipLaunchKernelGGL(an_tail_kernel, dim3(B), dim3(256), 0, s, act8, T8, fc_w, fc_b, S, threshold, y, ls, want_grad, emb,
-                       scores, decisions, loss, dact8, loss_trace, dec_trace, success, coef_rows);
+                       scores, decisions, loss, dact8, loss_trace, dec_trace, success, coef_rows, tr_on ? tr_dev : nullptr);
+    if (tr_on && tr_dev && hipStreamSynchronize(s) == hipSuccess) {
+        unsigned long long h[8];
+        if (hipMemcpy(h, tr_dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "an_tail phases (us): max-over-time %.2f  fc %.2f  loss %.2f  d emb %.2f  d act8 %.2f  total %.2f\n", (h[1] - h[0]) * 0.01,
+                    (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01, (h[5] - h[0]) * 0.01);
+        }
+    }
     return hipGetLastError();
 }
 

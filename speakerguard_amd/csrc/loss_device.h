@@ -13,15 +13,45 @@ namespace sg {
 
 constexpr int kLossMaxS = 1024;
 
+// argmax in index order (the first maximum wins), eight independent loads in flight per step: written as one load +
+// compare per iteration, a single thread walking the 251 classes of the AudioNet head paid an LDS round trip per class
+// (6 us; together with the equally serial sum below 17 of the 23 us of an_tail_kernel).  Same comparisons, same order.
+__device__ __forceinline__ void argmax_in_order(const float* sc, int S, float& mx, int& ja) {
+    mx = sc[0];
+    ja = 0;
+    int s = 1;
+    for (; s + 8 <= S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sc[s + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > mx) { mx = v[u]; ja = s + u; }
+    }
+    for (; s < S; ++s)
+        if (sc[s] > mx) { mx = sc[s]; ja = s; }
+}
+// sum of ex[s], s != skip, in index order; the skipped term enters as + 0.f, which leaves a sum that started at + 0 unchanged
+__device__ __forceinline__ float sum_in_order_except(const float* ex, int S, int skip) {
+    float so = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ex[s + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) so += (s + u != skip) ? v[u] : 0.f;
+    }
+    for (; s < S; ++s) so += (s != skip) ? ex[s] : 0.f;
+    return so;
+}
+
 // sc[S]: scores (LDS or registers); dsc[S]: must be zero on entry, receives d loss / d scores.
 // coef: this utterance's row of ls.coef_dev (SG_LOSS_LINEAR), else unused.
-__device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, int S, float threshold, int64_t yy,
-                                                  bool has_y, const sg_loss_spec& ls, int64_t* dec_out,
-                                                  const float* coef = nullptr) {
-    int ja = 0;
-    float mx = sc[0];
-    for (int s = 1; s < S; ++s)
-        if (sc[s] > mx) { mx = sc[s]; ja = s; }
+// (mx, ja): the maximum score and the first index that holds it
+__device__ __forceinline__ float loss_and_dscores_given(const float* sc, float* dsc, int S, float threshold, int64_t yy,
+                                                        bool has_y, const sg_loss_spec& ls, int64_t* dec_out, const float* coef,
+                                                        float mx, int ja) {
     *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
     float loss = 0.f;
     if (ls.loss == SG_LOSS_LINEAR) {  // vector-Jacobian product of the scores: the label plays no role
@@ -101,39 +131,76 @@ __device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, i
     return loss;
 }
 
+__device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, int S, float threshold, int64_t yy,
+                                                  bool has_y, const sg_loss_spec& ls, int64_t* dec_out,
+                                                  const float* coef = nullptr) {
+    int ja;
+    float mx;
+    argmax_in_order(sc, S, mx, ja);
+    return loss_and_dscores_given(sc, dsc, S, threshold, yy, has_y, ls, dec_out, coef, mx, ja);
+}
+
+// The same (maximum, first index holding it) by the whole block: per-thread scan in ascending index order, then merges
+// that prefer the larger value and, among equal values, the lower index -- order-independent, so the result is the serial
+// one whatever the reduction tree (scores are finite; -inf everywhere gives index 0 like the serial scan).  scratch: 2
+// floats per wave.  Ends with a barrier; valid on every thread.
+__device__ __forceinline__ void argmax_block(const float* sc, int S, int tid, int nt, float* scratch, float& mx, int& ja) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (tid < S) { bv = sc[tid]; bi = tid; }
+    for (int s = tid + nt; s < S; s += nt) {
+        const float v = sc[s];
+        if (v > bv) { bv = v; bi = s; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();  // (scratch may still be read by an earlier phase)
+    if ((tid & 63) == 0) {
+        scratch[2 * (tid >> 6)] = bv;
+        scratch[2 * (tid >> 6) + 1] = __int_as_float(bi);
+    }
+    __syncthreads();
+    bv = scratch[0];
+    bi = __float_as_int(scratch[1]);
+    for (int w = 1; w < nt / 64; ++w) {
+        const float ov = scratch[2 * w];
+        const int oi = __float_as_int(scratch[2 * w + 1]);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    mx = bv;
+    ja = bi;
+    __syncthreads();
+}
+
 // Block-cooperative form, called by ALL threads of the block (it synchronises); the returned loss and *dec_out are valid
 // on thread 0.  Only the cross-entropy branch differs from the serial function: its 2 S expf evaluations -- 40 us on one
-// thread for the 251 classes of the AudioNet head -- are spread over the block, while every reduction stays on thread 0
-// in index order, so the result is bit-identical to loss_and_dscores.  ex: S floats of LDS scratch, bc: 4 floats.
+// thread for the 251 classes of the AudioNet head -- are spread over the block, while the SUM stays on thread 0 in index
+// order (eight loads in flight per step) and the arg-max, which does not depend on the order, is a block reduction
+// (round 4: the two serial scans were 17 of the 23 us of an_tail_kernel; now 5 of 11), so the result is bit-identical to
+// loss_and_dscores.  ex: max(S, 32) floats of LDS scratch, bc: 4 floats.
 __device__ __forceinline__ float loss_and_dscores_block(const float* sc, float* dsc, float* ex, float* bc, int S, float threshold,
                                                         int64_t yy, bool has_y, const sg_loss_spec& ls, int64_t* dec_out, int tid,
                                                         int nt, const float* coef = nullptr) {
     const bool ce = has_y && ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI && yy >= 0;  // block-uniform
+    float mx;
+    int ja;
+    argmax_block(sc, S, tid, nt, ex, mx, ja);  // (one thread scanning the 251 AudioNet classes took 6 us)
     if (!ce) {
         float loss = 0.f;
-        if (tid == 0) loss = loss_and_dscores(sc, dsc, S, threshold, yy, has_y, ls, dec_out, coef);
+        if (tid == 0) loss = loss_and_dscores_given(sc, dsc, S, threshold, yy, has_y, ls, dec_out, coef, mx, ja);
         __syncthreads();
         return loss;
     }
-    if (tid == 0) {
-        int ja = 0;
-        float mx = sc[0];
-        for (int s = 1; s < S; ++s)
-            if (sc[s] > mx) { mx = sc[s]; ja = s; }
-        *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
-        bc[0] = mx;
-        bc[1] = __int_as_float(ja);
-    }
-    __syncthreads();
-    const float mx = bc[0];
-    const int ja = __float_as_int(bc[1]);
+    if (tid == 0) *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
     for (int s = tid; s < S; s += nt) ex[s] = expf(sc[s] - mx);
     __syncthreads();
     float loss = 0.f;
     if (tid == 0) {
-        float so = 0.f;
-        for (int s = 0; s < S; ++s)
-            if (s != ja) so += ex[s];
+        const float so = sum_in_order_except(ex, S, ja);
         const float lse = logf(1.f + so);
         loss = lse - (sc[yy] - mx);
         bc[2] = lse;
