@@ -20,6 +20,7 @@
 // falls back to frame i when `force` (batch > 1) and is dropped otherwise (the host compacts).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "sg_internal.h"
 #include "philox.h"
@@ -39,6 +40,13 @@ int feco_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
     if (ctx) ctx->err = buf;
     return code;
 }
+
+// tuning aid (SG_FECO_TRACE=1): phase timestamps (100 MHz) of block (0, 0): per iteration [start, after the assignment,
+// after the member lists, after the update]
+__device__ unsigned long long g_feco_trace[4 * 16 + 4];
+__device__ int g_feco_trace_on;
+#define FECO_STAMP(i) \
+    if (g_feco_trace_on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (i) < 4 * 16 + 4) g_feco_trace[i] = __builtin_amdgcn_s_memrealtime();
 
 constexpr int kFecoMaxD = 64;
 __host__ __device__ constexpr int al4(int n) { return (n + 3) & ~3; }
@@ -86,8 +94,8 @@ __device__ __forceinline__ float2v pk_sub_xhi(float2v x, float2v c) {
 //     same ids, same ascending sums, same division -- so the kernel can hand them out itself (out / counts, an empty
 //     cluster i taking frame i): the separate compress launch walked all F ids per output element (28 us).
 // Same arithmetic, same order, same ids as before (oracle/feco.py restates the contract; tests compare bit for bit).
-// Dynamic LDS (every array 16-byte aligned): cs[ceil(k/2)][DPAD][2], ids[F], cnt[k], start[k + 1], members[F], pd[1024],
-// pj[1024], xs[F][D] (when it fits).
+// Dynamic LDS (every array 16-byte aligned): cs[ceil(k/2)][DPAD][2], ids[F], cnt[k], start[k + 1], members[F], pd[2048],
+// pj[2048], xs[F][D] (when it fits).
 template <int DPAD>
 __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
                                                            int max_iter, int seeded, uint64_t seed, int64_t index_base,
@@ -100,9 +108,9 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
     int* cnt = ids + al4(F);                                     // [k]
     int* start = cnt + al4(k);                                   // [k + 1]
     int* members = start + al4(k + 1);                           // [F] frames grouped by cluster, ascending inside a group
-    float* pd = reinterpret_cast<float*>(members + al4(F));      // [1024] chunk minima
-    int* pj = reinterpret_cast<int*>(pd + 1024);                 // [1024]
-    float* xs = reinterpret_cast<float*>(pj + 1024);             // [F][D] the frames, if x_in_lds
+    float* pd = reinterpret_cast<float*>(members + al4(F));      // [2048] chunk minima: [chunk][frame of the pass]
+    int* pj = reinterpret_cast<int*>(pd + 2048);                 // [2048]
+    float* xs = reinterpret_cast<float*>(pj + 2048);             // [F][D] the frames, if x_in_lds
     __shared__ int changed;
     const int tid = threadIdx.x;
     // blockIdx.y = repeat: the same utterances clustered again from other random frames (EOT over the defense); repeat r
@@ -143,76 +151,100 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
         }
         cs[CS_AT(j, d)] = v;
     }
-    // thread = (frame slot li, centroid chunk jc); F <= 1024: one pass, the frame stays in registers
-    const int fpp = F <= 1024 ? F : 1024;
-    const int JC = F <= 1024 ? max(1, min(8, 1024 / F)) : 1;
-    const int li = tid % fpp, jc = tid / fpp;
+    // thread = (frame slot li, centroid chunk jc), TWO frames per thread (li and li + slots): a centroid read (16-byte LDS
+    // broadcast) serves both frames -- half the 6.5 MB of LDS reads per assignment step.  Phase trace (SG_FECO_TRACE) at 64 x
+    // 300 x 32, k = 150: assignment 25.5 -> 23.5 us per step (lists 5.6, update 2.1) -- so the step is bound by its packed
+    // sub / mul / add (16 us at the full packed rate: it runs at ~70 % of it), not by the LDS; the third of them that an
+    // fma would save is the contract's separate roundings.  Same arithmetic per (frame, centroid); chunk minima are still
+    // merged in ascending centroid order.  F <= 2048: one pass, the frames stay in registers.
+    // (D > 32: one frame per thread -- two frames of 64 dimensions do not fit the 128 registers of a 1024-thread block)
+    constexpr bool TWO = DPAD == 32;
+    constexpr int PMAX = TWO ? 2048 : 1024;
+    const int P = F <= PMAX ? F : PMAX;         // frames per pass
+    const int slots = TWO ? (P + 1) / 2 : P;    // thread slots per chunk
+    const int JC = max(1, min(8, 1024 / slots));  // JC * P <= 2048: capacity of pd / pj
+    const int li = tid % slots, jc = tid / slots;
     const bool worker = jc < JC;
     const int plo = (int)((long long)npair * jc / JC), phi = worker ? (int)((long long)npair * (jc + 1) / JC) : 0;
-    float2v xr[DPAD / 2];  // the frame, dimensions (2q, 2q + 1) per register pair
+    float2v xr0[DPAD / 2], xr1[TWO ? DPAD / 2 : 1];  // the two frames, dimensions (2q, 2q + 1) per register pair
+    auto load_frames = [&](int f0) __attribute__((always_inline)) {
+        const int i0 = f0 + li, i1 = f0 + li + slots, fend = min(F, f0 + P);
 #pragma unroll
-    for (int q = 0; q < DPAD / 2; ++q) {
-        xr[q].x = (worker && li < F && 2 * q < D) ? x[(size_t)li * D + 2 * q] : 0.f;
-        xr[q].y = (worker && li < F && 2 * q + 1 < D) ? x[(size_t)li * D + 2 * q + 1] : 0.f;
-    }
+        for (int q = 0; q < DPAD / 2; ++q) {
+            xr0[q].x = (worker && i0 < fend && 2 * q < D) ? x[(size_t)i0 * D + 2 * q] : 0.f;
+            xr0[q].y = (worker && i0 < fend && 2 * q + 1 < D) ? x[(size_t)i0 * D + 2 * q + 1] : 0.f;
+            if constexpr (TWO) {
+                xr1[q].x = (worker && i1 < fend && 2 * q < D) ? x[(size_t)i1 * D + 2 * q] : 0.f;
+                xr1[q].y = (worker && i1 < fend && 2 * q + 1 < D) ? x[(size_t)i1 * D + 2 * q + 1] : 0.f;
+            }
+        }
+    };
+    load_frames(0);
     __syncthreads();
     for (int it = 0; it < max_iter; ++it) {
+        FECO_STAMP(4 * it)
         if (tid == 0) changed = 0;
         __syncthreads();
-        for (int f0 = 0; f0 < F; f0 += fpp) {
-            const int i = f0 + li;
-            if (F > fpp) {  // long utterances (several passes): load the frame of this pass
-#pragma unroll
-                for (int q = 0; q < DPAD / 2; ++q) {
-                    xr[q].x = (worker && i < F && 2 * q < D) ? x[(size_t)i * D + 2 * q] : 0.f;
-                    xr[q].y = (worker && i < F && 2 * q + 1 < D) ? x[(size_t)i * D + 2 * q + 1] : 0.f;
-                }
-            }
-            float best = INFINITY;
-            int bj = 2 * plo;
-            if (worker && i < F) {
+        for (int f0 = 0; f0 < F; f0 += P) {
+            const int np = min(P, F - f0);  // frames of this pass
+            if (F > P) load_frames(f0);     // long utterances (several passes)
+            float best0 = INFINITY, best1 = INFINITY;
+            int bj0 = 2 * plo, bj1 = 2 * plo;
+            if (worker && li < np) {
                 for (int pr = plo; pr < phi; ++pr) {
                     const float4* c4 = reinterpret_cast<const float4*>(cs + (size_t)pr * 2 * DPAD);
-                    float2v acc = {0.f, 0.f};  // (distance to centroid 2 pr, to centroid 2 pr + 1)
+                    float2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};  // (distance to centroid 2 pr, to centroid 2 pr + 1) per frame
 #pragma unroll
                     for (int q = 0; q < DPAD / 2; ++q) {  // d ascending; pad dims add +0 (x = c = 0), acc unchanged
                         const float4 c = c4[q];            // c[2q] of both centroids, c[2q + 1] of both
                         const float2v c0 = {c.x, c.y}, c1 = {c.z, c.w};
-                        float2v df = pk_sub_xlo(xr[q], c0);
-                        acc = acc + df * df;
-                        df = pk_sub_xhi(xr[q], c1);
-                        acc = acc + df * df;
+                        float2v df = pk_sub_xlo(xr0[q], c0);
+                        acc0 = acc0 + df * df;
+                        df = pk_sub_xhi(xr0[q], c1);
+                        acc0 = acc0 + df * df;
+                        if constexpr (TWO) {
+                            df = pk_sub_xlo(xr1[q], c0);
+                            acc1 = acc1 + df * df;
+                            df = pk_sub_xhi(xr1[q], c1);
+                            acc1 = acc1 + df * df;
+                        }
                     }
-                    if (acc.x < best) {
-                        best = acc.x;
-                        bj = 2 * pr;
-                    }
-                    if (2 * pr + 1 < k && acc.y < best) {
-                        best = acc.y;
-                        bj = 2 * pr + 1;
+                    const bool odd_ok = 2 * pr + 1 < k;
+                    if (acc0.x < best0) { best0 = acc0.x; bj0 = 2 * pr; }
+                    if (odd_ok && acc0.y < best0) { best0 = acc0.y; bj0 = 2 * pr + 1; }
+                    if constexpr (TWO) {
+                        if (acc1.x < best1) { best1 = acc1.x; bj1 = 2 * pr; }
+                        if (odd_ok && acc1.y < best1) { best1 = acc1.y; bj1 = 2 * pr + 1; }
                     }
                 }
             }
-            pd[tid] = best;
-            pj[tid] = bj;
+            if (worker && li < np) {
+                pd[jc * np + li] = best0;
+                pj[jc * np + li] = bj0;
+                if (TWO && li + slots < np) {
+                    pd[jc * np + li + slots] = best1;
+                    pj[jc * np + li + slots] = bj1;
+                }
+            }
             __syncthreads();
-            if (jc == 0 && i < F) {  // merge the chunks in ascending centroid order: the lowest index wins ties
-                float b = pd[li];
-                int bb = pj[li];
+            for (int r = tid; r < np; r += 1024) {  // merge the chunks in ascending centroid order: the lowest index wins ties
+                float b = pd[r];
+                int bb = pj[r];
                 for (int c = 1; c < JC; ++c) {
-                    const float v = pd[c * fpp + li];
+                    const float v = pd[c * np + r];
                     if (v < b) {
                         b = v;
-                        bb = pj[c * fpp + li];
+                        bb = pj[c * np + r];
                     }
                 }
-                if (ids[i] != bb) {
-                    ids[i] = bb;
+                if (ids[f0 + r] != bb) {
+                    ids[f0 + r] = bb;
                     changed = 1;
                 }
             }
             __syncthreads();
         }
+        FECO_STAMP(4 * it + 1)
         if (!changed) break;
         // member lists.  Counts: one LDS atomic per frame.
         for (int j = tid; j < k; j += 1024) cnt[j] = 0;
@@ -244,6 +276,7 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
             members[start[j] + pos] = i;
         }
         __syncthreads();
+        FECO_STAMP(4 * it + 2)
         // update: thread (j, d) sums its cluster's frames in ascending frame order; an empty cluster keeps its centroid
         for (int e = tid; e < k * DPAD; e += 1024) {
             const int j = e / DPAD, d = e - j * DPAD;
@@ -257,7 +290,9 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
             }
         }
         __syncthreads();
+        FECO_STAMP(4 * it + 3)
     }
+    FECO_STAMP(4 * 16)
     // cnt / cs describe the final ids in both exits: "nothing changed" leaves the previous iteration's lists and means
     // valid, the max_iter exit has just rebuilt them
     if (out) {
@@ -269,6 +304,7 @@ __global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restri
         for (int j = tid; j < k; j += 1024) counts[slot * k + j] = cnt[j];
     }
     for (int i = tid; i < F; i += 1024) assign[slot * F + i] = ids[i];
+    FECO_STAMP(4 * 16 + 1)
 }
 
 // out[b][j][d] = mean over frames with id j (ascending order) or, for an empty cluster, feats[b][j][d]
@@ -341,7 +377,7 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     constexpr size_t kLdsMax = 150 * 1024;
     const int dpad = D <= 32 ? 32 : 64;
     size_t lds = (size_t)((k + 1) / 2) * 2 * dpad * sizeof(float) +
-                 ((size_t)2 * al4(F) + al4(k) + al4(k + 1)) * sizeof(int) + 2 * 1024 * sizeof(float);
+                 ((size_t)2 * al4(F) + al4(k) + al4(k + 1)) * sizeof(int) + 2 * 2048 * sizeof(float);
     const size_t xbytes = (size_t)F * D * sizeof(float);
     const int x_in_lds = lds + xbytes <= kLdsMax;  // the frames too, so the update never leaves the CU
     if (x_in_lds) lds += xbytes;
@@ -360,6 +396,25 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
                            seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
+    static const bool tr_on = getenv("SG_FECO_TRACE") != nullptr;
+    if (tr_on) {
+        static bool armed = false;
+        if (!armed) {
+            const int one = 1;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_trace_on), &one, sizeof(one));
+            armed = true;
+        } else if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
+            unsigned long long h[4 * 16 + 4];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_feco_trace), sizeof(h)) == hipSuccess) {
+                fprintf(stderr, "feco k-means phases (us), block (0, 0): set-up %.2f;", 0.0);
+                for (int it = 0; it < max_iter && it < 16 && h[4 * it + 1] > h[4 * it]; ++it)
+                    fprintf(stderr, " it%d assign %.2f lists %.2f update %.2f;", it, (h[4 * it + 1] - h[4 * it]) * 0.01,
+                            h[4 * it + 2] > h[4 * it + 1] ? (h[4 * it + 2] - h[4 * it + 1]) * 0.01 : 0.0,
+                            h[4 * it + 3] > h[4 * it + 2] ? (h[4 * it + 3] - h[4 * it + 2]) * 0.01 : 0.0);
+                fprintf(stderr, " out %.2f; loop + out total %.2f\n", (h[65] - h[64]) * 0.01, (h[65] - h[0]) * 0.01);
+            }
+        }
+    }
     return SG_OK;
 }
 
