@@ -52,6 +52,15 @@ hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::mem
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+// device globals: the host-only objects keep a host shadow of every __device__ variable; copy to / from that
+hipError_t hipMemcpyToSymbol(const void* sym, const void* src, size_t n, size_t off, hipMemcpyKind) {
+    std::memmove(const_cast<char*>(static_cast<const char*>(sym)) + off, src, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n, size_t off, hipMemcpyKind) {
+    std::memmove(dst, static_cast<const char*>(sym) + off, n);
+    return hipSuccess;
+}
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
