@@ -46,3 +46,18 @@ void sg_conv_chain(const float* a, const float* w, const float* bias, const floa
         }
     }
 }
+
+/* FeCo k-means assignment scores (speakerguard_amd/csrc/k_feco.hip, contract version 2): score(i, j) = h[j] + x'_i . c_j as
+ * ONE fmaf chain in the k order above (Dp = 32 or 64 padded dimensions, pad entries zero).  The reference delegates the
+ * clustering to a randomly initialised third-party k-means (defense/feature_level.py:185-203): this restates the
+ * library's own contract, nothing of the reference.  xc (F, Dp), cc (k, Dp), h (k), out (F, k). */
+void sg_feco_scores(const float* xc, const float* cc, const float* h, float* out, int F, int k, int Dp) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < F; ++i)
+        for (int j = 0; j < k; ++j) {
+            float acc = h[j];
+            for (int g = 0; g < Dp; g += 8)
+                for (int s = 0; s < 8; ++s) acc = fmaf(cc[(size_t)j * Dp + g + kOrder[s]], xc[(size_t)i * Dp + g + kOrder[s]], acc);
+            out[(size_t)i * k + j] = acc;
+        }
+}

@@ -19,6 +19,7 @@ def _load():
             subprocess.run(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", _SO, "-lm"], check=True)
         _lib = C.CDLL(_SO)
         _lib.sg_conv_chain.restype = None
+        _lib.sg_feco_scores.restype = None
     return _lib
 
 
@@ -34,4 +35,19 @@ def conv_chain(a, w, B, Ta, Tc, taps, tap_step, tap_base=0, bias=None, mask=None
     epi = 1 if bias is not None else (2 if mask is not None else 0)
     _load().sg_conv_chain(a.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), fp(bias), fp(mask),
                           out.ctypes.data_as(C.c_void_p), B, Ta, Tc, Kc, N, taps, tap_step, tap_base, epi)
+    return out
+
+
+def feco_scores(xc, cc, h):
+    """FeCo assignment scores (k_feco.hip contract version 2): xc (F, Dp), cc (k, Dp), h (k) float32 -> (F, k) float32,
+    score(i, j) = fmaf chain from h[j] over the kernels' k order (Dp = 32 or 64, pad dimensions zero)."""
+    xc = np.ascontiguousarray(xc, np.float32)
+    cc = np.ascontiguousarray(cc, np.float32)
+    h = np.ascontiguousarray(h, np.float32)
+    F, Dp = xc.shape
+    k = cc.shape[0]
+    assert Dp in (32, 64) and cc.shape[1] == Dp and h.shape == (k,)
+    out = np.empty((F, k), np.float32)
+    _load().sg_feco_scores(xc.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p),
+                           out.ctypes.data_as(C.c_void_p), F, k, Dp)
     return out

@@ -4,20 +4,28 @@
 //
 // The reference calls a third-party k-means with a RANDOM initialisation (libKMCUDA / kmeans_pytorch), so its
 // cluster ids are not reproducible even between two runs of the reference.  The clustering here follows its own
-// DETERMINISM CONTRACT (restated in oracle/feco.py, checked bit for bit):
+// DETERMINISM CONTRACT (version 2, round 5: the assignment is a contraction on the matrix pipes; restated in
+// oracle/feco.py + oracle/conv_chain.c sg_feco_scores, checked bit for bit):
+//   * centring (k-means is translation invariant; it keeps the cancellation of the expanded distance small):
+//     mu[d] = (p_0 + p_1 + ... + p_15 in that order) / F with p_q = sum over frames i = q, q + 16, ... ascending (fp32, from
+//     0.f); x'[i][d] = x[i][d] - mu[d].  Everything below works on x'.
 //   * k = int(F * ratio) centroids, centroid j initialised to frame floor(j * F / k) -- or, for the SEEDED form
 //     (sg_feco_kmeans_seeded: what makes expectation-over-transformation against this defense meaningful, like
 //     the reference's randomly initialised k-means), to the frame of rank j when the frames are ordered by
 //     (Philox4x32-10(counter = (frame, 0, utterance lo, utterance hi), key = seed) word 0, frame) ascending:
 //     k distinct frames, a uniformly random subset in random order, a function of (seed, GLOBAL utterance index)
 //     only (oracle/philox.py feco_random_init);
-//   * assignment: squared L2 distance accumulated over d = 0..D-1 in fp32 without FMA contraction, nearest
-//     centroid wins, ties go to the lowest centroid index;
+//   * assignment: frame i goes to the centroid with the LARGEST score(i, j) = x'_i . c_j - |c_j|^2 / 2 (= the nearest one),
+//     ties to the lowest index.  The score is ONE fp32 fmaf chain: it starts at h_j = -0.5f * n_j and adds
+//     fmaf(c_j[d], x'_i[d], .) over d in the contraction kernels' order (groups of 8 ascending, inside a group 0, 4, 1, 5,
+//     2, 6, 3, 7; dimensions padded with zeros to DPAD = 32 or 64) -- what v_mfma_f32_32x32x2_f32 computes
+//     (tools/native/mfma_order.hip); n_j = the sum of the squares c_j[d]^2 (each rounded) over the DPAD padded
+//     dimensions by the butterfly s[d] += s[d ^ 1], s[d ^ 2], ... s[d ^ DPAD/2] (every step all d at once);
 //   * stop when no assignment changed or after max_iter assignment steps; otherwise update: centroid j = (sum of its
-//     frames in ascending frame order, fp32) / count, an empty cluster keeps its centroid;
+//     frames x' in ascending frame order, fp32, from 0.f) / count, an empty cluster keeps its centroid;
 //   * the ids of the LAST assignment step are the result.
-// Given the ids, the compression is the reference's :204-216: mean of the cluster's frames, an empty cluster i
-// falls back to frame i when `force` (batch > 1) and is dropped otherwise (the host compacts).
+// Given the ids, the compression is the reference's :204-216 on the ORIGINAL frames: mean of the cluster's frames, an
+// empty cluster i falls back to frame i when `force` (batch > 1) and is dropped otherwise (the host compacts).
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -42,269 +50,510 @@ int feco_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 // tuning aid (SG_FECO_TRACE=1): phase timestamps (100 MHz) of block (0, 0): per iteration [start, after the assignment,
-// after the member lists, after the update]
-__device__ unsigned long long g_feco_trace[4 * 16 + 4];
+// after the member lists, after the update] for the first 16 iterations, then [loop end, kernel end, kernel start]
+constexpr int kFecoTraceIters = 16;
+__device__ unsigned long long g_feco_trace[4 * kFecoTraceIters + 4 + 24];  // + detail stamps (set-up, iteration 0) + cycle counts
 __device__ int g_feco_trace_on;
+#ifdef SG_EXP_FECO_JC
+__device__ int g_feco_ablate;  // experiment builds only (never the shipped library): 1 no MFMAs, 2 no per-tile maxima, 4 no B operand loads
+#endif
 #define FECO_STAMP(i) \
-    if (g_feco_trace_on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (i) < 4 * 16 + 4) g_feco_trace[i] = __builtin_amdgcn_s_memrealtime();
+    if (g_feco_trace_on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_feco_trace[i] = __builtin_amdgcn_s_memrealtime();
+#define FECO_DETAIL(i) FECO_STAMP(4 * kFecoTraceIters + 4 + (i))
+#define FECO_CYCLES(i) \
+    if (g_feco_trace_on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_feco_trace[4 * kFecoTraceIters + 4 + (i)] = __builtin_readcyclecounter();
 
 constexpr int kFecoMaxD = 64;
+constexpr int kFecoThreads = 1024;
+constexpr int kFecoMaxChunks = 8;     // centroid-tile chunks a frame tile is cut into (JC)
+constexpr int kFecoMergeCap = 2048;   // JC * F <= this: capacity rule of the chunk-maxima arrays
 __host__ __device__ constexpr int al4(int n) { return (n + 3) & ~3; }
-typedef float float2v __attribute__((ext_vector_type(2)));
-// centroid j, dimension d inside the pair-interleaved image (rows of 2 * DPAD floats)
-#define CS_AT(j, d) ((size_t)((j) >> 1) * (2 * DPAD) + 2 * (size_t)(d) + ((j) & 1))
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// (x.lo - c.lo, x.lo - c.hi) and (x.hi - c.lo, x.hi - c.hi): one v_pk_add_f32 each.  The operand-select bits broadcast
-// one half of the x register pair to both lanes and the neg bits turn the add into an IEEE subtraction, so no
-// register is spent on splats (hipcc builds them with v_mov pairs and spills at 1024 threads per block).
-__device__ __forceinline__ float2v pk_sub_xlo(float2v x, float2v c) {
-    float2v r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float2v pk_sub_xhi(float2v x, float2v c) {
-    float2v r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(c));
-    return r;
+// Which units of the assignment a wave computes (host-built): u[wave][slot] = frame tile | first centroid tile << 8 | one
+// past the last << 16 | chunk index << 24, kFecoNoUnit = none; table == 0: more than 32 units, dealt round robin in the kernel.
+constexpr unsigned kFecoNoUnit = 0xFFFFFFFFu;
+struct FecoSched {
+    int table;
+    unsigned u[kFecoThreads / 64][2];
+};
+
+// Dynamic LDS of feco_kmeans_kernel in 4-byte words (every array 16-byte aligned); host and device use the same function.
+struct FecoLds {
+    int cq, hq, mu, part, ids, cnt, start, members, cw, spart, wtot, pd, pj, xq, total;
+};
+__host__ __device__ inline FecoLds feco_layout(int F, int k, int dpad, int JC, int fast_lists, int x_in_lds) {
+    const int kp = (k + 31) & ~31;
+    FecoLds L;
+    int o = 0;
+    L.cq = o; o += kp * dpad;              // centred centroids, [kp][dpad], 16-byte slots XOR-permuted per row
+    L.hq = o; o += kp;                     // -|c|^2 / 2
+    L.mu = o; o += dpad;
+    L.part = o; o += 16 * dpad;            // partial sums of the centring
+    L.ids = o; o += al4(F);
+    L.cnt = o; o += al4(k);
+    L.start = o; o += al4(k + 1);
+    L.members = o; o += al4(F);            // frames grouped by cluster, ascending inside a group
+    L.cw = o; o += fast_lists ? al4(((F + 63) >> 6) * k) : 0;   // members of cluster j among frames 64 c .. 64 c + 63
+    L.spart = o; o += fast_lists ? al4(k) : 0;                  // frames of the lower clusters of j's wave of clusters
+    L.wtot = o; o += fast_lists ? 16 : 0;                       // frames per wave of clusters
+    L.pd = o; o += JC > 1 ? al4(JC * F) : 0;                    // chunk maxima [chunk][frame]
+    L.pj = o; o += JC > 1 ? al4(JC * F) : 0;
+    L.xq = o; o += x_in_lds ? F * dpad : 0;                     // centred frames, same permuted rows
+    L.total = o;
+    return L;
 }
 
-// One 1024-thread block per utterance.  Round 1 kept frames and centroids in LDS and gave every thread a frame whose
-// D floats it re-read from LDS for every centroid: at D = 32 the 64 lanes of a wave hit ONE bank (stride 32 words) --
-// 3.1 ms per call at 64 x 300 x 32, 80 % of a step against a FeCo-defended AudioNet.  Now:
-//   * a thread keeps ITS frame in registers for the whole call (frames are read once, coalescing irrelevant), the
-//     centroids sit in LDS padded to DPAD floats per row and are read as 16-byte broadcasts;
-//   * the centroid range is cut into JC = 1024 / F chunks so that all 1024 threads work on the assignment (thread =
-//     (frame, chunk)); chunk minima are merged in ascending centroid order with a strict <, i.e. the lowest index still
-//     wins ties;
-//   * the update walks per-cluster member lists (built by a stable counting pass: ascending frame order, as the
-//     contract demands) instead of scanning all F ids for each of the k x D centroid entries.
-//   * the assignment is VALU-bound on the one CU an utterance gets (F x k x D x {sub, mul, add}: 4.3 M lane-operations at
-//     300 x 150 x 32 = 28 us per assignment step at 64 lanes per clock): centroids are kept in PAIRS, interleaved
-//     per dimension ([pair][d][2]), and a thread measures its frame against both centroids of a pair with packed-fp32
-//     instructions (v_pk_add_f32 / v_pk_mul_f32: two lane-operations per lane and clock) -- per centroid still
-//     sub, mul, add in ascending d with separate roundings, so the distances are the same bits.
-//   * what was left after that was LATENCY: the member lists were built by one thread per cluster walking all F ids
-//     (one LDS round trip per id), their offsets by thread 0 walking all k counts, and the update summed its members
-//     through a chain of dependent L2 loads -- together ~20 us of the ~30 us an iteration took.  Now the counts come
-//     from LDS atomics (one per frame), every cluster adds up the counts below it with 16-byte broadcast reads, every
-//     FRAME finds its own slot (number of earlier frames with its id: 16-byte reads again -- ascending frame order
-//     inside a cluster by construction), and the frames are staged in LDS once so the update never leaves the CU
-//     (utterances too long for that keep reading HBM / L2).
-//   * the cluster means the reference takes next (feature_level.py:204-216) ARE the centroids of the last update --
-//     same ids, same ascending sums, same division -- so the kernel can hand them out itself (out / counts, an empty
-//     cluster i taking frame i): the separate compress launch walked all F ids per output element (28 us).
-// Same arithmetic, same order, same ids as before (oracle/feco.py restates the contract; tests compare bit for bit).
-// Dynamic LDS (every array 16-byte aligned): cs[ceil(k/2)][DPAD][2], ids[F], cnt[k], start[k + 1], members[F], pd[2048],
-// pj[2048], xs[F][D] (when it fits).
+// float offset of 16-byte slot `slot` of row `row` in a [rows][DPAD] image: the 16 lanes one ds_read_b128 cycle serves
+// (MI355X_MICROARCH.md, LDS: rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row tile) hit 16 different slots
 template <int DPAD>
-__global__ __launch_bounds__(1024) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
-                                                           int max_iter, int seeded, uint64_t seed, int64_t index_base,
-                                                           int x_in_lds, int* __restrict__ assign, float* __restrict__ out,
-                                                           int* __restrict__ counts) {
+__device__ __forceinline__ int sw_slot(int row, int slot) {
+    const int key = DPAD == 32 ? ((row >> 1) & 7) : (row & 15);
+    return row * DPAD + ((slot ^ key) << 2);
+}
+template <int DPAD>
+__device__ __forceinline__ int sw_at(int row, int d) { return sw_slot<DPAD>(row, d >> 2) + (d & 3); }
+
+// The contract's butterfly over the DPAD lanes that hold a centroid row (s[d] += s[d ^ 1], s[d ^ 2], ...): what lane d = 0 ends
+// up with is the balanced pairwise tree over the row.  Steps 1 and 2 are quad permutes; after them a quad holds one value,
+// so mirroring the 8 lanes of a half row (then the 16 of a row) pairs exactly the quads the steps 4 and 8 pair -- four DPP
+// adds instead of four trips through the LDS crossbar; steps 16 (and 32) go through ds_bpermute.
+template <int DPAD>
+__device__ __forceinline__ float row_tree_sum(float v) {
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    v = v + __shfl_xor(v, 16);
+    if (DPAD == 64) v = v + __shfl_xor(v, 32);
+    return v;
+}
+
+// One 1024-thread block per (utterance, repeat).  Round 1 kept frames and centroids in LDS and gave every thread a frame
+// whose D floats it re-read from LDS for every centroid (3.1 ms per call at 64 x 300 x 32); rounds 2-4 kept a thread's
+// frame in registers and measured it against centroid pairs with packed fp32 sub / mul / add -- the contract then was the
+// literal sum of squared differences, 3 lane-operations per (frame, centroid, dimension), VALU-bound on the one CU an
+// instance gets: 23.5 us per assignment step at 300 x 150 x 32, 198 us per call (35 % of a PGD step against the
+// FeCo-defended AudioNet).  Round 5 (contract version 2 above):
+//   * the assignment is the contraction x' c^T on v_mfma_f32_32x32x2_f32 (A = 32 centroids, B = 32 frames, the accumulators
+//     start at h_j): one fused multiply-add per (frame, centroid, dimension) on the matrix pipes, 50 tile pairs x 16
+//     MFMAs = 5.3 us of the CU's four pipes at 300 x 150 x 32.  A unit of work is (frame tile, chunk of centroid tiles), dealt
+//     round-robin to the 16 waves; a lane keeps the running maximum of its 16 accumulator rows (ascending centroid, strict
+//     >), the two lane halves and then the chunks are merged in ascending centroid order: the lowest index wins ties;
+//   * operands come from LDS images whose 16-byte slots are XOR-permuted per row (conflict-free ds_read_b128; the k order
+//     0, 4, 1, 5, ... is what a lane half reading four consecutive dimensions per group gives);
+//   * member lists: per-64-frame-chunk counts by LDS atomics, a frame's rank inside its chunk by 64 v_readlane compares
+//     (was: every frame scanning all earlier ids, 5.6 us) -> ascending frame order inside a cluster by construction;
+//   * the update walks the member lists (LDS) and refreshes h_j with a butterfly over the lanes that hold the row;
+//   * the cluster means the reference takes next (feature_level.py:204-216) are the means of the ORIGINAL frames over the
+//     final lists -- same ids, same ascending sums, same division as feco_compress_kernel -- handed out by the kernel.
+template <int DPAD>
+__global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
+                                                                   int max_iter, int seeded, uint64_t seed, int64_t index_base,
+                                                                   int x_in_lds, int fast_lists, int JC, FecoSched sched,
+                                                                   int* __restrict__ assign, float* __restrict__ out,
+                                                                   int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int npair = (k + 1) >> 1;
-    float* cs = lds;                                             // [npair][DPAD][2], pad columns / odd partner zero
-    int* ids = reinterpret_cast<int*>(cs + (size_t)npair * 2 * DPAD);   // [F]
-    int* cnt = ids + al4(F);                                     // [k]
-    int* start = cnt + al4(k);                                   // [k + 1]
-    int* members = start + al4(k + 1);                           // [F] frames grouped by cluster, ascending inside a group
-    float* pd = reinterpret_cast<float*>(members + al4(F));      // [2048] chunk minima: [chunk][frame of the pass]
-    int* pj = reinterpret_cast<int*>(pd + 2048);                 // [2048]
-    float* xs = reinterpret_cast<float*>(pj + 2048);             // [F][D] the frames, if x_in_lds
+    const FecoLds L = feco_layout(F, k, DPAD, JC, fast_lists, x_in_lds);
+    const int kp = (k + 31) & ~31;
+    float* cq = lds + L.cq;
+    float* hq = lds + L.hq;
+    float* mu = lds + L.mu;
+    float* part = lds + L.part;
+    int* ids = reinterpret_cast<int*>(lds + L.ids);
+    int* cnt = reinterpret_cast<int*>(lds + L.cnt);
+    int* start = reinterpret_cast<int*>(lds + L.start);
+    int* members = reinterpret_cast<int*>(lds + L.members);
+    int* cw = reinterpret_cast<int*>(lds + L.cw);
+    int* spart = reinterpret_cast<int*>(lds + L.spart);
+    int* wtot = reinterpret_cast<int*>(lds + L.wtot);
+    float* pd = lds + L.pd;
+    int* pj = reinterpret_cast<int*>(lds + L.pj);
+    float* xq = lds + L.xq;
     __shared__ int changed;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, lh = lane >> 5, ln = lane & 31;
     // blockIdx.y = repeat: the same utterances clustered again from other random frames (EOT over the defense); repeat r
     // uses key seed + r * 0xC2B2AE3D27D4EB4F and writes slot r * gridDim.x + utterance of every output
     const float* x = feats + (size_t)blockIdx.x * F * D;
     const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     seed += (uint64_t)blockIdx.y * 0xC2B2AE3D27D4EB4Full;
-    for (int i = tid; i < al4(F); i += 1024) ids[i] = -1;  // the pad entries stay -1: no cluster
-    if (x_in_lds)
-        for (int e = tid; e < F * D; e += 1024) xs[e] = x[e];
-    const float* xu = x_in_lds ? xs : x;  // what the update reads
+    FECO_STAMP(4 * kFecoTraceIters + 2)
+    for (int i = tid; i < al4(F); i += kFecoThreads) ids[i] = -1;  // the pad entries stay -1: no cluster
+    if (fast_lists)
+        for (int e = tid; e < ((F + 63) >> 6) * k; e += kFecoThreads) cw[e] = 0;
+    // the raw frames go to LDS first (one batch of coalesced loads), the centring reads them there
+    if (x_in_lds) {
+        for (int e = tid; e < F * DPAD; e += kFecoThreads) {
+            const int i = e / DPAD, d = e - i * DPAD;
+            xq[sw_at<DPAD>(i, d)] = d < D ? x[(size_t)i * D + d] : 0.f;
+        }
+        __syncthreads();
+    }
+    // centring: 16 interleaved partial sums per dimension, added up in order
+    for (int e = tid; e < 16 * DPAD; e += kFecoThreads) {
+        const int q = e / DPAD, d = e - q * DPAD;
+        float s = 0.f;
+        if (d < D) {
+            if (x_in_lds) {
+#pragma unroll 8
+                for (int i = q; i < F; i += 16) s = s + xq[sw_at<DPAD>(i, d)];
+            } else {
+#pragma unroll 8
+                for (int i = q; i < F; i += 16) s = s + x[(size_t)i * D + d];
+            }
+        }
+        part[e] = s;
+    }
+    __syncthreads();
+    for (int d = tid; d < DPAD; d += kFecoThreads) {
+        float t = part[d];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t = t + part[q * DPAD + d];
+        mu[d] = d < D ? t / (float)F : 0.f;
+    }
+    __syncthreads();
+    FECO_DETAIL(0)
+    FECO_CYCLES(20)
+    if (x_in_lds) {
+        for (int e = tid; e < F * DPAD; e += kFecoThreads) {
+            const int i = e / DPAD, d = e - i * DPAD;
+            if (d < D) xq[sw_at<DPAD>(i, d)] = xq[sw_at<DPAD>(i, d)] - mu[d];
+        }
+        __syncthreads();
+    }
+    // element d of centred frame i (pad dimensions are zero)
+    auto xc_at = [&](int i, int d) __attribute__((always_inline)) -> float {
+        if (x_in_lds) return xq[sw_at<DPAD>(i, d)];
+        return d < D ? x[(size_t)i * D + d] - mu[d] : 0.f;
+    };
+    FECO_DETAIL(1)
     if (seeded) {
         // random initialisation: rank the frames by (key, frame); `members` holds the keys, `cnt` the k chosen frames
         // (both are free until the first update)
         unsigned* keys = reinterpret_cast<unsigned*>(members);
         int* chosen = cnt;
         const int64_t utt = index_base + blockIdx.x;
-        for (int i = tid; i < F; i += 1024)
-            keys[i] = philox4x32_10_w0(seed, (uint32_t)i, 0u, (uint32_t)utt, (uint32_t)((uint64_t)utt >> 32));
+        for (int i = tid; i < al4(F); i += kFecoThreads)
+            keys[i] = i < F ? philox4x32_10_w0(seed, (uint32_t)i, 0u, (uint32_t)utt, (uint32_t)((uint64_t)utt >> 32)) : 0xFFFFFFFFu;
         __syncthreads();
-        for (int i = tid; i < F; i += 1024) {
+        // rank of frame i = number of (key, frame) pairs below its own; the scan of the keys is shared by `parts` threads
+        // per frame (partial ranks meet in `ids`, which is not in use yet)
+        const int parts = F >= kFecoThreads ? 1 : kFecoThreads / F;
+        const int nq = al4(F) / 4, per = (nq + parts - 1) / parts;
+        for (int i = tid; i < F; i += kFecoThreads) ids[i] = 0;
+        __syncthreads();
+        for (int t0 = tid; t0 < F * parts; t0 += kFecoThreads) {
+            const int i = t0 % F, pt = t0 / F;
             const unsigned ki = keys[i];
             int rank = 0;
-            for (int g = 0; g < F; ++g) {
-                const unsigned kg = keys[g];
-                rank += (kg < ki) || (kg == ki && g < i);
+            const int q0 = pt * per, q1 = min(nq, q0 + per);
+#pragma unroll 4
+            for (int q = q0; q < q1; ++q) {  // a pad key (all ones, index >= F) never counts as smaller
+                const uint4 kg = *reinterpret_cast<const uint4*>(keys + 4 * q);
+                const int g = 4 * q;
+                rank += (kg.x < ki) || (kg.x == ki && g < i);
+                rank += (kg.y < ki) || (kg.y == ki && g + 1 < i);
+                rank += (kg.z < ki) || (kg.z == ki && g + 2 < i);
+                rank += (kg.w < ki) || (kg.w == ki && g + 3 < i);
             }
+            if (parts > 1) atomicAdd(&ids[i], rank);
+            else ids[i] = rank;
+        }
+        __syncthreads();
+        for (int i = tid; i < F; i += kFecoThreads) {
+            const int rank = ids[i];
             if (rank < k) chosen[rank] = i;
+            ids[i] = -1;
         }
         __syncthreads();
     }
-    for (int e = tid; e < npair * 2 * DPAD; e += 1024) {
+    FECO_DETAIL(2)
+    // initial centroids (centred) and their h; kp * DPAD is a multiple of the block: whole waves all the way
+    for (int e = tid; e < kp * DPAD; e += kFecoThreads) {
         const int j = e / DPAD, d = e - j * DPAD;
         float v = 0.f;
         if (j < k && d < D) {
             const int f0 = seeded ? cnt[j] : (int)((long long)j * F / k);
-            v = x[(size_t)f0 * D + d];
+            v = xc_at(f0, d);
         }
-        cs[CS_AT(j, d)] = v;
+        cq[sw_at<DPAD>(j, d)] = v;
+        const float sq = row_tree_sum<DPAD>(v * v);
+        if (d == 0) hq[j] = j < k ? -0.5f * sq : -INFINITY;  // a pad row of the last tile never wins
     }
-    // thread = (frame slot li, centroid chunk jc), TWO frames per thread (li and li + slots): a centroid read (16-byte LDS
-    // broadcast) serves both frames -- half the 6.5 MB of LDS reads per assignment step.  Phase trace (SG_FECO_TRACE) at 64 x
-    // 300 x 32, k = 150: assignment 25.5 -> 23.5 us per step (lists 5.6, update 2.1) -- so the step is bound by its packed
-    // sub / mul / add (16 us at the full packed rate: it runs at ~70 % of it), not by the LDS; the third of them that an
-    // fma would save is the contract's separate roundings.  Same arithmetic per (frame, centroid); chunk minima are still
-    // merged in ascending centroid order.  F <= 2048: one pass, the frames stay in registers.
-    // (D > 32: one frame per thread -- two frames of 64 dimensions do not fit the 128 registers of a 1024-thread block)
-    constexpr bool TWO = DPAD == 32;
-    constexpr int PMAX = TWO ? 2048 : 1024;
-    const int P = F <= PMAX ? F : PMAX;         // frames per pass
-    const int slots = TWO ? (P + 1) / 2 : P;    // thread slots per chunk
-    const int JC = max(1, min(8, 1024 / slots));  // JC * P <= 2048: capacity of pd / pj
-    const int li = tid % slots, jc = tid / slots;
-    const bool worker = jc < JC;
-    const int plo = (int)((long long)npair * jc / JC), phi = worker ? (int)((long long)npair * (jc + 1) / JC) : 0;
-    float2v xr0[DPAD / 2], xr1[TWO ? DPAD / 2 : 1];  // the two frames, dimensions (2q, 2q + 1) per register pair
-    auto load_frames = [&](int f0) __attribute__((always_inline)) {
-        const int i0 = f0 + li, i1 = f0 + li + slots, fend = min(F, f0 + P);
+    __syncthreads();
+    const int ntf = (F + 31) >> 5, ntc = kp >> 5, nunits = ntf * JC;
+    // B operand of frame tile ft: dimensions 8 g + 4 lh .. + 3 of this lane's frame (a column past the utterance is
+    // computed and never used)
+    auto load_b = [&](int ft, float4 (&xb)[DPAD / 8]) __attribute__((always_inline)) {
+        const int frame = ft * 32 + ln;
+        if (x_in_lds) {
+            const int fr = min(frame, F - 1);
 #pragma unroll
-        for (int q = 0; q < DPAD / 2; ++q) {
-            xr0[q].x = (worker && i0 < fend && 2 * q < D) ? x[(size_t)i0 * D + 2 * q] : 0.f;
-            xr0[q].y = (worker && i0 < fend && 2 * q + 1 < D) ? x[(size_t)i0 * D + 2 * q + 1] : 0.f;
-            if constexpr (TWO) {
-                xr1[q].x = (worker && i1 < fend && 2 * q < D) ? x[(size_t)i1 * D + 2 * q] : 0.f;
-                xr1[q].y = (worker && i1 < fend && 2 * q + 1 < D) ? x[(size_t)i1 * D + 2 * q + 1] : 0.f;
+            for (int g = 0; g < DPAD / 8; ++g) xb[g] = *reinterpret_cast<const float4*>(xq + sw_slot<DPAD>(fr, 2 * g + lh));
+        } else {
+#pragma unroll
+            for (int g = 0; g < DPAD / 8; ++g) {
+                const int d0 = 8 * g + 4 * lh;
+                const bool in = frame < F;
+                xb[g].x = in && d0 < D ? x[(size_t)frame * D + d0] - mu[d0] : 0.f;
+                xb[g].y = in && d0 + 1 < D ? x[(size_t)frame * D + d0 + 1] - mu[d0 + 1] : 0.f;
+                xb[g].z = in && d0 + 2 < D ? x[(size_t)frame * D + d0 + 2] - mu[d0 + 2] : 0.f;
+                xb[g].w = in && d0 + 3 < D ? x[(size_t)frame * D + d0 + 3] - mu[d0 + 3] : 0.f;
             }
         }
     };
-    load_frames(0);
-    __syncthreads();
+    // scores of frame tile ft against centroid tiles [ct_lo, ct_hi): the lane's best (value, lowest index) -> chunk maxima /
+    // ids (jc: the chunk's position inside the frame tile = its row of the merge arrays)
+    auto run_unit = [&](int ft, int ct_lo, int ct_hi, int jc, const float4 (&xb)[DPAD / 8]) __attribute__((always_inline)) {
+        const int frame = ft * 32 + ln;
+        float best = -INFINITY;
+        int bj = ct_lo * 32 + 4 * lh;
+        for (int ct = ct_lo; ct < ct_hi; ++ct) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // accumulator row (r & 3) + 8 (r >> 2) + 4 lh = centroid of the tile
+                const float4 hv = *reinterpret_cast<const float4*>(hq + ct * 32 + 8 * q + 4 * lh);
+                acc[4 * q] = hv.x;
+                acc[4 * q + 1] = hv.y;
+                acc[4 * q + 2] = hv.z;
+                acc[4 * q + 3] = hv.w;
+            }
+            const int row = ct * 32 + ln;
+#ifdef SG_EXP_FECO_JC
+            if (!(g_feco_ablate & 1))
+#endif
+#pragma unroll
+            for (int g = 0; g < DPAD / 8; ++g) {
+                const float4 a = *reinterpret_cast<const float4*>(cq + sw_slot<DPAD>(row, 2 * g + lh));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[g].x, acc, 0, 0, 0);  // k = 8 g + 0, 8 g + 4
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[g].y, acc, 0, 0, 0);  //     8 g + 1, 8 g + 5
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xb[g].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xb[g].w, acc, 0, 0, 0);
+            }
+            // the tile's largest score of this lane, then the lowest row that reaches it; tiles ascending, strict >
+            float tb = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tb = fmaxf(tb, acc[r]);
+            int tj = 0x7fffffff;
+            const int mb = ct * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tj = min(tj, acc[r] == tb ? mb + (r & 3) + 8 * (r >> 2) : 0x7fffffff);
+            if (tb > best) {
+                best = tb;
+                bj = tj;
+            }
+        }
+        {  // the other half of the tile's rows sits in lane ^ 32
+            const float ov = __shfl_xor(best, 32);
+            const int oj = __shfl_xor(bj, 32);
+            if (ov > best || (ov == best && oj < bj)) {
+                best = ov;
+                bj = oj;
+            }
+        }
+        if (lh == 0 && frame < F) {
+            if (JC > 1) {
+                pd[jc * F + frame] = best;
+                pj[jc * F + frame] = bj;
+            } else if (ids[frame] != bj) {
+                ids[frame] = bj;
+                changed = 1;
+            }
+        }
+    };
+    // (D > 32: two resident operands of 32 registers do not fit the 128 of a 1024-thread block -- round robin there)
+    const bool table = DPAD == 32 && sched.table;
+    float4 xb0[DPAD / 8], xb1[DPAD == 32 ? DPAD / 8 : 1];
+    const unsigned u0 = table ? sched.u[tid >> 6][0] : kFecoNoUnit, u1 = table ? sched.u[tid >> 6][1] : kFecoNoUnit;
+    if (u0 != kFecoNoUnit) load_b(u0 & 255, xb0);
+    if constexpr (DPAD == 32)
+        if (u1 != kFecoNoUnit) load_b(u1 & 255, xb1);
     for (int it = 0; it < max_iter; ++it) {
-        FECO_STAMP(4 * it)
+        if (it < kFecoTraceIters) { FECO_STAMP(4 * it) }
         if (tid == 0) changed = 0;
         __syncthreads();
-        for (int f0 = 0; f0 < F; f0 += P) {
-            const int np = min(P, F - f0);  // frames of this pass
-            if (F > P) load_frames(f0);     // long utterances (several passes)
-            float best0 = INFINITY, best1 = INFINITY;
-            int bj0 = 2 * plo, bj1 = 2 * plo;
-            if (worker && li < np) {
-                for (int pr = plo; pr < phi; ++pr) {
-                    const float4* c4 = reinterpret_cast<const float4*>(cs + (size_t)pr * 2 * DPAD);
-                    float2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};  // (distance to centroid 2 pr, to centroid 2 pr + 1) per frame
-#pragma unroll
-                    for (int q = 0; q < DPAD / 2; ++q) {  // d ascending; pad dims add +0 (x = c = 0), acc unchanged
-                        const float4 c = c4[q];            // c[2q] of both centroids, c[2q + 1] of both
-                        const float2v c0 = {c.x, c.y}, c1 = {c.z, c.w};
-                        float2v df = pk_sub_xlo(xr0[q], c0);
-                        acc0 = acc0 + df * df;
-                        df = pk_sub_xhi(xr0[q], c1);
-                        acc0 = acc0 + df * df;
-                        if constexpr (TWO) {
-                            df = pk_sub_xlo(xr1[q], c0);
-                            acc1 = acc1 + df * df;
-                            df = pk_sub_xhi(xr1[q], c1);
-                            acc1 = acc1 + df * df;
-                        }
-                    }
-                    const bool odd_ok = 2 * pr + 1 < k;
-                    if (acc0.x < best0) { best0 = acc0.x; bj0 = 2 * pr; }
-                    if (odd_ok && acc0.y < best0) { best0 = acc0.y; bj0 = 2 * pr + 1; }
-                    if constexpr (TWO) {
-                        if (acc1.x < best1) { best1 = acc1.x; bj1 = 2 * pr; }
-                        if (odd_ok && acc1.y < best1) { best1 = acc1.y; bj1 = 2 * pr + 1; }
-                    }
-                }
+        // ---- assignment on the matrix pipes.  A unit of work is (frame tile, chunk of its centroid tiles).  f32 MFMAs share
+        // the SIMD's issue with the VALU instructions of the waves on it (round 3), so what has to balance is the SIMDs: the
+        // host deals the units to the waves (waves w, w + 4, w + 8, w + 12 share a SIMD) and a wave keeps the B operands of
+        // its (at most two) units in registers for the whole call; utterances with more than 32 units go round the waves.
+        if (table) {
+            if (u0 != kFecoNoUnit) run_unit(u0 & 255, (u0 >> 8) & 255, (u0 >> 16) & 255, u0 >> 24, xb0);
+            if constexpr (DPAD == 32)
+                if (u1 != kFecoNoUnit) run_unit(u1 & 255, (u1 >> 8) & 255, (u1 >> 16) & 255, u1 >> 24, xb1);
+        } else {
+            for (int u = tid >> 6; u < nunits; u += kFecoThreads / 64) {
+                const int ft = u / JC, jc = u - ft * JC;
+                load_b(ft, xb0);
+                run_unit(ft, ntc * jc / JC, ntc * (jc + 1) / JC, jc, xb0);
             }
-            if (worker && li < np) {
-                pd[jc * np + li] = best0;
-                pj[jc * np + li] = bj0;
-                if (TWO && li + slots < np) {
-                    pd[jc * np + li + slots] = best1;
-                    pj[jc * np + li + slots] = bj1;
-                }
-            }
-            __syncthreads();
-            for (int r = tid; r < np; r += 1024) {  // merge the chunks in ascending centroid order: the lowest index wins ties
+        }
+        __syncthreads();
+        if (it == 0) { FECO_DETAIL(3) }
+        if (JC > 1) {
+            for (int r = tid; r < F; r += kFecoThreads) {  // merge the chunks in ascending centroid order: the lowest index wins ties
                 float b = pd[r];
                 int bb = pj[r];
                 for (int c = 1; c < JC; ++c) {
-                    const float v = pd[c * np + r];
-                    if (v < b) {
+                    const float v = pd[c * F + r];
+                    if (v > b) {
                         b = v;
-                        bb = pj[c * np + r];
+                        bb = pj[c * F + r];
                     }
                 }
-                if (ids[f0 + r] != bb) {
-                    ids[f0 + r] = bb;
+                if (ids[r] != bb) {
+                    ids[r] = bb;
                     changed = 1;
                 }
             }
             __syncthreads();
         }
-        FECO_STAMP(4 * it + 1)
+        if (it < kFecoTraceIters) { FECO_STAMP(4 * it + 1) }
         if (!changed) break;
-        // member lists.  Counts: one LDS atomic per frame.
-        for (int j = tid; j < k; j += 1024) cnt[j] = 0;
-        __syncthreads();
-        for (int i = tid; i < F; i += 1024) atomicAdd(&cnt[ids[i]], 1);
-        __syncthreads();
-        // offsets: cluster j adds up the counts below it (16-byte broadcast reads)
-        for (int j = tid; j <= k; j += 1024) {
-            int run = 0;
-            const int j4 = j & ~3;
-            for (int q = 0; q < j4; q += 4) {
-                const int4 c = *reinterpret_cast<const int4*>(cnt + q);
-                run += c.x + c.y + c.z + c.w;
+        // ---- member lists: frames grouped by cluster, ascending inside a cluster
+        if (fast_lists) {
+            // F <= 1024: one frame per thread, a wave holds the 64 frames of chunk tid >> 6.  Position of frame i in the
+            // lists = frames of lower clusters + frames of its cluster in earlier chunks + earlier frames of its cluster
+            // inside the wave (64 v_readlane compares).  Three block barriers.
+            const int myid = tid < F ? ids[tid] : -1;
+            int rank = 0;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) rank += (__builtin_amdgcn_readlane(myid, l) == myid) & (l < lane);
+            if (tid < F) atomicAdd(&cw[(tid >> 6) * k + myid], 1);  // cw is all zero here (start of the kernel / the last update)
+            __syncthreads();
+            if (it == 0) { FECO_DETAIL(4) }
+            const int nch = (F + 63) >> 6;
+            {   // cluster tid: its size, and (inclusive scan inside the wave) the frames of the wave's lower clusters
+                int c = 0;
+                if (tid < k)
+                    for (int ch = 0; ch < nch; ++ch) c += cw[ch * k + tid];
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                if (tid < k) {
+                    cnt[tid] = c;
+                    spart[tid] = incl - c;
+                }
+                if (lane == 63) wtot[tid >> 6] = incl;
             }
-            for (int q = j4; q < j; ++q) run += cnt[q];
-            start[j] = run;
-        }
-        __syncthreads();
-        // slots: frame i goes behind the earlier frames of its cluster -> ascending frame order inside a cluster
-        for (int i = tid; i < F; i += 1024) {
-            const int j = ids[i];
-            int pos = 0;
-            const int i4 = i & ~3;
-            for (int q = 0; q < i4; q += 4) {
-                const int4 v = *reinterpret_cast<const int4*>(ids + q);
-                pos += (v.x == j) + (v.y == j) + (v.z == j) + (v.w == j);
+            __syncthreads();
+            if (it == 0) { FECO_DETAIL(5) }
+            if (tid < F) {
+                int pos = spart[myid] + rank;
+                for (int w = 0; w < (myid >> 6); ++w) pos += wtot[w];
+                for (int ch = 0; ch < (tid >> 6); ++ch) pos += cw[ch * k + myid];
+                members[pos] = tid;
             }
-            for (int q = i4; q < i; ++q) pos += ids[q] == j;
-            members[start[j] + pos] = i;
+            if (tid < k) {
+                int st = spart[tid];
+                for (int w = 0; w < (tid >> 6); ++w) st += wtot[w];
+                start[tid] = st;
+            }
+            __syncthreads();
+            if (it == 0) { FECO_DETAIL(6) }
+            // zero the chunk counts for the next iteration (their next use is behind the update's barrier)
+            for (int e = tid; e < nch * k; e += kFecoThreads) cw[e] = 0;
+        } else {
+            for (int j = tid; j < k; j += kFecoThreads) cnt[j] = 0;
+            __syncthreads();
+            for (int i = tid; i < F; i += kFecoThreads) atomicAdd(&cnt[ids[i]], 1);
+            __syncthreads();
+            // offsets: cluster j adds up the counts below it (16-byte broadcast reads)
+            for (int j = tid; j <= k; j += kFecoThreads) {
+                int run = 0;
+                const int j4 = j & ~3;
+                for (int q = 0; q < j4; q += 4) {
+                    const int4 c = *reinterpret_cast<const int4*>(cnt + q);
+                    run += c.x + c.y + c.z + c.w;
+                }
+                for (int q = j4; q < j; ++q) run += cnt[q];
+                start[j] = run;
+            }
+            __syncthreads();
+            // slots: frame i goes behind the earlier frames of its cluster
+            for (int i = tid; i < F; i += kFecoThreads) {
+                const int j = ids[i];
+                int pos = 0;
+                const int i4 = i & ~3;
+                for (int q = 0; q < i4; q += 4) {
+                    const int4 v = *reinterpret_cast<const int4*>(ids + q);
+                    pos += (v.x == j) + (v.y == j) + (v.z == j) + (v.w == j);
+                }
+                for (int q = i4; q < i; ++q) pos += ids[q] == j;
+                members[start[j] + pos] = i;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        FECO_STAMP(4 * it + 2)
-        // update: thread (j, d) sums its cluster's frames in ascending frame order; an empty cluster keeps its centroid
-        for (int e = tid; e < k * DPAD; e += 1024) {
+        if (it < kFecoTraceIters) { FECO_STAMP(4 * it + 2) }
+        // ---- update: thread (j, d) sums its cluster's centred frames in ascending frame order; an empty cluster keeps
+        // its centroid; the row's lanes then rebuild h_j
+        for (int e = tid; e < kp * DPAD; e += kFecoThreads) {
             const int j = e / DPAD, d = e - j * DPAD;
-            const int n = cnt[j];
-            if (d < D && n > 0) {
+            const int n = j < k ? cnt[j] : 0;
+            float v;
+            if (n > 0) {
+                // four members per round: their list entries, then their frame elements, are loads in flight together; the
+                // additions keep the ascending order (entries past the cluster are read -- inside the lists -- and not added)
                 float sum = 0.f;
                 const int o = start[j];
-#pragma unroll 4
-                for (int m = 0; m < n; ++m) sum = sum + xu[(size_t)members[o + m] * D + d];
-                cs[CS_AT(j, d)] = sum / (float)n;
+                for (int m = 0; m < n; m += 4) {
+                    const int i0 = members[o + m], i1 = members[min(o + m + 1, F - 1)], i2 = members[min(o + m + 2, F - 1)],
+                              i3 = members[min(o + m + 3, F - 1)];
+                    const float v0 = xc_at(i0, d), v1 = xc_at(i1, d), v2 = xc_at(i2, d), v3 = xc_at(i3, d);
+                    sum = sum + v0;
+                    if (m + 1 < n) sum = sum + v1;
+                    if (m + 2 < n) sum = sum + v2;
+                    if (m + 3 < n) sum = sum + v3;
+                }
+                v = sum / (float)n;
+            } else {
+                v = cq[sw_at<DPAD>(j, d)];
+            }
+            const float sq = row_tree_sum<DPAD>(v * v);
+            if (n > 0) {
+                cq[sw_at<DPAD>(j, d)] = v;
+                if (d == 0) hq[j] = -0.5f * sq;
             }
         }
         __syncthreads();
-        FECO_STAMP(4 * it + 3)
+        if (it < kFecoTraceIters) { FECO_STAMP(4 * it + 3) }
     }
-    FECO_STAMP(4 * 16)
-    // cnt / cs describe the final ids in both exits: "nothing changed" leaves the previous iteration's lists and means
-    // valid, the max_iter exit has just rebuilt them
+    FECO_STAMP(4 * kFecoTraceIters)
+    FECO_CYCLES(21)
+    // cnt / start / members describe the final ids in both exits: "nothing changed" leaves the previous iteration's lists
+    // valid, the max_iter exit has just rebuilt them.  (max_iter >= 1 and ids start at -1: the lists exist.)
     if (out) {
         float* o = out + slot * k * D;
-        for (int e = tid; e < k * D; e += 1024) {
+        for (int e = tid; e < k * D; e += kFecoThreads) {
             const int j = e / D, d = e - j * D;
-            o[e] = cnt[j] > 0 ? cs[CS_AT(j, d)] : x[(size_t)j * D + d];  // feature_level.py:213-214 `force` fallback
+            const int n = cnt[j];
+            float v;
+            if (n > 0) {
+                float sum = 0.f;
+                const int s0 = start[j];
+                for (int m = 0; m < n; m += 4) {  // four loads in flight, additions in ascending order (as in the update)
+                    const int i0 = members[s0 + m], i1 = members[min(s0 + m + 1, F - 1)], i2 = members[min(s0 + m + 2, F - 1)],
+                              i3 = members[min(s0 + m + 3, F - 1)];
+                    const float v0 = x[(size_t)i0 * D + d], v1 = x[(size_t)i1 * D + d], v2 = x[(size_t)i2 * D + d],
+                                v3 = x[(size_t)i3 * D + d];
+                    sum = sum + v0;
+                    if (m + 1 < n) sum = sum + v1;
+                    if (m + 2 < n) sum = sum + v2;
+                    if (m + 3 < n) sum = sum + v3;
+                }
+                v = sum / (float)n;
+            } else {
+                v = x[(size_t)j * D + d];  // feature_level.py:213-214 `force` fallback
+            }
+            o[e] = v;
         }
-        for (int j = tid; j < k; j += 1024) counts[slot * k + j] = cnt[j];
+        for (int j = tid; j < k; j += kFecoThreads) counts[slot * k + j] = cnt[j];
     }
-    for (int i = tid; i < F; i += 1024) assign[slot * F + i] = ids[i];
-    FECO_STAMP(4 * 16 + 1)
+    for (int i = tid; i < F; i += kFecoThreads) assign[slot * F + i] = ids[i];
+    FECO_STAMP(4 * kFecoTraceIters + 1)
 }
 
 // out[b][j][d] = mean over frames with id j (ascending order) or, for an empty cluster, feats[b][j][d]
@@ -372,28 +621,66 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
         reps > 65535)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: need 0 < k <= F, 0 < D <= %d, max_iter > 0", kFecoMaxD);
     if (hipSetDevice(ctx->device) != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: hipSetDevice failed");
-    // LDS holds the centroids (rows padded to 32 / 64 floats), ids, member lists and the chunk minima; the frames stay
-    // in registers / HBM.  150 KB of it covers ~23 s at D <= 32, ratio 0.5 (k = 1150); beyond that the call is refused.
+    // LDS holds the centred centroids (rows padded to 32 / 64 floats), ids, member lists and -- when they fit -- the chunk
+    // counts of the fast member lists and the centred frames (else the frames are re-read from HBM / L2 in every step).
+    // 150 KB cover ~19 s at D <= 32, ratio 0.5 (F = 1930, k = 965); beyond that the call is refused.
     constexpr size_t kLdsMax = 150 * 1024;
     const int dpad = D <= 32 ? 32 : 64;
-    size_t lds = (size_t)((k + 1) / 2) * 2 * dpad * sizeof(float) +
-                 ((size_t)2 * al4(F) + al4(k) + al4(k + 1)) * sizeof(int) + 2 * 2048 * sizeof(float);
-    const size_t xbytes = (size_t)F * D * sizeof(float);
-    const int x_in_lds = lds + xbytes <= kLdsMax;  // the frames too, so the update never leaves the CU
-    if (x_in_lds) lds += xbytes;
-    if (lds > kLdsMax)
+    const int ntc = (k + 31) / 32;
+    // a frame tile's centroid tiles are cut into JC chunks (300 x 150: 10 frame tiles x 2 chunks of 3 / 2 tiles)
+    const int ntf = (F + 31) / 32;
+    int JC = (20 + ntf - 1) / ntf;  // >= 20 units for the 16 waves (5 per SIMD), each as many tiles as possible
+    JC = JC > ntc ? ntc : JC;
+    JC = JC > kFecoMaxChunks ? kFecoMaxChunks : JC;
+    while (JC > 1 && JC * F > kFecoMergeCap) --JC;
+#ifdef SG_EXP_FECO_JC
+    if (const char* ev = getenv("SG_FECO_ABLATE")) { const int a = atoi(ev); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_ablate), &a, sizeof(a)); }
+    if (const char* ev = getenv("SG_FECO_JC")) { JC = atoi(ev); JC = JC < 1 ? 1 : (JC > ntc ? ntc : JC); while (JC > 1 && JC * F > kFecoMergeCap) --JC; }
+#endif
+    auto bytes = [&](int jc, int fast, int xin) { return (size_t)feco_layout(F, k, dpad, jc, fast, xin).total * sizeof(float); };
+    if (bytes(JC, 0, 0) > kLdsMax) JC = 1;
+    if (bytes(JC, 0, 0) > kLdsMax)
         return feco_fail(ctx, SG_ERR_ARG, "sg_feco_kmeans: %d clusters x %d dims + %d frames need %zu bytes of LDS (limit %zu): "
-                         "utterance too long for one block", k, D, F, lds, kLdsMax);
+                         "utterance too long for one block", k, D, F, bytes(JC, 0, 0), kLdsMax);
+    // the assignment's units (frame tile, chunk jc of its centroid tiles [ntc jc / JC, ntc (jc + 1) / JC)) dealt to the waves:
+    // largest first, each to the least loaded SIMD (waves w, w + 4, w + 8, w + 12) and there to the least loaded wave with a
+    // free slot -- 300 x 150: 20 units of 2 / 3 tiles -> 12 / 13 / 12 / 13 tiles per SIMD
+    FecoSched sched{};
+    const int nunits = ntf * JC;
+    constexpr int kWaves = kFecoThreads / 64;
+    if (nunits <= 2 * kWaves) {
+        sched.table = 1;
+        int simd_load[4] = {0, 0, 0, 0}, wave_load[kWaves] = {}, wave_n[kWaves] = {};
+        for (int w = 0; w < kWaves; ++w) sched.u[w][0] = sched.u[w][1] = kFecoNoUnit;
+        for (int size = ntc; size >= 1; --size)
+            for (int u = 0; u < nunits; ++u) {
+                const int ft = u / JC, jc = u - ft * JC, lo = ntc * jc / JC, hi = ntc * (jc + 1) / JC;
+                if (hi - lo != size) continue;
+                int best_w = -1;
+                for (int w = 0; w < kWaves; ++w) {
+                    if (wave_n[w] >= 2) continue;
+                    if (best_w < 0 || simd_load[w & 3] < simd_load[best_w & 3] ||
+                        (simd_load[w & 3] == simd_load[best_w & 3] && wave_load[w] < wave_load[best_w]))
+                        best_w = w;
+                }
+                sched.u[best_w][wave_n[best_w]++] = (unsigned)ft | (unsigned)lo << 8 | (unsigned)hi << 16 | (unsigned)jc << 24;
+                wave_load[best_w] += size;
+                simd_load[best_w & 3] += size;
+            }
+    }
+    const int x_in_lds = bytes(JC, 0, 1) <= kLdsMax;
+    const int fast_lists = F <= kFecoThreads && bytes(JC, 1, x_in_lds) <= kLdsMax;
+    const size_t lds = bytes(JC, fast_lists, x_in_lds);
     const void* fn = dpad == 32 ? reinterpret_cast<const void*>(feco_kmeans_kernel<32>)
                                 : reinterpret_cast<const void*>(feco_kmeans_kernel<64>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     if (dpad == 32)
-        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B, reps), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
-                           seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
+        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B, reps), dim3(kFecoThreads), lds, (hipStream_t)stream, feats_dev, F, D, k,
+                           max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, assign_dev, out_dev, counts_dev);
     else
-        hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B, reps), dim3(1024), lds, (hipStream_t)stream, feats_dev, F, D, k, max_iter,
-                           seeded, seed, index_base, x_in_lds, assign_dev, out_dev, counts_dev);
+        hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B, reps), dim3(kFecoThreads), lds, (hipStream_t)stream, feats_dev, F, D, k,
+                           max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, assign_dev, out_dev, counts_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     static const bool tr_on = getenv("SG_FECO_TRACE") != nullptr;
@@ -404,14 +691,20 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_trace_on), &one, sizeof(one));
             armed = true;
         } else if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
-            unsigned long long h[4 * 16 + 4];
+            unsigned long long h[4 * kFecoTraceIters + 4 + 24];
             if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_feco_trace), sizeof(h)) == hipSuccess) {
-                fprintf(stderr, "feco k-means phases (us), block (0, 0): set-up %.2f;", 0.0);
-                for (int it = 0; it < max_iter && it < 16 && h[4 * it + 1] > h[4 * it]; ++it)
+                fprintf(stderr, "feco k-means phases (us), block (0, 0): set-up %.2f;", (h[0] - h[4 * kFecoTraceIters + 2]) * 0.01);
+                for (int it = 0; it < max_iter && it < kFecoTraceIters && h[4 * it + 1] > h[4 * it]; ++it)
                     fprintf(stderr, " it%d assign %.2f lists %.2f update %.2f;", it, (h[4 * it + 1] - h[4 * it]) * 0.01,
                             h[4 * it + 2] > h[4 * it + 1] ? (h[4 * it + 2] - h[4 * it + 1]) * 0.01 : 0.0,
                             h[4 * it + 3] > h[4 * it + 2] ? (h[4 * it + 3] - h[4 * it + 2]) * 0.01 : 0.0);
-                fprintf(stderr, " out %.2f; loop + out total %.2f\n", (h[65] - h[64]) * 0.01, (h[65] - h[0]) * 0.01);
+                const unsigned long long* dt = h + 4 * kFecoTraceIters + 4;
+                fprintf(stderr, " [set-up: centring %.2f staging %.2f seeding %.2f init %.2f; it0: units %.2f merge %.2f | rank+count %.2f sizes+scan %.2f "
+                        "slots %.2f zero %.2f; shader clock %.0f MHz]", (dt[0] - h[4 * kFecoTraceIters + 2]) * 0.01, (dt[1] - dt[0]) * 0.01,
+                        (dt[2] - dt[1]) * 0.01, (h[0] - dt[2]) * 0.01, (dt[3] - h[0]) * 0.01, (h[1] - dt[3]) * 0.01, (dt[4] - h[1]) * 0.01,
+                        (dt[5] - dt[4]) * 0.01, (dt[6] - dt[5]) * 0.01, (h[2] - dt[6]) * 0.01,
+                        (double)(dt[21] - dt[20]) / ((h[4 * kFecoTraceIters] - dt[0]) * 0.01));
+                fprintf(stderr, " out %.2f; loop + out total %.2f\n", (h[4 * kFecoTraceIters + 1] - h[4 * kFecoTraceIters]) * 0.01, (h[4 * kFecoTraceIters + 1] - h[0]) * 0.01);
             }
         }
     }
