@@ -280,6 +280,15 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
  * or shape differ, the forward is recomputed. */
 int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* dfeats_dev, float* grad_dev,
                           int32_t reuse_forward, void* stream);
+/* How the log-mel front-end and its adjoint run on this context (round 5; defaults 32, 0, 1):
+ *   fft_bits 32 | 64: the scalar type of the STFT's transforms.  The reference computes its STFT in float32
+ *     (model/_audionet/Preprocessor.py:100-105, torch.stft on a float32 signal); 64 is the form of rounds 1-4.
+ *   spectrum_cache: the forward of a pass keeps every frame's packed spectrum (B x F x 4 KB) for the backward of the same
+ *     pass instead of the backward transforming the frame again.
+ *   fused_overlap_add: the adjoint adds the frames' gradients up on chip (and applies the attack's update there) instead
+ *     of writing B x F x 800 floats for a second kernel; same sums in the same order, same bits.
+ * Takes effect from the next pass; results of the two transform precisions differ by float32 round-off. */
+int sg_an_configure(sg_ctx* ctx, int32_t fft_bits, int32_t spectrum_cache, int32_t fused_overlap_add);
 /* audionet_csine.make_decision / score / embedding (:149-257): decisions (B), scores (B,num_class), emb (B,32) */
 int sg_an_forward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T_or_F, int32_t flag,
                   int64_t* decisions_dev, float* scores_dev, float* emb_dev, void* stream);

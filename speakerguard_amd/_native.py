@@ -23,7 +23,7 @@ EXPORTS = (
     "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
     "sg_an_pgd_run", "sg_an_pgd_run_feco", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
     "sg_xv_mfcc_backward", "sg_xv_cmvn_backward", "sg_feco_kmeans", "sg_feco_kmeans_seeded", "sg_feco_kmeans_compress", "sg_feco_compress_backward_reps", "sg_feco_compress", "sg_feco_compress_backward",
-    "sg_an_logmel_backward", "sg_xv_enroll_override", "sg_health", "sg_trace_begin", "sg_trace_end",
+    "sg_an_logmel_backward", "sg_an_configure", "sg_xv_enroll_override", "sg_health", "sg_trace_begin", "sg_trace_end",
 )
 
 # stage tags of sg_trace_end (include/speakerguard_hip.h); +l / -l = forward / data-gradient contraction of TDNN layer l
@@ -142,6 +142,7 @@ def load():
         "sg_xv_mfcc_backward": (C.c_int, [vp, vp, i32, i32, vp, C.POINTER(Dither), vp, vp, vp]),
         "sg_xv_cmvn_backward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "sg_an_logmel_backward": (C.c_int, [vp, vp, i32, i32, vp, vp, i32, vp]),
+        "sg_an_configure": (C.c_int, [vp, i32, i32, i32]),
         "sg_feco_kmeans": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         "sg_feco_kmeans_seeded": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, C.c_uint64, C.c_int64, vp, vp]),
         "sg_feco_kmeans_compress": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, C.c_uint64, C.c_int64, i32, vp, vp, vp, vp]),

@@ -10,6 +10,7 @@
 #include "loss_device.h"
 #include "sg_internal.h"
 #include "fft512.h"
+#include "fft512t.h"
 
 namespace sg {
 
@@ -24,38 +25,39 @@ __device__ __forceinline__ float an_wave_sum(float v) {
     return v;
 }
 
-// Log-mel front-end, one wave per frame, persistent over frames (same recipe as the MFCC kernels, k_mfcc.hip):
+// Log-mel front-end, one wave per frame (same recipe as the MFCC kernels, k_mfcc.hip):
 //   * the 1024 real samples x[q] of a frame are packed as z[n] = x[2n] + i x[2n+1] and transformed by ONE 512-point
-//     complex FFT (fft512.h: in-register radix-8, padded conflict-free LDS buffer, fp64); the spectrum follows from
+//     complex FFT (fft512t.h: in-register radix-8, padded conflict-free LDS buffer); the spectrum follows from
 //         X[k] = A_k Z[k] + B_k conj(Z[512-k]),   A_k = (1 - i W^k)/2,  B_k = (1 + i W^k)/2,  W = exp(-2 pi i/1024),
-//     for k = 0..512 -- half the butterflies and half the LDS of a 1024-point transform (the first version: radix-2,
-//     320 LDS accesses per lane per transform with twiddles and bit-reversal tables read from global memory);
+//     for k = 0..512 -- half the butterflies and half the LDS of a 1024-point transform;
 //   * the backward is the adjoint of exactly that: dZ[j] = conj(A_j) G[j] + B_{512-j} conj(G[512-j]) (+ the k = 512
 //     terms folded into j = 0), one inverse 512-point transform, d x[2n] = Re dz[n], d x[2n+1] = Im dz[n];
 //   * everything a lane needs for every frame is in registers for the whole kernel: its 16 window taps, the W^k of
 //     its 4 spectrum pairs, the weights of its half mel filter (ascending bins, zero-padded), its bins' filter
 //     membership; only the FFT twiddles live in LDS.
-struct AnFrameLds {
-    double2 spec[kAnHalf + kAnHalf / 8];  // element i at SP(i)
-    float power[kAnBins + 3];
+// Round 5: the scalar type R of the transforms is a template parameter.  float: what the reference computes in
+// (Preprocessor.py:100-105: torch.stft on a float32 signal) -- half the LDS bytes of the exchange passes these kernels are
+// bound by; double: the form of rounds 1-4 (sg_an_configure).  Twiddles are float64 values rounded once in both.
+template <typename R, bool POWER>
+struct AnFrameLdsT {
+    cx<R> spec[kAnHalf + kAnHalf / 8];  // element i at SP(i)
+    float power[POWER ? kAnBins + 3 : 4];
     float mel[32];
-    float dmel[34];
+    float dmel[36];
 };
 
-// pre-emphasised sample p of utterance row xr (length T), p in [0, T-2]: x[p+1] - 0.97 x[p]
-__device__ __forceinline__ float an_preemph(const float* __restrict__ xr, int p, float scale) {
-    return (xr[p + 1] - 0.97f * xr[p]) * scale;
-}
 __device__ __forceinline__ int an_reflect(int p, int L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
 
-struct AnLaneConst {
+template <typename R>
+struct AnLaneConstT {
     float win[16];            // window tap of FFT input q = 2 (lane + 64 i) + {0, 1} (0 outside the 800-tap window)
-    double2 wk[4];            // W^j for this lane's pairs j = lane + 64 i
+    cx<R> wk[4];              // W^j for this lane's pairs j = lane + 64 i
     int mel_k0;
     float mel_w[kAnMelLaneBins];
 };
 
-__device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLaneConst& lc) {
+template <typename R, bool MEL>
+__device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLaneConstT<R>& lc) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -65,7 +67,11 @@ __device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLane
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lc.wk[i] = t.twiddle[lane + 64 * i];
+    for (int i = 0; i < 4; ++i) {
+        const double2 w = t.twiddle[lane + 64 * i];
+        lc.wk[i] = cmk<R>((R)w.x, (R)w.y);
+    }
+    if (!MEL) return;
     const int m = lane >> 1, h = lane & 1;
     const int lo = t.mel_lo[m], hi = t.mel_hi[m];
     const int mid = lo + (hi - lo + 1) / 2;
@@ -75,14 +81,11 @@ __device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLane
     for (int j = 0; j < kAnMelLaneBins; ++j) lc.mel_w[j] = j < cnt ? t.mel_w[m * kAnBins + min(k0 + j, kAnBins - 1)] : 0.f;
 }
 
-// raw samples of frame f: x[p], x[p + 1] for the 16 FFT inputs of this lane (loaded one frame ahead)
+// raw samples of frame f: x[p], x[p + 1] for the 16 FFT inputs of this lane
 struct AnRaw {
     float a[16], b[16];
 };
-__device__ __forceinline__ void an_load_frame(const float* __restrict__ x, int T, int F, int gf, int total, int lane, AnRaw& r) {
-    const int g = gf < total ? gf : total - 1;
-    const int bb = g / F, f = g - bb * F;
-    const float* xr = x + (size_t)bb * T;
+__device__ __forceinline__ void an_load_frame(const float* __restrict__ xr, int T, int f, int lane, AnRaw& r) {
     const int Lp = T - 1;                         // length of the pre-emphasised signal
     const int base = f * kAnHop - kAnWin / 2;     // centre=True: frame f is centred on sample f*hop
 #pragma unroll
@@ -96,90 +99,101 @@ __device__ __forceinline__ void an_load_frame(const float* __restrict__ x, int T
     }
 }
 
-__device__ __forceinline__ double2 an_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ double2 an_conj(double2 a) { return make_double2(a.x, -a.y); }
-
 // X[k] and X[512 - k] from the pair (Z[k], Z[512 - k]); w = W^k.  A_k = (1 - i w)/2, B_k = (1 + i w)/2,
 // and W^(512-k) = -conj(W^k).
-__device__ __forceinline__ void an_split(double2 zk, double2 zr, double2 w, double2& xk, double2& xr) {
-    const double2 iw = make_double2(-w.y, w.x);                       // i w
-    const double2 ak = make_double2(0.5 * (1.0 - iw.x), -0.5 * iw.y);
-    const double2 bk = make_double2(0.5 * (1.0 + iw.x), 0.5 * iw.y);
-    const double2 t0 = an_cmul(ak, zk), t1 = an_cmul(bk, an_conj(zr));
-    xk = make_double2(t0.x + t1.x, t0.y + t1.y);
-    const double2 wr = make_double2(-w.x, w.y);                       // W^(512-k)
-    const double2 iwr = make_double2(-wr.y, wr.x);
-    const double2 ar = make_double2(0.5 * (1.0 - iwr.x), -0.5 * iwr.y);
-    const double2 br = make_double2(0.5 * (1.0 + iwr.x), 0.5 * iwr.y);
-    const double2 u0 = an_cmul(ar, zr), u1 = an_cmul(br, an_conj(zk));
-    xr = make_double2(u0.x + u1.x, u0.y + u1.y);
+template <typename R>
+__device__ __forceinline__ void an_split(cx<R> zk, cx<R> zr, cx<R> w, cx<R>& xk, cx<R>& xr) {
+    const R half = (R)0.5, one = (R)1;
+    const cx<R> iw = cmk<R>(-w.y, w.x);                       // i w
+    const cx<R> ak = cmk<R>(half * (one - iw.x), -half * iw.y);
+    const cx<R> bk = cmk<R>(half * (one + iw.x), half * iw.y);
+    const cx<R> t0 = cmulT<R>(ak, zk), t1 = cmulT<R>(bk, cconjT<R>(zr));
+    xk = cmk<R>(t0.x + t1.x, t0.y + t1.y);
+    const cx<R> wr = cmk<R>(-w.x, w.y);                       // W^(512-k)
+    const cx<R> iwr = cmk<R>(-wr.y, wr.x);
+    const cx<R> ar = cmk<R>(half * (one - iwr.x), -half * iwr.y);
+    const cx<R> br = cmk<R>(half * (one + iwr.x), half * iwr.y);
+    const cx<R> u0 = cmulT<R>(ar, zr), u1 = cmulT<R>(br, cconjT<R>(zk));
+    xr = cmk<R>(u0.x + u1.x, u0.y + u1.y);
 }
 
-// packed spectrum Z of the frame into L.spec (element i at SP(i)), power of bins 0..512 into L.power, mel into L.mel
-// WITH_MEL = false: only the packed spectrum (the cached backward takes the mel energies from the forward pass)
-template <bool WITH_MEL>
-__device__ __forceinline__ void an_frame_forward(const double2* tw1, const double2* tw2, AnFrameLds& L, const AnLaneConst& lc,
+// packed spectrum Z of the frame into L.spec (element i at SP(i)); WITH_MEL: power of bins 0..512 into L.power, mel into
+// L.mel (false: only the packed spectrum -- the cached backward takes the mel energies from the forward pass)
+template <typename R, bool WITH_MEL, bool POWER>
+__device__ __forceinline__ void an_frame_forward(const cx<R>* tw1, const cx<R>* tw2, AnFrameLdsT<R, POWER>& L, const AnLaneConstT<R>& lc,
                                                  const AnRaw& r, float scale, int lane) {
+    static_assert(POWER || !WITH_MEL, "the mel energies need the power buffer");
+    cx<R> in[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float v0 = (r.b[2 * i] - 0.97f * r.a[2 * i]) * scale * lc.win[2 * i];
         const float v1 = (r.b[2 * i + 1] - 0.97f * r.a[2 * i + 1]) * scale * lc.win[2 * i + 1];
-        L.spec[SP(lane + 64 * i)] = make_double2((double)v0, (double)v1);
+        in[i] = cmk<R>((R)v0, (R)v1);
     }
-    wave_sync();
-    fft512_r8_t(L.spec, tw1, tw2, lane, -1.0);
-    if (!WITH_MEL) return;
+    fft512T_regin<R>(L.spec, tw1, tw2, lane, (R)-1, in);
+    if constexpr (WITH_MEL) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = lane + 64 * i;  // pairs (k, 512 - k), k = 0..255
-        const double2 zk = L.spec[SP(k)], zr = L.spec[SP((kAnHalf - k) & (kAnHalf - 1))];
-        double2 xk, xr;
-        an_split(zk, zr, lc.wk[i], xk, xr);
-        L.power[k] = (float)(xk.x * xk.x + xk.y * xk.y);
-        L.power[kAnHalf - k] = (float)(xr.x * xr.x + xr.y * xr.y);  // k = 0: X[512] = Re Z[0] - Im Z[0] (split with w = 1)
-    }
-    if (lane == 0) {  // the self-paired bin 256: w = W^256 = -i
-        const double2 z = L.spec[SP(256)];
-        double2 xk, xr;
-        an_split(z, z, make_double2(0.0, -1.0), xk, xr);
-        L.power[256] = (float)(xk.x * xk.x + xk.y * xk.y);
-    }
-    wave_sync();
-    // 32 slaney-mel filters, two lanes per filter (each takes half of the filter's bin range, ascending)
-    {
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;  // pairs (k, 512 - k), k = 0..255
+            const cx<R> zk = L.spec[SP(k)], zr = L.spec[SP((kAnHalf - k) & (kAnHalf - 1))];
+            cx<R> xk, xr;
+            an_split<R>(zk, zr, lc.wk[i], xk, xr);
+            L.power[k] = (float)(xk.x * xk.x + xk.y * xk.y);
+            L.power[kAnHalf - k] = (float)(xr.x * xr.x + xr.y * xr.y);  // k = 0: X[512] = Re Z[0] - Im Z[0] (split with w = 1)
+        }
+        if (lane == 0) {  // the self-paired bin 256: w = W^256 = -i
+            const cx<R> z = L.spec[SP(256)];
+            cx<R> xk, xr;
+            an_split<R>(z, z, cmk<R>((R)0, (R)-1), xk, xr);
+            L.power[256] = (float)(xk.x * xk.x + xk.y * xk.y);
+        }
+        wave_sync();
+        // 32 slaney-mel filters, two lanes per filter (each takes half of the filter's bin range, ascending)
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < kAnMelLaneBins; ++j) acc += L.power[min(lc.mel_k0 + j, kAnBins - 1)] * lc.mel_w[j];
         acc += __shfl_xor(acc, 1, 64);
         if ((lane & 1) == 0) L.mel[lane >> 1] = acc;
+        wave_sync();
     }
-    wave_sync();
 }
 
 // the 512-point transform's twiddles as its lanes read them (fft512.h: conflict-free tables), from the half circle of
 // W512^i = W1024^(2 i) staged in tw512
-__device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512, double2* tw1, double2* tw2) {
+template <typename R>
+__device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512, cx<R>* tw1, cx<R>* tw2) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) tw512[i] = t.twiddle[2 * i];
     __syncthreads();
-    fft512_fill_tables(tw512, tw1, tw2);
+    fft512_fill_tablesT<R>(tw512, tw1, tw2);
     __syncthreads();
 }
 
+template <typename R>
 __global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p, float* __restrict__ feats) {
-    __shared__ AnFrameLds lds[kAnWavesPerBlock];
-    __shared__ double2 tw512[256], tw1[kFftTw1], tw2[kFftTw2];
-    an_stage_tw(t, tw512, tw1, tw2);
+    __shared__ AnFrameLdsT<R, true> lds[kAnWavesPerBlock];
+    __shared__ double2 tw512[256];
+    __shared__ cx<R> tw1[kFftTw1], tw2[kFftTw2];
+    an_stage_tw<R>(t, tw512, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
-    AnFrameLds& L = lds[wid];
-    AnLaneConst lc;
-    an_lane_init(t, lane, lc);
+    AnFrameLdsT<R, true>& L = lds[wid];
+    AnLaneConstT<R> lc;
+    an_lane_init<R, true>(t, lane, lc);
     const int total = B * F, stride = gridDim.x * kAnWavesPerBlock;
     AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
     for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
-        an_load_frame(x, T, F, gf, total, lane, cur);
-        an_frame_forward<true>(tw1, tw2, L, lc, cur, scale, lane);
+        const int bb = gf / F;
+        an_load_frame(x + (size_t)bb * T, T, gf - bb * F, lane, cur);
+        an_frame_forward<R, true, true>(tw1, tw2, L, lc, cur, scale, lane);
+        if (t.spec_cache) {  // packed spectrum for the backward of the same pass (float32 whatever R is)
+            float2* sc = t.spec_cache + (size_t)gf * kAnHalf;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const cx<R> z = L.spec[SP(lane + 64 * i)];
+                sc[lane + 64 * i] = make_float2((float)z.x, (float)z.y);
+            }
+        }
         if (lane < kAnMel) {
             feats[(size_t)gf * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
             if (t.mel_cache) t.mel_cache[(size_t)gf * kAnMel + lane] = L.mel[lane];
@@ -188,103 +202,171 @@ __global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const
     }
 }
 
-// dfeats (B,F,32) -> dframes (B,F,800): gradient wrt the pre-emphasised, reflect-padded frame samples
-// CACHED: the forward kernel of the same pass left the mel energies in t.mel_cache (the attack loop); otherwise they
-// are recomputed (standalone sg_an_logmel_backward).  Two instantiations: the cached one does not carry the 44
-// mel-weight registers.
-template <bool CACHED>
+// filter membership of every bin (which mel filter pair it feeds, with which weights): LDS, shared by the block
+struct AnBinLds {
+    int m0[kAnBins + 3];
+    float w0[kAnBins + 3], w1[kAnBins + 3];
+};
+__device__ __forceinline__ void an_stage_bins(const AnTables& t, AnBinLds& bl) {
+    for (int i = threadIdx.x; i < kAnBins; i += blockDim.x) {
+        bl.m0[i] = t.bin_m0[i];
+        bl.w0[i] = t.bin_w0[i];
+        bl.w1[i] = t.bin_w1[i];
+    }
+}
+
+// One frame of the adjoint: from d loss / d log-mel (32 values of frame gf) to the 512 complex dz[n] = (d x[2n], d x[2n+1])
+// of the frame's 1024 FFT inputs, left in L.spec (element n at SP(n)); the caller multiplies by the window.
+// CACHED: the forward kernel of the same pass left the mel energies in t.mel_cache; SPEC: and the packed spectrum in
+// t.spec_cache (else the frame is transformed again from the waveform row xr).
+template <typename R, bool CACHED, bool SPEC, bool POWER>
+__device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>* tw1, const cx<R>* tw2, const AnBinLds& bl,
+                                                  AnFrameLdsT<R, POWER>& L, const AnLaneConstT<R>& lc, const float* __restrict__ xr, int T,
+                                                  int f, size_t gf, float scale, const float* __restrict__ dfeats, int lane) {
+    if constexpr (SPEC) {
+        const float2* sc = t.spec_cache + gf * kAnHalf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 z = sc[lane + 64 * i];
+            L.spec[SP(lane + 64 * i)] = cmk<R>((R)z.x, (R)z.y);
+        }
+        wave_sync();
+    } else {
+        AnRaw cur;
+        an_load_frame(xr, T, f, lane, cur);
+        an_frame_forward<R, !CACHED, POWER>(tw1, tw2, L, lc, cur, scale, lane);
+    }
+    if (lane < 34) {
+        float dm = 0.f;
+        if (lane < kAnMel) {
+            const float mel = CACHED ? t.mel_cache[gf * kAnMel + lane] : L.mel[lane];
+            // d/d mel of 10 log10(max(mel, 1e-16))
+            dm = mel > 1e-16f ? dfeats[gf * kAnMel + lane] * (10.f / 2.302585092994046f) / mel : 0.f;
+        }
+        L.dmel[lane] = dm;
+    }
+    wave_sync();
+    // G[k] = 2 X[k] dP[k] for both bins of every pair, folded straight into dZ (in place: a lane owns its pair)
+    auto dpow = [&](int k) {
+        const int m0 = bl.m0[k];
+        return m0 >= 0 ? (R)2 * (R)(L.dmel[m0] * bl.w0[k] + L.dmel[m0 + 1] * bl.w1[k]) : (R)0;
+    };
+    const R half = (R)0.5, one = (R)1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        const int kr = (kAnHalf - k) & (kAnHalf - 1);
+        const cx<R> zk = L.spec[SP(k)], zr = L.spec[SP(kr)];
+        const cx<R> w = lc.wk[i];
+        cx<R> xk, xr2;
+        an_split<R>(zk, zr, w, xk, xr2);
+        const R dpk = dpow(k), dpr = dpow(kAnHalf - k);
+        const cx<R> gk = cmk<R>(xk.x * dpk, xk.y * dpk), gr = cmk<R>(xr2.x * dpr, xr2.y * dpr);
+        const cx<R> iw = cmk<R>(-w.y, w.x);
+        const cx<R> ak = cmk<R>(half * (one - iw.x), -half * iw.y), bk = cmk<R>(half * (one + iw.x), half * iw.y);
+        const cx<R> wr = cmk<R>(-w.x, w.y);
+        const cx<R> iwr = cmk<R>(-wr.y, wr.x);
+        const cx<R> ar = cmk<R>(half * (one - iwr.x), -half * iwr.y), br = cmk<R>(half * (one + iwr.x), half * iwr.y);
+        // dZ[k] = conj(A_k) G[k] + B_{512-k} conj(G[512-k]);  dZ[512-k] = conj(A_{512-k}) G[512-k] + B_k conj(G[k])
+        const cx<R> d0 = cmulT<R>(cconjT<R>(ak), gk), d1 = cmulT<R>(br, cconjT<R>(gr));
+        const cx<R> e0 = cmulT<R>(cconjT<R>(ar), gr), e1 = cmulT<R>(bk, cconjT<R>(gk));
+        if (k == 0) {
+            // bins 0 and 512 both fold onto dZ[0]
+            L.spec[SP(0)] = cmk<R>(d0.x + d1.x + e0.x + e1.x, d0.y + d1.y + e0.y + e1.y);
+        } else {
+            L.spec[SP(k)] = cmk<R>(d0.x + d1.x, d0.y + d1.y);
+            L.spec[SP(kr)] = cmk<R>(e0.x + e1.x, e0.y + e1.y);
+        }
+    }
+    wave_sync();
+    if (lane == 0) {  // self-paired bin 256
+        const cx<R> z = L.spec[SP(256)];
+        const cx<R> w = cmk<R>((R)0, (R)-1);
+        cx<R> xk, xr2;
+        an_split<R>(z, z, w, xk, xr2);
+        const R dp = dpow(256);
+        const cx<R> g = cmk<R>(xk.x * dp, xk.y * dp);
+        const cx<R> iw = cmk<R>(-w.y, w.x);
+        const cx<R> ak = cmk<R>(half * (one - iw.x), -half * iw.y), bk = cmk<R>(half * (one + iw.x), half * iw.y);
+        const cx<R> d0 = cmulT<R>(cconjT<R>(ak), g), d1 = cmulT<R>(bk, cconjT<R>(g));
+        L.spec[SP(256)] = cmk<R>(d0.x + d1.x, d0.y + d1.y);
+    }
+    wave_sync();
+    fft512T<R>(L.spec, tw1, tw2, lane, (R)1);
+}
+
+// dfeats (B,F,32) -> dframes (B,F,800): gradient wrt the pre-emphasised, reflect-padded frame samples (the overlap-add is
+// an_frames_to_wave_kernel's).  Instantiations by (R, CACHED, SPEC): the cached ones do not carry the 44 mel-weight
+// registers.
+template <typename R, bool CACHED, bool SPEC>
 __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p,
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
-    __shared__ AnFrameLds lds[kAnWavesPerBlock];
-    __shared__ double2 tw512[256], tw1[kFftTw1], tw2[kFftTw2];
-    an_stage_tw(t, tw512, tw1, tw2);
+    constexpr bool POWER = !CACHED && !SPEC;
+    __shared__ AnFrameLdsT<R, POWER> lds[kAnWavesPerBlock];
+    __shared__ double2 tw512[256];
+    __shared__ cx<R> tw1[kFftTw1], tw2[kFftTw2];
+    __shared__ AnBinLds bl;
+    an_stage_bins(t, bl);
+    an_stage_tw<R>(t, tw512, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
-    AnFrameLds& L = lds[wid];
-    AnLaneConst lc;
-    an_lane_init(t, lane, lc);
-    // filter membership of every bin (which mel filter pair it feeds, with which weights): LDS, shared by the block
-    __shared__ int bin_m0[kAnBins + 3];
-    __shared__ float bin_w0[kAnBins + 3], bin_w1[kAnBins + 3];
-    for (int i = threadIdx.x; i < kAnBins; i += blockDim.x) {
-        bin_m0[i] = t.bin_m0[i];
-        bin_w0[i] = t.bin_w0[i];
-        bin_w1[i] = t.bin_w1[i];
-    }
-    __syncthreads();
+    AnFrameLdsT<R, POWER>& L = lds[wid];
+    AnLaneConstT<R> lc;
+    an_lane_init<R, POWER>(t, lane, lc);
     const int total = B * F, stride = gridDim.x * kAnWavesPerBlock;
-    AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
     for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
-        an_load_frame(x, T, F, gf, total, lane, cur);
-        an_frame_forward<!CACHED>(tw1, tw2, L, lc, cur, scale, lane);
-        if (lane < 34) {
-            float dm = 0.f;
-            if (lane < kAnMel) {
-                const float mel = CACHED ? t.mel_cache[(size_t)gf * kAnMel + lane] : L.mel[lane];
-                // d/d mel of 10 log10(max(mel, 1e-16))
-                dm = mel > 1e-16f ? dfeats[(size_t)gf * kAnMel + lane] * (10.f / 2.302585092994046f) / mel : 0.f;
-            }
-            L.dmel[lane] = dm;
-        }
-        wave_sync();
-        // G[k] = 2 X[k] dP[k] for both bins of every pair, folded straight into dZ (in place: a lane owns its pair)
-        auto dpow = [&](int k) {
-            const int m0 = bin_m0[k];
-            return m0 >= 0 ? 2.0 * (double)(L.dmel[m0] * bin_w0[k] + L.dmel[m0 + 1] * bin_w1[k]) : 0.0;
-        };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = lane + 64 * i;
-            const int kr = (kAnHalf - k) & (kAnHalf - 1);
-            const double2 zk = L.spec[SP(k)], zr = L.spec[SP(kr)];
-            const double2 w = lc.wk[i];
-            double2 xk, xr;
-            an_split(zk, zr, w, xk, xr);
-            const double dpk = dpow(k), dpr = dpow(kAnHalf - k);
-            const double2 gk = make_double2(xk.x * dpk, xk.y * dpk), gr = make_double2(xr.x * dpr, xr.y * dpr);
-            const double2 iw = make_double2(-w.y, w.x);
-            const double2 ak = make_double2(0.5 * (1.0 - iw.x), -0.5 * iw.y), bk = make_double2(0.5 * (1.0 + iw.x), 0.5 * iw.y);
-            const double2 wr = make_double2(-w.x, w.y);
-            const double2 iwr = make_double2(-wr.y, wr.x);
-            const double2 ar = make_double2(0.5 * (1.0 - iwr.x), -0.5 * iwr.y), br = make_double2(0.5 * (1.0 + iwr.x), 0.5 * iwr.y);
-            // dZ[k] = conj(A_k) G[k] + B_{512-k} conj(G[512-k]);  dZ[512-k] = conj(A_{512-k}) G[512-k] + B_k conj(G[k])
-            const double2 d0 = an_cmul(an_conj(ak), gk), d1 = an_cmul(br, an_conj(gr));
-            const double2 e0 = an_cmul(an_conj(ar), gr), e1 = an_cmul(bk, an_conj(gk));
-            if (k == 0) {
-                // bins 0 and 512 both fold onto dZ[0]
-                L.spec[SP(0)] = make_double2(d0.x + d1.x + e0.x + e1.x, d0.y + d1.y + e0.y + e1.y);
-            } else {
-                L.spec[SP(k)] = make_double2(d0.x + d1.x, d0.y + d1.y);
-                L.spec[SP(kr)] = make_double2(e0.x + e1.x, e0.y + e1.y);
-            }
-        }
-        wave_sync();
-        if (lane == 0) {  // self-paired bin 256
-            const double2 z = L.spec[SP(256)];
-            const double2 w = make_double2(0.0, -1.0);
-            double2 xk, xr;
-            an_split(z, z, w, xk, xr);
-            const double dp = dpow(256);
-            const double2 g = make_double2(xk.x * dp, xk.y * dp);
-            const double2 iw = make_double2(-w.y, w.x);
-            const double2 ak = make_double2(0.5 * (1.0 - iw.x), -0.5 * iw.y), bk = make_double2(0.5 * (1.0 + iw.x), 0.5 * iw.y);
-            const double2 d0 = an_cmul(an_conj(ak), g), d1 = an_cmul(bk, an_conj(g));
-            L.spec[SP(256)] = make_double2(d0.x + d1.x, d0.y + d1.y);
-        }
-        wave_sync();
-        fft512_r8_t(L.spec, tw1, tw2, lane, 1.0);
+        const int bb = gf / F;
+        an_frame_backward<R, CACHED || SPEC, SPEC, POWER>(t, tw1, tw2, bl, L, lc, x + (size_t)bb * T, T, gf - bb * F, (size_t)gf, scale, dfeats,
+                                                          lane);
         float* out = dframes + (size_t)gf * kAnWin;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = lane + 64 * i;
             const int q = 2 * n - (kAnFft - kAnWin) / 2;  // window index of FFT input 2n (even, since (1024-800)/2 = 112)
-            const double2 dz = L.spec[SP(n)];
+            const cx<R> dz = L.spec[SP(n)];
             if (q >= 0 && q < kAnWin)
                 *reinterpret_cast<float2*>(out + q) = make_float2((float)dz.x * lc.win[2 * i], (float)dz.y * lc.win[2 * i + 1]);
         }
         wave_sync();
     }
+}
+
+// ---- overlap-add pieces shared by the three kernels that produce d loss / d waveform (same expressions, same bits)
+// d x[t] from d pre[t - 1], d pre[t] (pre-emphasis adjoint: pre[p] = x[p + 1] - 0.97 x[p]) and the input scale
+__device__ __forceinline__ float an_dx(float dpm1, float dp0, int t, int Lp, float scale) {
+    float g = 0.f;
+    if (t >= 1) g += dpm1;
+    if (t <= Lp - 1) g -= 0.97f * dp0;
+    return g * scale;
+}
+__device__ __forceinline__ void an_emit(float g, size_t o, float* __restrict__ grad_out, const float* __restrict__ x_in,
+                                        float* __restrict__ x_out, const float* __restrict__ lower, const float* __restrict__ upper,
+                                        float step, int grad_sign) {
+    if (grad_out) grad_out[o] = g;
+    if (x_out) {
+        const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+        x_out[o] = fminf(fmaxf(x_in[o] + step * sg * (float)grad_sign, lower[o]), upper[o]);
+    }
+}
+// sum over the frames that cover signal position p (ascending frames), frames in global memory
+__device__ __forceinline__ float an_at_pos(const float* __restrict__ df, int F, int p) {
+    const int pmin = -kAnWin / 2, pmax = (F - 1) * kAnHop + kAnWin / 2 - 1;
+    float g = 0.f;
+    if (p < pmin || p > pmax) return g;
+    const int q = p + kAnWin / 2;  // >= 0
+    int fhi = q / kAnHop;
+    const int flo = q > kAnWin - 1 ? (q - (kAnWin - 1) + kAnHop - 1) / kAnHop : 0;
+    if (fhi > F - 1) fhi = F - 1;
+    for (int f = flo; f <= fhi; ++f) g += df[(size_t)f * kAnWin + (q - f * kAnHop)];
+    return g;
+}
+// gradient wrt pre-emphasised sample s in [0, Lp): the position itself and what torch.stft's reflect padding maps onto it
+__device__ __forceinline__ float an_dpre(const float* __restrict__ df, int F, int Lp, int s) {
+    float g = an_at_pos(df, F, s);
+    if (s >= 1) g += an_at_pos(df, F, -s);                    // left reflection  p = -s
+    if (s <= Lp - 2) g += an_at_pos(df, F, 2 * (Lp - 1) - s);  // right reflection p = 2(L-1) - s
+    return g;
 }
 
 // Deterministic overlap-add + pre-emphasis backward (+ optional fused PGD update).
@@ -300,23 +382,6 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
     const float scale = scale_p ? *scale_p : 1.f;
     const float* df = dframes + (size_t)b * F * kAnWin;
     const int Lp = T - 1;
-    const int pmin = -kAnWin / 2, pmax = (F - 1) * kAnHop + kAnWin / 2 - 1;
-    auto at_pos = [&](int p) {  // sum over the frames that cover signal position p
-        float g = 0.f;
-        if (p < pmin || p > pmax) return g;
-        const int q = p + kAnWin / 2;  // >= 0
-        int fhi = q / kAnHop;
-        const int flo = q > kAnWin - 1 ? (q - (kAnWin - 1) + kAnHop - 1) / kAnHop : 0;
-        if (fhi > F - 1) fhi = F - 1;
-        for (int f = flo; f <= fhi; ++f) g += df[(size_t)f * kAnWin + (q - f * kAnHop)];
-        return g;
-    };
-    auto dpre = [&](int s) {  // gradient wrt pre-emphasised sample s in [0, Lp)
-        float g = at_pos(s);
-        if (s >= 1) g += at_pos(-s);                    // left reflection  p = -s
-        if (s <= Lp - 2) g += at_pos(2 * (Lp - 1) - s);  // right reflection p = 2(L-1) - s
-        return g;
-    };
     // every d pre value is gathered once per block (up to 5 frame reads) and shared through LDS: d x[t] needs
     // d pre[t-1] and d pre[t] -- the first version gathered both per thread and read the 491 MB of per-frame
     // gradients of a batch-512 step twice
@@ -324,21 +389,118 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
     const int t0 = blockIdx.x * 256;
     {
         const int sidx = t0 + (int)threadIdx.x;  // d pre[s], stored at dp[threadIdx.x + 1]
-        dp[threadIdx.x + 1] = sidx <= Lp - 1 ? dpre(sidx) : 0.f;
-        if (threadIdx.x == 0) dp[0] = t0 >= 1 ? dpre(t0 - 1) : 0.f;
+        dp[threadIdx.x + 1] = sidx <= Lp - 1 ? an_dpre(df, F, Lp, sidx) : 0.f;
+        if (threadIdx.x == 0) dp[0] = t0 >= 1 ? an_dpre(df, F, Lp, t0 - 1) : 0.f;
     }
     __syncthreads();
     if (t >= T) return;
-    float g = 0.f;
-    if (t >= 1) g += dp[threadIdx.x];
-    if (t <= Lp - 1) g -= 0.97f * dp[threadIdx.x + 1];
-    g *= scale;
-    const size_t o = (size_t)b * T + t;
-    if (grad_out) grad_out[o] = g;
-    if (x_io) {
-        const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
-        x_io[o] = fminf(fmaxf(x_io[o] + step * sg * (float)grad_sign, lower[o]), upper[o]);
+    const float g = an_dx(dp[threadIdx.x], dp[threadIdx.x + 1], t, Lp, scale);
+    an_emit(g, (size_t)b * T + t, grad_out, x_io, x_io, lower, upper, step, grad_sign);
+}
+
+// ---- round 5: the overlap-add INSIDE the adjoint.  The separate pair wrote every frame's 800 gradient samples to HBM and
+// read them back (491 MB each way at 512 utterances: 242 us of an_frames_to_wave_kernel + the write half of the adjoint's
+// 558).  Here a block owns a run of consecutive frames [fa, fb) of ONE utterance and walks it in groups of NW frames (one
+// per wave): the waves leave their frame's windowed gradient in an LDS ring of NW + 4 frame slots, the block then adds up
+// -- in ascending frame order, like an_at_pos -- every signal position whose last covering frame is in the group
+// (position q = p + 400 is covered by frames (q - 799) / 160 .. q / 160), and turns the d pre values into d x (+ the fused
+// sign / project / clamp update).  A block starts 5 frames before fa (its first d x needs d pre one position to the left
+// of its first own position, which reaches 5 frames back); those halo frames are transformed twice -- 64 utterances x 8
+// slices: +13 %, 512 x 1: none.  What reaches across the utterance's ends -- the reflect padding of torch.stft, the first
+// 402 and the last ~400 samples -- is left to an_edge_to_wave_kernel, for which the first 6 and last 5 frames also go to HBM.
+// Same sums in the same order as the separate pair: same bits (tests/test_gpu_audionet.py).
+// The update reads x_in and writes x_out, two DIFFERENT buffers: a neighbour block still reads the waveform around the cut
+// (its halo frames) while this one writes its positions.
+template <typename R, int NW>
+struct AnOlaLds {  // dynamic LDS of the fused kernel (float, NW = 4: 61 KB, two blocks per CU; double, NW = 8: 139 KB, one)
+    AnFrameLdsT<R, false> lds[NW];
+    cx<R> tw1[kFftTw1], tw2[kFftTw2];
+    AnBinLds bl;
+    __attribute__((aligned(16))) float ring[NW + 4][kAnWin];
+    float dpl[2][NW * kAnHop + 1];
+};
+
+template <typename R, int NW, bool SPEC>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_kernel(AnTables t, AnOlaArgs a) {
+    constexpr int RING = NW + 4, NPOS = NW * kAnHop;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ola_lds_raw[];
+    AnOlaLds<R, NW>& S = *reinterpret_cast<AnOlaLds<R, NW>*>(ola_lds_raw);
+    auto& lds = S.lds;
+    cx<R>* tw1 = S.tw1;
+    cx<R>* tw2 = S.tw2;
+    AnBinLds& bl = S.bl;
+    auto& ring = S.ring;
+    auto& dpl = S.dpl;
+    an_stage_bins(t, bl);
+    an_stage_tw<R>(t, reinterpret_cast<double2*>(&ring[0][0]), tw1, tw2);  // (the ring is free until the first frame)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
+    const float scale = a.scale_p ? *a.scale_p : 1.f;
+    AnFrameLdsT<R, false>& L = lds[wid];
+    AnLaneConstT<R> lc;
+    an_lane_init<R, false>(t, lane, lc);
+    const int b = blockIdx.y, F = a.F, T = a.T, Lp = T - 1;
+    const int fa = (int)((long long)F * blockIdx.x / a.S), fb = (int)((long long)F * (blockIdx.x + 1) / a.S);
+    const int fs = fa > 5 ? fa - 5 : 0;
+    const int q_lo = kAnHop * fa, q_hi = kAnHop * fb;  // own positions q = t + 400; d pre is needed from q_lo - 1
+    const float* xr = a.x + (size_t)b * T;
+    int par = 0;
+    for (int g0 = fs; g0 < fb; g0 += NW, par ^= 1) {
+        const int f = g0 + wid;
+        if (f < fb) {
+            const size_t gf = (size_t)b * F + f;
+            an_frame_backward<R, true, SPEC, false>(t, tw1, tw2, bl, L, lc, xr, T, f, gf, scale, a.dfeats, lane);
+            float* slot = ring[f % RING];
+            float* edge = (f >= fa && (f < a.edge_lo || f >= a.edge_hi)) ? a.dframes + gf * kAnWin : nullptr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = lane + 64 * i;
+                const int q = 2 * n - (kAnFft - kAnWin) / 2;
+                const cx<R> dz = L.spec[SP(n)];
+                if (q >= 0 && q < kAnWin) {
+                    const float2 v = make_float2((float)dz.x * lc.win[2 * i], (float)dz.y * lc.win[2 * i + 1]);
+                    *reinterpret_cast<float2*>(slot + q) = v;
+                    if (edge) *reinterpret_cast<float2*>(edge + q) = v;
+                }
+            }
+        }
+        __syncthreads();
+        float* cur = dpl[par];
+        const float* prv = dpl[par ^ 1];
+        for (int i = tid; i < NPOS; i += NW * 64) {
+            const int q = kAnHop * g0 + i;
+            float g = 0.f;
+            if (q >= q_lo - 1 && q < q_hi) {
+                const int fhi = q / kAnHop;  // < fb <= F
+                const int flo = q > kAnWin - 1 ? (q - (kAnWin - 1) + kAnHop - 1) / kAnHop : 0;
+                for (int ff = flo; ff <= fhi; ++ff) g += ring[ff % RING][q - ff * kAnHop];
+            }
+            cur[1 + i] = g;
+        }
+        if (tid == 0) cur[0] = prv[NPOS];  // d pre of the position before the group (unused garbage in a block's first group)
+        __syncthreads();
+        for (int i = tid; i < NPOS; i += NW * 64) {
+            const int q = kAnHop * g0 + i, tt = q - kAnWin / 2;
+            if (q >= q_lo && q < q_hi && tt >= a.t_lo && tt <= a.t_hi) {
+                const float g = an_dx(cur[i], cur[i + 1], tt, Lp, scale);
+                an_emit(g, (size_t)b * T + tt, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
+            }
+        }
     }
+}
+
+// the utterance's ends: d x[t] for t < t_lo and t > t_hi from the edge frames the fused kernel left in HBM
+__global__ __launch_bounds__(256) void an_edge_to_wave_kernel(AnOlaArgs a) {
+    const int n_left = a.t_lo, n_right = a.T - 1 - a.t_hi;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_left + n_right) return;
+    const int t = idx < n_left ? idx : a.t_hi + 1 + (idx - n_left);
+    const int b = blockIdx.y, Lp = a.T - 1;
+    const float scale = a.scale_p ? *a.scale_p : 1.f;
+    const float* df = a.dframes + (size_t)b * a.F * kAnWin;
+    const float dpm1 = t >= 1 ? an_dpre(df, a.F, Lp, t - 1) : 0.f;
+    const float dp0 = t <= Lp - 1 ? an_dpre(df, a.F, Lp, t) : 0.f;
+    const float g = an_dx(dpm1, dp0, t, Lp, scale);
+    an_emit(g, (size_t)b * a.T + t, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
 }
 
 // ---------------------------------------------------------------- 5x5 pre-filter over (time, mel)
@@ -504,18 +666,91 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
 }
 
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
-                                hipStream_t s) {
+                                int fft32, hipStream_t s) {
     const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
-    hipLaunchKernelGGL(an_logmel_fwd_kernel, dim3(want < kAnMaxBlocks ? want : kAnMaxBlocks), dim3(256), 0, s, t, x, B, T, F,
-                       scale, feats);
+    const dim3 grid(want < kAnMaxBlocks ? want : kAnMaxBlocks);
+    if (fft32) hipLaunchKernelGGL(an_logmel_fwd_kernel<float>, grid, dim3(256), 0, s, t, x, B, T, F, scale, feats);
+    else hipLaunchKernelGGL(an_logmel_fwd_kernel<double>, grid, dim3(256), 0, s, t, x, B, T, F, scale, feats);
     return hipGetLastError();
 }
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
-                                const float* dfeats, float* dframes, hipStream_t s) {
+                                const float* dfeats, float* dframes, int fft32, hipStream_t s) {
     const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
     const dim3 grid(want < kAnMaxBlocks ? want : kAnMaxBlocks);
-    if (t.mel_cache) hipLaunchKernelGGL(an_logmel_bwd_kernel<true>, grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes);
-    else hipLaunchKernelGGL(an_logmel_bwd_kernel<false>, grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes);
+    const int kind = (t.mel_cache ? 1 : 0) + (t.mel_cache && t.spec_cache ? 2 : 0) + (fft32 ? 4 : 0);
+#define AN_BWD(R, C, SP) hipLaunchKernelGGL((an_logmel_bwd_kernel<R, C, SP>), grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes)
+    switch (kind) {
+        case 0: AN_BWD(double, false, false); break;
+        case 1: AN_BWD(double, true, false); break;
+        case 3: AN_BWD(double, true, true); break;
+        case 4: AN_BWD(float, false, false); break;
+        case 5: AN_BWD(float, true, false); break;
+        default: AN_BWD(float, true, true); break;
+    }
+#undef AN_BWD
+    return hipGetLastError();
+}
+
+// where the fused overlap-add hands over to the edge kernel (see an_logmel_bwd_ola_kernel)
+static void an_ola_ranges(int T, int F, AnOlaArgs& a) {
+    const int Lp = T - 1, pmax = (F - 1) * kAnHop + kAnWin / 2 - 1;
+    a.t_lo = kAnWin / 2 + 2;  // d pre[t - 1] with t - 1 > 400: no left reflection lands on it
+    int s_r0 = 2 * (Lp - 1) - pmax;  // first s with a right reflection term
+    if (s_r0 > F * kAnHop - kAnWin / 2) s_r0 = F * kAnHop - kAnWin / 2;  // positions q = s + 400 < 160 F: inside the block loop
+    a.t_hi = s_r0 - 1;
+    if (a.t_hi > Lp - 1) a.t_hi = Lp - 1;
+    if (a.t_hi < a.t_lo) {  // short utterance: everything is edge
+        a.t_lo = T;
+        a.t_hi = T - 1;
+        a.edge_lo = F;
+        a.edge_hi = F;
+        return;
+    }
+    a.edge_lo = (a.t_lo - 1 + kAnWin / 2) / kAnHop + 1;  // frames covering q <= t_lo - 1 + 400
+    const int q = a.t_hi + kAnWin / 2;
+    a.edge_hi = q > kAnWin - 1 ? (q - (kAnWin - 1) + kAnHop - 1) / kAnHop : 0;
+}
+
+hipError_t launch_an_logmel_bwd_ola(const AnTables& t, AnOlaArgs a, int fft32, int num_cus, hipStream_t s) {
+    if (!t.mel_cache) return hipErrorInvalidValue;  // the fused form is for the pass whose forward has just run
+    an_ola_ranges(a.T, a.F, a);
+    const int nw = fft32 ? 4 : 8, slots = (num_cus > 0 ? num_cus : 256) * (fft32 ? 2 : 1);
+    // slices per utterance: rounds of resident blocks x groups of nw frames per block (5 halo frames per slice)
+    int best_s = 1;
+    long best_cost = -1;
+    const int smax = a.F / 8 > 0 ? a.F / 8 : 1;
+    for (int sl = 1; sl <= smax; ++sl) {
+        const long rounds = ((long)a.B * sl + slots - 1) / slots;
+        const long groups = ((a.F + sl - 1) / sl + 5 + nw - 1) / nw;
+        const long cost = rounds * groups;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_s = sl;
+        }
+    }
+    a.S = best_s;
+    const dim3 grid(a.S, a.B);
+    const bool spec = t.spec_cache != nullptr;
+    hipError_t e = hipSuccess;
+#define AN_OLA(R, NW, SP)                                                                                                   \
+    do {                                                                                                                    \
+        const int bytes = (int)sizeof(AnOlaLds<R, NW>);                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(an_logmel_bwd_ola_kernel<R, NW, SP>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                          \
+        if (e == hipSuccess) hipLaunchKernelGGL((an_logmel_bwd_ola_kernel<R, NW, SP>), grid, dim3(NW * 64), bytes, s, t, a);   \
+    } while (0)
+    if (fft32) {
+        if (spec) AN_OLA(float, 4, true);
+        else AN_OLA(float, 4, false);
+    } else {
+        if (spec) AN_OLA(double, 8, true);
+        else AN_OLA(double, 8, false);
+    }
+#undef AN_OLA
+    if (e != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const int n_edge = a.t_lo + (a.T - 1 - a.t_hi);
+    if (n_edge > 0) hipLaunchKernelGGL(an_edge_to_wave_kernel, dim3((n_edge + 255) / 256, a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,

@@ -240,8 +240,17 @@ int an_frontend_forward(sg_ctx* ctx, const float* x, const AnDims& d, hipStream_
     if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
-    w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T;
-    AN_STAGE(SG_STAGE_AN_LOGMEL_FWD, launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, s));
+    if (ctx->an_cfg.spec_cache) {
+        if (!w.spec_cache) {  // first use: room for the workspace's capacity
+            void* p = nullptr;
+            AN_HIP(hipMalloc(&p, (size_t)w.B * w.F * (kAnFft / 2) * sizeof(float2)));
+            w.allocs.push_back(p);
+            w.spec_cache = static_cast<float2*>(p);
+        }
+        tab.spec_cache = w.spec_cache;
+    }
+    w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T; w.cache_spec = tab.spec_cache != nullptr;
+    AN_STAGE(SG_STAGE_AN_LOGMEL_FWD, launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, ctx->an_cfg.fft32, s));
     return SG_OK;
 }
 
@@ -368,22 +377,49 @@ int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t
 }
 
 // d loss / d log-mel (B, F, 32) -> d loss / d waveform: written to grad_out and / or applied as the fused PGD update
-int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const float* dfeats, float* grad_out, float* x_update, const float* lower, const float* upper, float step, int grad_sign,
-                         hipStream_t s) {
+// x_update: the iterate to step from (== x); x_next: where the stepped iterate goes.  The fused overlap-add needs
+// x_next != x_update (neighbour blocks still read x around their cut); the separate pair updates in place and copies if
+// the caller asked for another buffer.
+int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const float* dfeats, float* grad_out, float* x_update, float* x_next,
+                         const float* lower, const float* upper, float step, int grad_sign, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
-    AN_STAGE(SG_STAGE_AN_LOGMEL_BWD, launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, dfeats, w.dframes, s));
+    tab.spec_cache = w.cache_spec ? w.spec_cache : nullptr;
+    if (ctx->an_cfg.ola && (!x_update || x_next != x_update)) {
+        AnOlaArgs a{};
+        a.x = x; a.dfeats = dfeats; a.dframes = w.dframes; a.grad_out = grad_out;
+        a.x_in = x_update; a.x_out = x_update ? x_next : nullptr; a.lower = lower; a.upper = upper; a.scale_p = w.scale;
+        a.step = step; a.grad_sign = grad_sign; a.B = d.B; a.T = d.T; a.F = d.F;
+        AN_STAGE(SG_STAGE_AN_LOGMEL_BWD, launch_an_logmel_bwd_ola(tab, a, ctx->an_cfg.fft32, ctx->num_cus, s));
+        return SG_OK;
+    }
+    AN_STAGE(SG_STAGE_AN_LOGMEL_BWD, launch_an_logmel_bwd(tab, x, d.B, d.T, d.F, w.scale, dfeats, w.dframes, ctx->an_cfg.fft32, s));
     AN_STAGE(SG_STAGE_AN_OVERLAP_ADD, launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_out, x_update, lower, upper, step, grad_sign, s));
+    if (x_update && x_next != x_update)
+        AN_HIP(hipMemcpyAsync(x_next, x_update, (size_t)d.B * d.T * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SG_OK;
 }
 
-int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, float* grad_out, float* x_update,
+// the buffer the fused overlap-add steps into (null: the separate pair updates in place)
+float* an_step_target(sg_ctx* ctx, const AnDims& d) {
+    AnWorkspace& w = ctx->an_ws;
+    if (!ctx->an_cfg.ola) return nullptr;
+    if (!w.x_alt) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)w.B * w.T * sizeof(float)) != hipSuccess) return nullptr;  // falls back to the separate pair
+        w.allocs.push_back(p);
+        w.x_alt = static_cast<float*>(p);
+    }
+    return w.x_alt;
+}
+
+int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, float* grad_out, float* x_update, float* x_next,
                     const float* lower, const float* upper, float step, int grad_sign, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     int rc = an_net_backward(ctx, d.B, d.F, flag == 1 ? grad_out : w.dfeats, s);
     if (rc || flag == 1) return rc;
-    return an_frontend_backward(ctx, x, d, w.dfeats, grad_out, x_update, lower, upper, step, grad_sign, s);
+    return an_frontend_backward(ctx, x, d, w.dfeats, grad_out, x_update, x_next, lower, upper, step, grad_sign, s);
 }
 
 }  // namespace
@@ -467,14 +503,14 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
         if ((rc = an_check(ctx, B, T, 0, &d))) return rc;
         AnWorkspace& w = ctx->an_ws;
         tab.mel_cache = w.mel_cache;
-        w.cache_x = x_dev; w.cache_B = B; w.cache_T = T;
+        w.cache_x = x_dev; w.cache_B = B; w.cache_T = T; w.cache_spec = false;
     } else if (!ctx->an_ws.scale) {
         rc = an_ensure_workspace(ctx, 1, kAnFft, an_num_frames(kAnFft) + 40);
         if (rc) return rc;
     }
     scale = ctx->an_ws.scale;
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, scale, 1, s));
-    AN_HIP(launch_an_logmel_fwd(tab, x_dev, B, T, an_num_frames(T), scale, feats_dev, s));
+    AN_HIP(launch_an_logmel_fwd(tab, x_dev, B, T, an_num_frames(T), scale, feats_dev, ctx->an_cfg.fft32, s));
     return SG_OK;
 }
 
@@ -487,10 +523,31 @@ int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T,
     hipStream_t s = (hipStream_t)stream;
     AnWorkspace& w = ctx->an_ws;
     AnTables tab = ctx->an_tab;
-    if (reuse_forward && w.cache_x == x_dev && w.cache_B == B && w.cache_T == T) tab.mel_cache = w.mel_cache;
+    if (reuse_forward && w.cache_x == x_dev && w.cache_B == B && w.cache_T == T) {
+        tab.mel_cache = w.mel_cache;
+        tab.spec_cache = w.cache_spec ? w.spec_cache : nullptr;
+    }
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, w.scale, 1, s));
-    AN_HIP(launch_an_logmel_bwd(tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, s));
+    if (tab.mel_cache && ctx->an_cfg.ola) {  // the attack loops' form of the adjoint (same sums in the same order as the pair below)
+        AnOlaArgs a{};
+        a.x = x_dev; a.dfeats = dfeats_dev; a.dframes = w.dframes; a.grad_out = grad_dev; a.scale_p = w.scale;
+        a.B = d.B; a.T = d.T; a.F = d.F;
+        AN_HIP(launch_an_logmel_bwd_ola(tab, a, ctx->an_cfg.fft32, ctx->num_cus, s));
+        return SG_OK;
+    }
+    AN_HIP(launch_an_logmel_bwd(tab, x_dev, d.B, d.T, d.F, w.scale, dfeats_dev, w.dframes, ctx->an_cfg.fft32, s));
     AN_HIP(launch_an_frames_to_wave(w.dframes, d.B, d.T, d.F, w.scale, grad_dev, nullptr, nullptr, nullptr, 0.f, 1, s));
+    return SG_OK;
+}
+
+int sg_an_configure(sg_ctx* ctx, int32_t fft_bits, int32_t spectrum_cache, int32_t fused_overlap_add) {
+    if (!ctx) return SG_ERR_ARG;
+    if (fft_bits != 32 && fft_bits != 64) return an_fail(ctx, SG_ERR_ARG, "fft_bits must be 32 or 64");
+    ctx->an_cfg.fft32 = fft_bits == 32;
+    ctx->an_cfg.spec_cache = spectrum_cache != 0;
+    ctx->an_cfg.ola = fused_overlap_add != 0;
+    ctx->an_ws.cache_x = nullptr;  // what an earlier forward left behind was computed under the old settings
+    ctx->an_ws.cache_spec = false;
     return SG_OK;
 }
 
@@ -548,7 +605,7 @@ int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, *loss,
                           grad_dev != nullptr, nullptr, scores_dev, decisions_dev, loss_dev, w.dact[L], nullptr, nullptr,
                           nullptr, s));
-    if (grad_dev) return an_backward_net(ctx, x_dev, d, flag, grad_dev, nullptr, nullptr, nullptr, 0.f, 0, s);
+    if (grad_dev) return an_backward_net(ctx, x_dev, d, flag, grad_dev, nullptr, nullptr, nullptr, nullptr, 0.f, 0, s);
     return SG_OK;
 }
 
@@ -564,20 +621,27 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     hipStream_t s = (hipStream_t)stream;
     AnWorkspace& w = ctx->an_ws;
     const int L = kAnConv - 1;
+    // the fused overlap-add steps from one waveform buffer into another: the iterate alternates between the caller's
+    // buffer and a workspace twin and is copied home once if the attack ends on the twin
+    float* xc = x_adv_dev;
+    float* xn = an_step_target(ctx, d);
+    if (!xn) xn = x_adv_dev;
     for (int it = 0; it <= p->max_iter; ++it) {
         const bool last = it == p->max_iter;
         d.keep_scale = it > 0;  // iterates stay in [-1, 1]
-        if ((rc = an_forward_net(ctx, x_adv_dev, d, 0, s))) return rc;
+        if ((rc = an_forward_net(ctx, xc, d, 0, s))) return rc;
         AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
                               nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
                               w.dact[L], loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
                               decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr,
                               last ? success_dev : nullptr, s));
         if (!last) {
-            rc = an_backward_net(ctx, x_adv_dev, d, 0, nullptr, x_adv_dev, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
+            rc = an_backward_net(ctx, xc, d, 0, nullptr, xc, xn, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
             if (rc) return rc;
+            if (xn != xc) std::swap(xc, xn);
         }
     }
+    if (xc != x_adv_dev) AN_HIP(hipMemcpyAsync(x_adv_dev, xc, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SG_OK;
 }
 
@@ -616,11 +680,14 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
     const int L = kAnConv - 1;
     for (int r = 0; r < reps; ++r)
         AN_HIP(hipMemcpyAsync(w.y_rep + (size_t)r * B, y_dev, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    float* xc = x_adv_dev;  // waveform ping-pong of the fused overlap-add (sg_an_pgd_run)
+    float* xn = an_step_target(ctx, d);
+    if (!xn) xn = x_adv_dev;
     for (int it = 0; it <= p->max_iter; ++it) {
         const bool last = it == p->max_iter;
         const int R = last ? 1 : reps, rows = B * R;
         d.keep_scale = it > 0;  // iterates stay in [-1, 1]
-        if ((rc = an_frontend_forward(ctx, x_adv_dev, d, s))) return rc;
+        if ((rc = an_frontend_forward(ctx, xc, d, s))) return rc;
         const uint64_t key = f->seed + (uint64_t)it * 0x9E3779B97F4A7C15ull;  // repeat r: + r * 0xC2B2AE3D27D4EB4F
         trace_mark(ctx, SG_STAGE_AN_FECO_FWD, s, 0);
         rc = sg_feco_kmeans_compress(ctx, w.feats, B, d.F, kAnMel, k, f->max_iter, f->random_init, key, f->index_base, R,
@@ -644,9 +711,11 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
         trace_mark(ctx, SG_STAGE_AN_FECO_BWD, s, 0);
         if ((rc = sg_feco_compress_backward_reps(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, R, w.dfeats, s))) return rc;
         trace_mark(ctx, SG_STAGE_AN_FECO_BWD, s, 1);
-        rc = an_frontend_backward(ctx, x_adv_dev, d, w.dfeats, nullptr, x_adv_dev, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
+        rc = an_frontend_backward(ctx, xc, d, w.dfeats, nullptr, xc, xn, lower_dev, upper_dev, p->step_size, p->grad_sign, s);
         if (rc) return rc;
+        if (xn != xc) std::swap(xc, xn);
     }
+    if (xc != x_adv_dev) AN_HIP(hipMemcpyAsync(x_adv_dev, xc, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SG_OK;
 }
 

@@ -61,6 +61,29 @@ struct AnTables {            // device pointers
     double2* twiddle;        // [512] exp(-2 pi i k / 1024)
     uint16_t* bitrev;        // [1024]
     float* mel_cache;        // [B*F][32] forward -> backward hand-over within one pass (null: the backward recomputes)
+    float2* spec_cache;      // [B*F][512] packed spectrum Z of every frame, same hand-over (null: the backward transforms again)
+};
+// how the AudioNet front-end runs (sg_an_configure)
+struct AnFrontCfg {
+    int fft32 = 1;       // transforms in float32 (the reference's precision) or float64
+    int spec_cache = 0;  // the forward keeps every frame's packed spectrum for the backward of the same pass
+    int ola = 1;         // overlap-add (+ update) inside the log-mel adjoint
+};
+struct AnOlaArgs {
+    const float* x;        // (B, T) waveform the frames are re-transformed from (spectrum cache: unused)
+    const float* dfeats;   // (B, F, 32)
+    float* dframes;        // (B, F, 800): only the edge frames are written (f < edge_lo or f >= edge_hi)
+    float* grad_out;       // (B, T) or null
+    const float* x_in;     // update: x_out = clamp(x_in + step * sign(g) * grad_sign); null: no update
+    float* x_out;
+    const float* lower;
+    const float* upper;
+    const float* scale_p;
+    float step;
+    int grad_sign;
+    int B, T, F, S;        // S slices per utterance (chosen by the launcher)
+    int edge_lo, edge_hi;  // frames the edge kernel needs (launcher)
+    int t_lo, t_hi;        // d x[t] for t in [t_lo, t_hi] comes from the fused kernel, the rest from the edge kernel (launcher)
 };
 
 struct AnModel {
@@ -99,9 +122,12 @@ struct AnWorkspace {
     float* trace_l = nullptr;    // (B * R) per-row loss / decision records of such a pass (reduced over the repeats afterwards)
     int64_t* trace_d = nullptr;
     float* mel_cache = nullptr;  // (B, F, 32) mel energies of the forward pass, kept for the backward of the same pass
+    float2* spec_cache = nullptr;  // (B, F, 512) packed spectra of the forward pass (allocated when sg_an_configure asks for it)
+    float* x_alt = nullptr;      // (B, T) the other half of the waveform ping-pong of the fused overlap-add update (on demand)
     // which input the mel cache belongs to (sg_an_logmel_backward(reuse_forward) checks pointer and shape, not contents)
     const float* cache_x = nullptr;
     int cache_B = 0, cache_T = 0;
+    bool cache_spec = false;     // the spectrum cache holds that input's spectra too
     std::vector<void*> allocs;
 };
 
@@ -206,6 +232,7 @@ struct sg_ctx {
     unsigned* err_host = nullptr;
     unsigned* err_dev = nullptr;
     sg::AnTables an_tab{};
+    sg::AnFrontCfg an_cfg{};
     bool an_tables_ready = false;
     sg::AnModel an;
     sg::AnWorkspace an_ws;
@@ -351,9 +378,11 @@ bool an_fused_supported(const int* Tin, const int* Tout, int Fnet, int rows, int
 // force_slices > 0: that many time slices per utterance instead of the planner's choice (tests: same bits for any cut)
 hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backward, int force_slices, hipStream_t s);
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
-                                hipStream_t s);
+                                int fft32, hipStream_t s);
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
-                                const float* dfeats, float* dframes, hipStream_t s);
+                                const float* dfeats, float* dframes, int fft32, hipStream_t s);
+// the adjoint with the overlap-add (+ update) inside: needs t.mel_cache of the same pass; x_out != x_in
+hipError_t launch_an_logmel_bwd_ola(const AnTables& t, AnOlaArgs a, int fft32, int num_cus, hipStream_t s);
 hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
                                     float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                     hipStream_t s);

@@ -38,7 +38,12 @@ def sd():
 @pytest.fixture(scope="module")
 def hip(sd, dev):
     from speakerguard_amd.model.audionet_csine import audionet_csine
-    return audionet_csine.from_weights(sd, device=dev)
+    m = audionet_csine.from_weights(sd, device=dev)
+    cfg = os.environ.get("SG_AN_TEST_CFG")  # A/B runs of this file: "fft_bits,spectrum_cache,fused_overlap_add" (default: the library's)
+    if cfg:
+        bits, cache, ola = (int(v) for v in cfg.split(","))
+        m.configure_frontend(bits, bool(cache), bool(ola))
+    return m
 
 
 @pytest.fixture(scope="module")
@@ -346,3 +351,67 @@ def test_fused_cnn_random_shapes(hip, dev, monkeypatch):
     tags = [t for t, _ in hip.trace_stages(lambda: hip.make_decision(x), max_records=64)]
     assert "an_cnn_fwd" not in tags and any(t.startswith("an_conv") for t in tags), tags
     log("audionet fused CNN: %d random shapes (B 1..7, 0.25..9 s, random cuts) equal the per-layer sequence bit for bit; 180 s falls back" % len(shapes))
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+@pytest.mark.parametrize("B,T", [(3, 48000), (2, 20011), (1, 16000), (5, 4000), (2, 6000), (9, 65000)])
+def test_overlap_add_inside_the_adjoint_equals_the_separate_pair(sd, dev, bits, B, T):
+    """Round 5: the log-mel adjoint adds the frames' gradients up on chip (an_logmel_bwd_ola_kernel + an_edge_to_wave_kernel)
+    instead of writing them out for an_frames_to_wave_kernel -- same sums in the same order: d loss / d wav and the stepped
+    iterate of the device loop are EQUAL, whatever the utterance length (short ones are all 'edge'), the slice cut and the
+    transform precision; in float32 the spectrum cache holds exactly what the backward would recompute."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    m = audionet_csine.from_weights(sd, device=dev)
+    x = torch.from_numpy(synth.make_waveforms(B, T, seed=90 + B)).to(dev)
+    y = m.make_decision(x)[0]
+    lower, upper = torch.clamp(x - 0.002, min=-1), torch.clamp(x + 0.002, max=1)
+    spec = SEC4SR_CrossEntropy()
+    out = {}
+    for cache in (False, True):
+        for ola in (False, True):
+            m.configure_frontend(bits, cache, ola)
+            g = m.loss_grad(x, y, spec)[3]
+            xa = m.pgd_run(x, y, lower, upper, spec, 0.0004, 3, 1)[0]  # odd number of steps: the iterate ends on the twin buffer
+            xb = m.pgd_run(x, y, lower, upper, spec, 0.0004, 2, 1)[0]
+            out[(cache, ola)] = (g, xa, xb)
+    ref = out[(False, False)]
+    assert ref[0].abs().max().item() > 0
+    for key, val in out.items():
+        if bits == 64 and key[0]:
+            continue  # the cached float32 spectrum rounds the float64 one: compared among themselves below
+        for a, b in zip(ref, val):
+            assert torch.equal(a, b), "fft %d, spectrum cache %s, fused overlap-add %s differs" % ((bits,) + key)
+    if bits == 64:
+        for a, b in zip(out[(True, False)], out[(True, True)]):
+            assert torch.equal(a, b)
+        d = (out[(True, True)][0] - ref[0]).abs().max().item() / ref[0].abs().max().item()
+        log("audionet adjoint, float64 transforms, B=%d T=%d: cached float32 spectrum vs re-transform, d loss/d wav differs by %.2e of max" % (B, T, d))
+        assert d < 1e-5
+
+
+def test_float32_transforms_against_float64(sd, dev):
+    """The two transform precisions of sg_an_configure side by side on the full-size input: log-mel in dB, logits,
+    decisions, d loss / d wav (recorded in the parity log; the reference's own STFT is float32)."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    m = audionet_csine.from_weights(sd, device=dev)
+    x = torch.from_numpy(synth.make_waveforms(16, 48000, seed=77)).to(dev)
+    spec = SEC4SR_CrossEntropy()
+    res = {}
+    for bits in (64, 32):
+        m.configure_frontend(bits, False, True)
+        feats = m.compute_feat(x)
+        y = m.make_decision(x)[0] if bits == 64 else res[64][1]
+        dec, scores, loss, g = m.loss_grad(x, y, spec)
+        res[bits] = (feats, y, dec, scores, g)
+    f64, _, d64, s64, g64 = res[64]
+    f32, _, d32, s32, g32 = res[32]
+    gerr = (g32 - g64).abs().max().item() / g64.abs().max().item()
+    sign = float((torch.sign(g32) != torch.sign(g64)).float().mean())
+    log("audionet float32 vs float64 transforms (16 x 3 s): log-mel max %.2e dB, logits max %.2e, decisions equal %s, "
+        "d loss/d wav %.2e of max, sign mismatch %.2e" % ((f32 - f64).abs().max().item(), (s32 - s64).abs().max().item(),
+                                                          bool(torch.equal(d32, d64)), gerr, sign))
+    assert (f32 - f64).abs().max().item() < 2e-3 and torch.equal(d32, d64) and gerr < 1e-3
