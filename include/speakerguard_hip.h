@@ -47,6 +47,18 @@ int sg_sync(sg_ctx* ctx, void* stream);
  * out: the contraction's output, and everything computed from it, is invalid); clears the word.  Does not
  * synchronise -- call it after the results were awaited (sg_sync does both).  Every pass entry point checks it too. */
 int sg_health(sg_ctx* ctx);
+/* The large contractions (TDNN layers 2-5, both directions) run as "stream-K" launches: one persistent block per compute
+ * unit, a tile that is split between two blocks handed over through device memory.  A waiting block spins on its
+ * predecessor, so ALL blocks of a launch must be resident at once: the context needs the GPU TO ITSELF while a pass runs
+ * (no other process or context computing on the same device).  On a shared GPU a hand-off wait can time out; that is
+ * reported, never silent (sg_health), and the caller's remedy is sg_set_streamk(ctx, 0): every contraction then runs as
+ * one block per tile -- the same fused multiply-add chain per output, bit-identical results, a few percent slower at
+ * batch 64 -- with no residency requirement.  speakerguard_amd's attack drivers do exactly that once, automatically
+ * (attack/FGSM.py _run_batches), before they give up.  Default: enabled. */
+int sg_set_streamk(sg_ctx* ctx, int32_t enable);
+/* TEST HOOK (fault injection for the health path; no production use): the next `launches` stream-K launches of this
+ * context publish no hand-off flags, so their waiting blocks time out (after a shortened bound) and raise the health word. */
+int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches);
 
 /* ---- x-vector + PLDA model ----------------------------------------------------------------
  * Replaces the tensors the reference holds after model/xv_plda.py:17-47 ran: the xvecTDNN
@@ -280,7 +292,7 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
  * or shape differ, the forward is recomputed. */
 int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* dfeats_dev, float* grad_dev,
                           int32_t reuse_forward, void* stream);
-/* How the log-mel front-end and its adjoint run on this context (round 5; defaults 32, 0, 1):
+/* How the log-mel front-end and its adjoint run on this context (round 5; defaults 32, 1, 0 = the fastest measured):
  *   fft_bits 32 | 64: the scalar type of the STFT's transforms.  The reference computes its STFT in float32
  *     (model/_audionet/Preprocessor.py:100-105, torch.stft on a float32 signal); 64 is the form of rounds 1-4.
  *   spectrum_cache: the forward of a pass keeps every frame's packed spectrum (B x F x 4 KB) for the backward of the same

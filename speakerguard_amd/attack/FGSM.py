@@ -130,6 +130,19 @@ class FGSM(Attack):
             base.begin_batch(self.index_offset + start, 0 if tag is None else int(tag) + 1)
 
     def _run_batches(self, x, y, lower, upper, tag=None):
+        base = getattr(self.model, 'base_model', self.model)
+        try:
+            return self._run_batches_once(x, y, lower, upper, tag)
+        except Exception as e:  # the engine's NativeError (kept generic: the CPU test double has no such class)
+            # A stream-K hand-off that timed out (the GPU was shared: include/speakerguard_hip.h, sg_set_streamk): the
+            # inputs are untouched (attack_batch works on copies) and the noise keys depend on positions only, so the
+            # batches are run again, once, as one block per tile -- the same bits, no residency requirement.
+            if 'hand-off' not in str(e) or not hasattr(base, 'set_streamk') or getattr(base, 'streamk', True) is False:
+                raise
+            base.set_streamk(False)
+            return self._run_batches_once(x, y, lower, upper, tag)
+
+    def _run_batches_once(self, x, y, lower, upper, tag=None):
         n_audios = x.shape[0]
         batch_size = min(self.batch_size, n_audios)
         n_batches = int(np.ceil(n_audios / float(batch_size)))

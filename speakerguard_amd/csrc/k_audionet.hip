@@ -15,7 +15,7 @@
 namespace sg {
 
 constexpr int kAnWavesPerBlock = 4;
-constexpr int kAnMaxBlocks = 512;   // 2 blocks (51 KB of LDS each) per CU x 256 CUs
+constexpr int kAnMaxBlocks = 768;   // up to 3 blocks per CU x 256 CUs
 constexpr int kAnHalf = kAnFft / 2; // 512: a 1024-point REAL frame is one 512-point complex transform + a split step
 constexpr int kAnMelLaneBins = 44;  // >= bins per half filter (exactly 44 for 32 slaney filters over 513 bins; host-checked)
 
@@ -41,53 +41,97 @@ __device__ __forceinline__ float an_wave_sum(float v) {
 template <typename R, bool POWER>
 struct AnFrameLdsT {
     cx<R> spec[kAnHalf + kAnHalf / 8];  // element i at SP(i)
-    float power[POWER ? kAnBins + 3 : 4];
+    float power[POWER ? kAnBins + 3 + kAnMelLaneBins : 4];  // bins past 512 stay zero: a lane's 44 taps need no clamp
     float mel[32];
     float dmel[36];
 };
 
 __device__ __forceinline__ int an_reflect(int p, int L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
 
+// Per-lane constants of a block's waves.  The window taps and the half mel filter of a lane are the same in every wave:
+// they sit in block-shared LDS tables read lane-linearly (round 5: 60 registers less per thread -- three blocks per CU
+// instead of two for the float32 kernels, whose stalls are LDS and L2 round trips, not arithmetic).
+template <bool MEL>
+struct AnLaneTab {
+    float win[16][64];                        // [tap of FFT input q = 2 (lane + 64 i) + {0, 1}][lane] (0 outside the 800-tap window)
+    float mel_w[MEL ? kAnMelLaneBins : 1][64];  // [tap][lane]: weights of the lane's half mel filter, ascending bins, zero-padded
+};
 template <typename R>
 struct AnLaneConstT {
-    float win[16];            // window tap of FFT input q = 2 (lane + 64 i) + {0, 1} (0 outside the 800-tap window)
+    const float* win;         // &tab.win[0][lane]: tap i at win[64 i]
+    const float* mel_w;       // &tab.mel_w[0][lane]
     cx<R> wk[4];              // W^j for this lane's pairs j = lane + 64 i
+    int m[8];                 // an_lane_offsets
     int mel_k0;
-    float mel_w[kAnMelLaneBins];
 };
 
+__device__ __forceinline__ void an_lane_offsets(int lane, int (&m)[8]);
+// fills the block's table (all threads; the caller synchronises before the first frame) and the lane's registers
 template <typename R, bool MEL>
-__device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLaneConstT<R>& lc) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = 2 * (lane + 64 * i) + h - (kAnFft - kAnWin) / 2;
-            lc.win[2 * i + h] = (n >= 0 && n < kAnWin) ? t.window[n] : 0.f;
-        }
+__device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLaneTab<MEL>& tab, AnLaneConstT<R>& lc) {
+    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {
+        const int tap = e >> 6, l = e & 63;
+        const int n = 2 * (l + 64 * (tap >> 1)) + (tap & 1) - (kAnFft - kAnWin) / 2;
+        tab.win[tap][l] = (n >= 0 && n < kAnWin) ? t.window[n] : 0.f;
     }
+    lc.win = &tab.win[0][lane];
+    lc.mel_w = &tab.mel_w[0][lane];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double2 w = t.twiddle[lane + 64 * i];
         lc.wk[i] = cmk<R>((R)w.x, (R)w.y);
     }
-    if (!MEL) return;
-    const int m = lane >> 1, h = lane & 1;
-    const int lo = t.mel_lo[m], hi = t.mel_hi[m];
-    const int mid = lo + (hi - lo + 1) / 2;
-    const int k0 = h ? mid : lo, cnt = (h ? hi : mid) - k0;
-    lc.mel_k0 = k0;
-#pragma unroll
-    for (int j = 0; j < kAnMelLaneBins; ++j) lc.mel_w[j] = j < cnt ? t.mel_w[m * kAnBins + min(k0 + j, kAnBins - 1)] : 0.f;
+    an_lane_offsets(lane, lc.m);
+    lc.mel_k0 = 0;
+    if constexpr (MEL) {
+        auto half_filter = [&](int l, int& k0, int& cnt) {
+            const int m = l >> 1, h = l & 1;
+            const int lo = t.mel_lo[m], hi = t.mel_hi[m];
+            const int mid = lo + (hi - lo + 1) / 2;
+            k0 = h ? mid : lo;
+            cnt = (h ? hi : mid) - k0;
+        };
+        int k0, cnt;
+        half_filter(lane, k0, cnt);
+        lc.mel_k0 = k0;
+        for (int e = threadIdx.x; e < kAnMelLaneBins * 64; e += blockDim.x) {
+            const int j = e >> 6, l = e & 63;
+            half_filter(l, k0, cnt);
+            tab.mel_w[j][l] = j < cnt ? t.mel_w[(l >> 1) * kAnBins + min(k0 + j, kAnBins - 1)] : 0.f;
+        }
+    }
 }
 
 // raw samples of frame f: x[p], x[p + 1] for the 16 FFT inputs of this lane
 struct AnRaw {
     float a[16], b[16];
 };
-__device__ __forceinline__ void an_load_frame(const float* __restrict__ xr, int T, int f, int lane, AnRaw& r) {
+// Round 5 (the float32 kernels are bound by VALU issue, and two thirds of what they issued was index arithmetic): a frame
+// that does not touch the reflected ends reads x[base + m_i + {0, 1, 2}] for the lane's 8 pairs of FFT inputs, m_i a lane
+// constant (kept by the caller) -- the frame's base address is wave-uniform, so the loads need no per-lane address
+// arithmetic at all.  A tap outside the 800-sample window has weight 0: any finite sample will do there (m_i is clamped).
+__device__ __forceinline__ void an_lane_offsets(int lane, int (&m)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = 2 * (lane + 64 * i) - (kAnFft - kAnWin) / 2;
+        m[i] = n < 0 ? 0 : (n > kAnWin - 2 ? kAnWin - 2 : n);  // taps n, n + 1 and the sample after them
+    }
+}
+__device__ __forceinline__ void an_load_frame(const float* __restrict__ xr, int T, int f, int lane, const int (&m)[8], AnRaw& r) {
     const int Lp = T - 1;                         // length of the pre-emphasised signal
     const int base = f * kAnHop - kAnWin / 2;     // centre=True: frame f is centred on sample f*hop
+    if (base >= 0 && base + kAnWin <= Lp) {       // x[base .. base + 800] exist and no position is reflected (wave-uniform)
+        const float* xb = xr + base;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v0 = xb[m[i]], v1 = xb[m[i] + 1], v2 = xb[m[i] + 2];
+            r.a[2 * i] = v0;
+            r.b[2 * i] = v1;
+            r.a[2 * i + 1] = v1;
+            r.b[2 * i + 1] = v2;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int q = 2 * (lane + 64 * (i >> 1)) + (i & 1);
@@ -126,8 +170,8 @@ __device__ __forceinline__ void an_frame_forward(const cx<R>* tw1, const cx<R>* 
     cx<R> in[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float v0 = (r.b[2 * i] - 0.97f * r.a[2 * i]) * scale * lc.win[2 * i];
-        const float v1 = (r.b[2 * i + 1] - 0.97f * r.a[2 * i + 1]) * scale * lc.win[2 * i + 1];
+        const float v0 = (r.b[2 * i] - 0.97f * r.a[2 * i]) * scale * lc.win[64 * (2 * i)];
+        const float v1 = (r.b[2 * i + 1] - 0.97f * r.a[2 * i + 1]) * scale * lc.win[64 * (2 * i + 1)];
         in[i] = cmk<R>((R)v0, (R)v1);
     }
     fft512T_regin<R>(L.spec, tw1, tw2, lane, (R)-1, in);
@@ -151,7 +195,7 @@ __device__ __forceinline__ void an_frame_forward(const cx<R>* tw1, const cx<R>* 
         // 32 slaney-mel filters, two lanes per filter (each takes half of the filter's bin range, ascending)
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < kAnMelLaneBins; ++j) acc += L.power[min(lc.mel_k0 + j, kAnBins - 1)] * lc.mel_w[j];
+        for (int j = 0; j < kAnMelLaneBins; ++j) acc += L.power[lc.mel_k0 + j] * lc.mel_w[64 * j];  // weights past the filter are 0
         acc += __shfl_xor(acc, 1, 64);
         if ((lane & 1) == 0) L.mel[lane >> 1] = acc;
         wave_sync();
@@ -168,8 +212,23 @@ __device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512, c
     __syncthreads();
 }
 
+// Which frames a wave of the persistent front-end kernels takes.  Blocks are dispatched round robin over the 8 XCDs, each
+// with its own L2: dealing frames out by block index makes every XCD touch every utterance (8 x 98 MB of waveform through the
+// fabric per pass at 512 utterances).  Instead XCD x = block % 8 takes the x-th eighth of the frames, its blocks striding
+// through that range -- neighbouring frames (which share 4/5 of their samples) meet in one L2.
+struct AnFrameRange {
+    int first, end, stride;
+};
+__device__ __forceinline__ AnFrameRange an_frame_range(int total, int wid) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    if (nb < 16 || (nb & 7)) return {b * kAnWavesPerBlock + wid, total, nb * kAnWavesPerBlock};
+    const int xcd = b & 7, local = b >> 3, nloc = nb >> 3;
+    const int lo = (int)((long long)total * xcd / 8), hi = (int)((long long)total * (xcd + 1) / 8);
+    return {lo + local * kAnWavesPerBlock + wid, hi, nloc * kAnWavesPerBlock};
+}
+
 template <typename R>
-__global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
+__global__ __launch_bounds__(256, sizeof(R) == 4 ? 3 : 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p, float* __restrict__ feats) {
     __shared__ AnFrameLdsT<R, true> lds[kAnWavesPerBlock];
     __shared__ double2 tw512[256];
@@ -178,13 +237,16 @@ __global__ __launch_bounds__(256, 2) void an_logmel_fwd_kernel(AnTables t, const
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLdsT<R, true>& L = lds[wid];
+    if (lane < 3 + kAnMelLaneBins) L.power[kAnBins + lane] = 0.f;  // the pad the mel taps may reach into (weight 0 there)
+    __shared__ AnLaneTab<true> ltab;
     AnLaneConstT<R> lc;
-    an_lane_init<R, true>(t, lane, lc);
-    const int total = B * F, stride = gridDim.x * kAnWavesPerBlock;
+    an_lane_init<R, true>(t, lane, ltab, lc);
+    __syncthreads();
+    const AnFrameRange fr = an_frame_range(B * F, wid);
     AnRaw cur;  // (a one-frame-ahead prefetch of these 32 registers cost the second wave per SIMD)
-    for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
+    for (int gf = fr.first; gf < fr.end; gf += fr.stride) {
         const int bb = gf / F;
-        an_load_frame(x + (size_t)bb * T, T, gf - bb * F, lane, cur);
+        an_load_frame(x + (size_t)bb * T, T, gf - bb * F, lane, lc.m, cur);
         an_frame_forward<R, true, true>(tw1, tw2, L, lc, cur, scale, lane);
         if (t.spec_cache) {  // packed spectrum for the backward of the same pass (float32 whatever R is)
             float2* sc = t.spec_cache + (size_t)gf * kAnHalf;
@@ -233,7 +295,7 @@ __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>
         wave_sync();
     } else {
         AnRaw cur;
-        an_load_frame(xr, T, f, lane, cur);
+        an_load_frame(xr, T, f, lane, lc.m, cur);
         an_frame_forward<R, !CACHED, POWER>(tw1, tw2, L, lc, cur, scale, lane);
     }
     if (lane < 34) {
@@ -299,7 +361,7 @@ __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>
 // an_frames_to_wave_kernel's).  Instantiations by (R, CACHED, SPEC): the cached ones do not carry the 44 mel-weight
 // registers.
 template <typename R, bool CACHED, bool SPEC>
-__global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
+__global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p,
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
     constexpr bool POWER = !CACHED && !SPEC;
@@ -312,10 +374,13 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLdsT<R, POWER>& L = lds[wid];
+    if (POWER && lane < 3 + kAnMelLaneBins) L.power[kAnBins + lane] = 0.f;
+    __shared__ AnLaneTab<POWER> ltab;
     AnLaneConstT<R> lc;
-    an_lane_init<R, POWER>(t, lane, lc);
-    const int total = B * F, stride = gridDim.x * kAnWavesPerBlock;
-    for (int gf = blockIdx.x * kAnWavesPerBlock + wid; gf < total; gf += stride) {
+    an_lane_init<R, POWER>(t, lane, ltab, lc);
+    __syncthreads();
+    const AnFrameRange fr = an_frame_range(B * F, wid);
+    for (int gf = fr.first; gf < fr.end; gf += fr.stride) {
         const int bb = gf / F;
         an_frame_backward<R, CACHED || SPEC, SPEC, POWER>(t, tw1, tw2, bl, L, lc, x + (size_t)bb * T, T, gf - bb * F, (size_t)gf, scale, dfeats,
                                                           lane);
@@ -326,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void an_logmel_bwd_kernel(AnTables t, const
             const int q = 2 * n - (kAnFft - kAnWin) / 2;  // window index of FFT input 2n (even, since (1024-800)/2 = 112)
             const cx<R> dz = L.spec[SP(n)];
             if (q >= 0 && q < kAnWin)
-                *reinterpret_cast<float2*>(out + q) = make_float2((float)dz.x * lc.win[2 * i], (float)dz.y * lc.win[2 * i + 1]);
+                *reinterpret_cast<float2*>(out + q) = make_float2((float)dz.x * lc.win[64 * (2 * i)], (float)dz.y * lc.win[64 * (2 * i + 1)]);
         }
         wave_sync();
     }
@@ -411,18 +476,26 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
 // Same sums in the same order as the separate pair: same bits (tests/test_gpu_audionet.py).
 // The update reads x_in and writes x_out, two DIFFERENT buffers: a neighbour block still reads the waveform around the cut
 // (its halo frames) while this one writes its positions.
+// frame slots of the ring: a group's position sums read frames g0 - 4 .. g0 + NW - 1.  With 2 NW + 4 slots the next group's
+// frames land in slots nobody reads, so ONE block barrier per group is enough (float, NW = 4: 12 slots); the float64 form
+// (NW = 8, one block per CU) has LDS for NW + 4 slots only and pays a second barrier.
 template <typename R, int NW>
-struct AnOlaLds {  // dynamic LDS of the fused kernel (float, NW = 4: 61 KB, two blocks per CU; double, NW = 8: 139 KB, one)
+constexpr int an_ola_ring() { return sizeof(R) == 4 ? 2 * NW + 4 : NW + 4; }
+
+template <typename R, int NW>
+struct AnOlaLds {  // dynamic LDS of the fused kernel (float, NW = 4: 69 KB, two blocks per CU; double, NW = 8: 129 KB, one)
     AnFrameLdsT<R, false> lds[NW];
     cx<R> tw1[kFftTw1], tw2[kFftTw2];
     AnBinLds bl;
-    __attribute__((aligned(16))) float ring[NW + 4][kAnWin];
-    float dpl[2][NW * kAnHop + 1];
+    AnLaneTab<false> ltab;
+    __attribute__((aligned(16))) float ring[an_ola_ring<R, NW>()][kAnWin];
+    float carry[2];  // d pre of a group's last position, for the first d x of the next group
 };
 
 template <typename R, int NW, bool SPEC>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_kernel(AnTables t, AnOlaArgs a) {
-    constexpr int RING = NW + 4, NPOS = NW * kAnHop;
+    constexpr int RING = an_ola_ring<R, NW>(), NPOS = NW * kAnHop, NT = NW * 64, NJ = (NPOS + NT - 1) / NT;
+    constexpr bool kSecondBarrier = RING < 2 * NW + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char ola_lds_raw[];
     AnOlaLds<R, NW>& S = *reinterpret_cast<AnOlaLds<R, NW>*>(ola_lds_raw);
     auto& lds = S.lds;
@@ -430,19 +503,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_ke
     cx<R>* tw2 = S.tw2;
     AnBinLds& bl = S.bl;
     auto& ring = S.ring;
-    auto& dpl = S.dpl;
     an_stage_bins(t, bl);
     an_stage_tw<R>(t, reinterpret_cast<double2*>(&ring[0][0]), tw1, tw2);  // (the ring is free until the first frame)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
     const float scale = a.scale_p ? *a.scale_p : 1.f;
     AnFrameLdsT<R, false>& L = lds[wid];
     AnLaneConstT<R> lc;
-    an_lane_init<R, false>(t, lane, lc);
+    an_lane_init<R, false>(t, lane, S.ltab, lc);
+    __syncthreads();
     const int b = blockIdx.y, F = a.F, T = a.T, Lp = T - 1;
     const int fa = (int)((long long)F * blockIdx.x / a.S), fb = (int)((long long)F * (blockIdx.x + 1) / a.S);
     const int fs = fa > 5 ? fa - 5 : 0;
     const int q_lo = kAnHop * fa, q_hi = kAnHop * fb;  // own positions q = t + 400; d pre is needed from q_lo - 1
     const float* xr = a.x + (size_t)b * T;
+    // position i = tid + NT j of a group: frame fi past the group's first, sample ri of that frame's first hop
+    int fi[NJ], ri[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = tid + NT * j;
+        fi[j] = i / kAnHop;
+        ri[j] = i - fi[j] * kAnHop;
+    }
+    // sum over the (up to five) frames that cover position q = 160 (g0 + fq) + rq, ascending frames like an_at_pos;
+    // sg0: ring slot of frame g0
+    auto at_q = [&](int g0, int sg0, int fq, int rq) __attribute__((always_inline)) -> float {
+        float g = 0.f;
+#pragma unroll
+        for (int d = 4; d >= 0; --d) {
+            int sl = sg0 + fq - d;
+            sl = sl < 0 ? sl + RING : (sl >= RING ? sl - RING : sl);
+            if (g0 + fq - d >= 0) g += ring[sl][rq + kAnHop * d];
+        }
+        return g;
+    };
     int par = 0;
     for (int g0 = fs; g0 < fb; g0 += NW, par ^= 1) {
         const int f = g0 + wid;
@@ -457,34 +550,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_ke
                 const int q = 2 * n - (kAnFft - kAnWin) / 2;
                 const cx<R> dz = L.spec[SP(n)];
                 if (q >= 0 && q < kAnWin) {
-                    const float2 v = make_float2((float)dz.x * lc.win[2 * i], (float)dz.y * lc.win[2 * i + 1]);
+                    const float2 v = make_float2((float)dz.x * lc.win[64 * (2 * i)], (float)dz.y * lc.win[64 * (2 * i + 1)]);
                     *reinterpret_cast<float2*>(slot + q) = v;
                     if (edge) *reinterpret_cast<float2*>(edge + q) = v;
                 }
             }
         }
         __syncthreads();
-        float* cur = dpl[par];
-        const float* prv = dpl[par ^ 1];
-        for (int i = tid; i < NPOS; i += NW * 64) {
+        const int sg0 = g0 % RING;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = tid + NT * j;
+            if (NPOS % NT != 0 && j == NJ - 1 && i >= NPOS) break;  // (whole waves: NPOS and NT are multiples of 64)
             const int q = kAnHop * g0 + i;
-            float g = 0.f;
-            if (q >= q_lo - 1 && q < q_hi) {
-                const int fhi = q / kAnHop;  // < fb <= F
-                const int flo = q > kAnWin - 1 ? (q - (kAnWin - 1) + kAnHop - 1) / kAnHop : 0;
-                for (int ff = flo; ff <= fhi; ++ff) g += ring[ff % RING][q - ff * kAnHop];
+            const bool need = q >= q_lo - 1 && q < q_hi;
+            const float dp0 = need ? at_q(g0, sg0, fi[j], ri[j]) : 0.f;
+            // d pre of the position before: the lane below holds it; a wave's first lane adds it up itself -- or, for the
+            // group's first position, takes what the previous group left
+            float dpm1 = __shfl_up(dp0, 1);
+            if (lane == 0) {
+                if (i == 0) dpm1 = S.carry[par ^ 1];
+                else if (q - 1 >= q_lo - 1 && q - 1 < q_hi) {
+                    const int i1 = i - 1, f1 = i1 / kAnHop;
+                    dpm1 = at_q(g0, sg0, f1, i1 - f1 * kAnHop);
+                } else dpm1 = 0.f;
             }
-            cur[1 + i] = g;
-        }
-        if (tid == 0) cur[0] = prv[NPOS];  // d pre of the position before the group (unused garbage in a block's first group)
-        __syncthreads();
-        for (int i = tid; i < NPOS; i += NW * 64) {
-            const int q = kAnHop * g0 + i, tt = q - kAnWin / 2;
+            if (i == NPOS - 1) S.carry[par] = dp0;
+            const int tt = q - kAnWin / 2;
             if (q >= q_lo && q < q_hi && tt >= a.t_lo && tt <= a.t_hi) {
-                const float g = an_dx(cur[i], cur[i + 1], tt, Lp, scale);
+                const float g = an_dx(dpm1, dp0, tt, Lp, scale);
                 an_emit(g, (size_t)b * T + tt, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
             }
         }
+        if (kSecondBarrier) __syncthreads();
     }
 }
 
@@ -665,18 +763,23 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
 #undef ATSTAMP
 }
 
+// persistent blocks of the front-end kernels: a multiple of 8 (one share per XCD) once there is work for 16 blocks
+static int an_front_blocks(int frames) {
+    int want = (frames + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
+    if (want > kAnMaxBlocks) want = kAnMaxBlocks;
+    if (want >= 16) want &= ~7;
+    return want;
+}
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 int fft32, hipStream_t s) {
-    const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
-    const dim3 grid(want < kAnMaxBlocks ? want : kAnMaxBlocks);
+    const dim3 grid(an_front_blocks(B * F));
     if (fft32) hipLaunchKernelGGL(an_logmel_fwd_kernel<float>, grid, dim3(256), 0, s, t, x, B, T, F, scale, feats);
     else hipLaunchKernelGGL(an_logmel_fwd_kernel<double>, grid, dim3(256), 0, s, t, x, B, T, F, scale, feats);
     return hipGetLastError();
 }
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
                                 const float* dfeats, float* dframes, int fft32, hipStream_t s) {
-    const int want = (B * F + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
-    const dim3 grid(want < kAnMaxBlocks ? want : kAnMaxBlocks);
+    const dim3 grid(an_front_blocks(B * F));
     const int kind = (t.mel_cache ? 1 : 0) + (t.mel_cache && t.spec_cache ? 2 : 0) + (fft32 ? 4 : 0);
 #define AN_BWD(R, C, SP) hipLaunchKernelGGL((an_logmel_bwd_kernel<R, C, SP>), grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes)
     switch (kind) {
@@ -781,8 +884,8 @@ hipError_t launch_an_tail(const float* act8, int B, int T8, const float* fc_w, c
     if (S < 1 || S > kLossMaxS) return hipErrorInvalidValue;
     // tuning aid: SG_AN_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
     static const bool tr_on = getenv("SG_AN_TAIL_TRACE") != nullptr;
-    static unsigned long long* tr_dev = nullptr;
-    if (tr_on && !tr_dev) (void)hipMalloc(reinterpret_cast<void**>(&tr_dev), 8 * 8);
+    static PerDeviceScratch tr_buf;
+    unsigned long long* tr_dev = tr_on ? static_cast<unsigned long long*>(tr_buf.get(8 * 8)) : nullptr;
     hipLaunchKernelGGL(an_tail_kernel, dim3(B), dim3(256), 0, s, act8, T8, fc_w, fc_b, S, threshold, y, ls, want_grad, emb,
                        scores, decisions, loss, dact8, loss_trace, dec_trace, success, coef_rows, tr_on ? tr_dev : nullptr);
     if (tr_on && tr_dev && hipStreamSynchronize(s) == hipSuccess) {

@@ -27,6 +27,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <atomic>
+
 #include "sg_internal.h"
 
 namespace sg {
@@ -716,29 +718,24 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
     a.S = S;
     a.buf_floats = bf;
     const size_t lds = (size_t)bf * 2 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};  // per device (sg_internal.h: sg_device_slot)
+    const unsigned long long dev_bit = 1ull << sg_device_slot();
+    if (!(attr_mask.load(std::memory_order_relaxed) & dev_bit)) {
         const void* fns[4] = {reinterpret_cast<const void*>(an_cnn_fwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_fwd_kernel<true>),
                               reinterpret_cast<const void*>(an_cnn_bwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true>)};
         for (const void* fn : fns) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        attr_mask.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     // two builds of each kernel (fz_mac): small slices -- three or more per utterance, one 32-row tile per wave -- take the
     // deep W ring, whole / half utterances the compact multiply loop with the straight-path epilogues.  Same bits.
     const bool small = S >= 3;
     static const char* trace_file = getenv("SG_AN_TRACE");  // tuning aid: dump the per-block stage timestamps of every launch
-    static unsigned long long* trace_dev = nullptr;
-    static size_t trace_cap = 0;
+    static PerDeviceScratch trace_buf;
     const size_t nblk = (size_t)S * rows;
-    if (trace_file && trace_cap < nblk) {
-        if (trace_dev) (void)hipFree(trace_dev);
-        (void)hipMalloc(reinterpret_cast<void**>(&trace_dev), nblk * 16 * 8);
-        trace_cap = nblk;
-    }
-    a.trace = trace_file ? trace_dev : nullptr;
+    a.trace = trace_file ? static_cast<unsigned long long*>(trace_buf.get(nblk * 16 * 8)) : nullptr;
     if (a.trace) (void)hipMemsetAsync(a.trace, 0, nblk * 16 * 8, s);
     if (backward) {
         if (small) hipLaunchKernelGGL(an_cnn_bwd_kernel<true>, dim3(S, rows), dim3(kFzThreads), lds, s, a);

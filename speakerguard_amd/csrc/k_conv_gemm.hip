@@ -1469,9 +1469,9 @@ static hipError_t launch_s16(const ConvGemmArgs& a_in, int epi, hipStream_t s) {
     constexpr int R = 6;  // chunks in flight per thread (multiple of 3)
     ConvGemmArgs a = a_in;
     static const bool tr_on = getenv("SG_S16_TRACE") != nullptr;  // tuning aid: cycle split of block 0 (synchronises)
-    static unsigned long long* tr_dev = nullptr;
-    if (tr_on && !tr_dev) (void)hipMalloc(reinterpret_cast<void**>(&tr_dev), 64);
-    a.trace = tr_on ? tr_dev : nullptr;
+    static PerDeviceScratch tr_buf;
+    unsigned long long* tr_dev = tr_on ? static_cast<unsigned long long*>(tr_buf.get(64)) : nullptr;
+    a.trace = tr_dev;
     const int ntile32 = a.N / 32;
     dim3 grid(((a.M + 31) / 32) * ntile32);
 #define SG_S16(EPI) \
@@ -1673,10 +1673,10 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     unsigned epoch = ++launch_counter;
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
     static const char* trace_file = getenv("SG_SK_TRACE");  // tuning aid: dump per-worker phase timestamps
-    static unsigned long long* trace_dev = nullptr;
+    static PerDeviceScratch trace_buf;
+    unsigned long long* trace_dev = trace_file ? static_cast<unsigned long long*>(trace_buf.get((size_t)workers * 16 * 8)) : nullptr;
     ConvGemmArgs at = a;
-    if (trace_file && !trace_dev) (void)hipMalloc(reinterpret_cast<void**>(&trace_dev), (size_t)workers * 16 * 8);
-    at.trace = trace_file ? trace_dev : nullptr;
+    at.trace = trace_dev;
     dim3 grid(workers);
 #define a at
 #define SG_SK(EPI)                                                                                          \
@@ -1736,16 +1736,20 @@ int conv_gemm_tile_rows(int M, int N) {
 }
 
 hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int splits, hipStream_t s) {
+#ifdef SG_EXP_ABLATE  // timing experiments (results become wrong): never in the shipped library
     static const int ablate = [] {
-        const char* e = getenv("SG_ABLATE");  // timing experiments only (results become wrong)
+        const char* e = getenv("SG_ABLATE");
         return e ? atoi(e) : 0;
     }();
+#else
+    constexpr int ablate = 0;
+#endif
     static const int use_streamk = [] {
         const char* e = getenv("SG_STREAMK");  // 0 = always one block per tile
         return e ? atoi(e) : 1;
     }();
     ConvGemmArgs a = a_in;
-    a.ablate = ablate;
+    a.ablate |= ablate;  // (a_in.ablate: the fault-injection bit of sg_debug_lose_handoffs)
     static const int sk_xcd = [] {
         const char* e = getenv("SG_STREAMK_XCD");  // tuning aid, see the kernel
         return e ? atoi(e) : 2;
@@ -1776,7 +1780,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     switch (tile) {
         case 0: {
             if (a.N % 128) return hipErrorInvalidValue;
-            if (splits == 1 && use_streamk && a.force != 1 && a.force != 4) {
+            if (splits == 1 && use_streamk && !a.no_streamk && a.force != 1 && a.force != 4) {
                 const hipError_t e = launch_streamk(a, epi, a.sk_slabs, a.sk_flags, s);
                 if (e != hipErrorNotSupported) return e;
                 if (a.force >= 6) return hipErrorInvalidValue;  // a forced wave-specialised kind never silently becomes a tile launch

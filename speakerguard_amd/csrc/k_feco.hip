@@ -685,11 +685,12 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     static const bool tr_on = getenv("SG_FECO_TRACE") != nullptr;
     if (tr_on) {
-        static bool armed = false;
-        if (!armed) {
+        static bool armed[kMaxDevices] = {};  // the switch is a device symbol: one per device
+        const int dslot = sg_device_slot();
+        if (!armed[dslot]) {
             const int one = 1;
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_trace_on), &one, sizeof(one));
-            armed = true;
+            armed[dslot] = true;
         } else if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
             unsigned long long h[4 * kFecoTraceIters + 4 + 24];
             if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_feco_trace), sizeof(h)) == hipSuccess) {

@@ -287,8 +287,8 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
     // tuning aid: SG_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
     static const bool tr_on = getenv("SG_TAIL_TRACE") != nullptr;
-    static unsigned long long* tr_dev = nullptr;
-    if (tr_on && !tr_dev) (void)hipMalloc(reinterpret_cast<void**>(&tr_dev), 16 * 8);
+    static PerDeviceScratch tr_buf;
+    unsigned long long* tr_dev = tr_on ? static_cast<unsigned long long*>(tr_buf.get(16 * 8)) : nullptr;
     const int grid = a.B < 64 ? 64 : a.B;  // small batches: helper blocks up to one full set of 8 per XCD (see touch_matrices)
     hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(kTailThreads), 0, s, m, a.fc1_part, a.nsplit, a.B, a.y, a.loss, a.want_grad,
                        a.tdnn_emb, a.emb, a.scores, a.decisions, a.loss_out, a.demb, a.loss_trace, a.decision_trace,

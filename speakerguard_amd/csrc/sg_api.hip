@@ -152,10 +152,10 @@ int build_tables(sg_ctx* ctx) {
         br[i] = (uint16_t)r;
     }
     MfccTables& t = ctx->tab;
-    {
-        const char* e = getenv("SG_MFCC_ABLATE");
-        t.ablate = e ? atoi(e) : 0;
-    }
+    t.ablate = 0;
+#ifdef SG_EXP_ABLATE  // timing experiments (results become wrong): never in the shipped library
+    if (const char* e = getenv("SG_MFCC_ABLATE")) t.ablate = atoi(e);
+#endif
     int rc = 0;
     rc |= dev_upload(ctx, ctx->model_allocs, &t.window, window);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_w, melw);
@@ -264,7 +264,7 @@ int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const
     return SG_OK;
 }
 
-ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
+ConvGemmArgs fwd_layer_args(sg_ctx* ctx, int l, int B, int F) {
     const Workspace& w = ctx->ws;
     ConvGemmArgs a{};
     a.A = l == 0 ? w.feats : w.act[l - 1];
@@ -286,10 +286,7 @@ ConvGemmArgs fwd_layer_args(const sg_ctx* ctx, int l, int B, int F) {
     a.total_chunks = a.taps * (a.Kc / 32);
     a.chunks_per_split = a.total_chunks;
     a.split_stride = 0;
-    a.sk_slabs = ctx->sk_slabs;
-    a.sk_flags = ctx->sk_flags;
-    a.err_word = ctx->err_dev;
-    a.num_cus = ctx->num_cus;
+    conv_ctx_args(ctx, a);
     return a;
 }
 
@@ -345,10 +342,7 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.total_chunks = a.taps * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
         a.split_stride = 0;
-        a.sk_slabs = ctx->sk_slabs;
-        a.sk_flags = ctx->sk_flags;
-        a.err_word = ctx->err_dev;
-        a.num_cus = ctx->num_cus;
+        conv_ctx_args(ctx, a);
         int splits = 1;
         if (l == 0) {  // 32 output columns: 148 tiles at B = 64 -- split K per tap to fill the chip
             splits = kL1BwdSplitK;
@@ -498,6 +492,18 @@ int sg_health(sg_ctx* ctx) {
                     "not resident: CU mask or a competing kernel?); results produced since then are invalid. "
                     "SG_STREAMK=0 selects the one-block-per-tile launches");
     }
+    return SG_OK;
+}
+
+int sg_set_streamk(sg_ctx* ctx, int32_t enable) {
+    if (!ctx) return SG_ERR_ARG;
+    ctx->use_streamk = enable != 0;
+    return SG_OK;
+}
+
+int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches) {
+    if (!ctx || launches < 0) return SG_ERR_ARG;
+    ctx->lose_handoffs = launches;
     return SG_OK;
 }
 
@@ -975,7 +981,8 @@ int sg_conv1d_rows(sg_ctx* ctx, const float* a_dev, const float* w_dev, float* c
     a.M = B * Tc; a.N = N; a.Ta = Ta; a.Tc = Tc; a.Kc = Kc; a.lda = Kc; a.ldw = N; a.ldc = N;
     a.taps = taps; a.tap_step = tap_step; a.tap_base = tap_base;
     a.total_chunks = taps * (Kc / 32); a.chunks_per_split = a.total_chunks;
-    a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.err_word = ctx->err_dev; a.num_cus = ctx->num_cus; a.force = kernel;
+    conv_ctx_args(ctx, a);
+    a.force = kernel;
     if (e == hipSuccess) e = launch_conv_gemm(a, 0, epi, 1, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(wq);
@@ -1003,7 +1010,7 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
         a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
         a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];
         a.total_chunks = a.taps * (a.Kc / 32); a.chunks_per_split = a.total_chunks;
-        a.sk_slabs = ctx->sk_slabs; a.sk_flags = ctx->sk_flags; a.err_word = ctx->err_dev; a.num_cus = ctx->num_cus;
+        conv_ctx_args(ctx, a);
         tile = l == 0 ? 1 : 0;
         epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;
         if (l == 0) {

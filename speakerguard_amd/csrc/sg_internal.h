@@ -65,9 +65,10 @@ struct AnTables {            // device pointers
 };
 // how the AudioNet front-end runs (sg_an_configure)
 struct AnFrontCfg {
+    // defaults = the fastest measured combination (profiles/r05_an_frontend_ab.txt)
     int fft32 = 1;       // transforms in float32 (the reference's precision) or float64
-    int spec_cache = 0;  // the forward keeps every frame's packed spectrum for the backward of the same pass
-    int ola = 1;         // overlap-add (+ update) inside the log-mel adjoint
+    int spec_cache = 1;  // the forward keeps every frame's packed spectrum for the backward of the same pass
+    int ola = 0;         // overlap-add (+ update) inside the log-mel adjoint (built and bit-equal; not faster: see DESIGN.md)
 };
 struct AnOlaArgs {
     const float* x;        // (B, T) waveform the frames are re-transformed from (spectrum cache: unused)
@@ -231,6 +232,8 @@ struct sg_ctx {
     // bit into it; every pass entry point and sg_sync read the host side and fail loudly (no synchronisation needed).
     unsigned* err_host = nullptr;
     unsigned* err_dev = nullptr;
+    bool use_streamk = true;         // sg_set_streamk
+    int lose_handoffs = 0;           // sg_debug_lose_handoffs: stream-K launches left that publish no hand-off flags
     sg::AnTables an_tab{};
     sg::AnFrontCfg an_cfg{};
     bool an_tables_ready = false;
@@ -295,13 +298,53 @@ struct ConvGemmArgs {
                         // 4 one quad-fed block per tile, 5 one 16 x 16 block per wave, 6 / 7 / 8 / 9 stream-K with the roles split
                         // between waves, 128- / 64- / 32- / 256-row tiles, 10 = 128-row tiles as four 64 x 64 computing waves
                         // (kind 9) (parity tests)
-    int ablate;         // timing experiments (SG_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier;
-                        // 8 = fault injection: stream-K hand-off flags are never published (health-word test);
-                        // 16 = A/B: agent-scope release / acquire fences around the stream-K hand-off (results stay right)
+    int ablate;         // 8 = fault injection (sg_debug_lose_handoffs): stream-K hand-off flags are never published;
+                        // builds with -DSG_EXP_ABLATE only (never the shipped library), from SG_ABLATE: 1 no global loads,
+                        // 2 no LDS stores, 4 no barrier (results become wrong), 16 = A/B agent-scope fences around the hand-off
+    int no_streamk;     // one block per tile whatever the shape (sg_set_streamk(ctx, 0): same bits, no co-residency needed)
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags
     unsigned* err_word; // stream-K: device-visible health word (bit 0 = a hand-off wait timed out), may be null
 };
+
+// A process may hold one sg_ctx per GPU: whatever a launcher remembers between calls -- the > 64 KB dynamic-LDS opt-in of a
+// kernel, a tuning aid's device buffer -- is remembered PER DEVICE (index = the current device, which every entry point
+// sets from its context before launching).
+constexpr int kMaxDevices = 64;
+inline int sg_device_slot() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & (kMaxDevices - 1);
+}
+// a tuning aid's scratch buffer on the current device (allocated on first use, grown on demand, never freed: tuning aids only)
+struct PerDeviceScratch {
+    void* ptr[kMaxDevices] = {};
+    size_t cap[kMaxDevices] = {};
+    void* get(size_t bytes) {
+        const int d = sg_device_slot();
+        if (cap[d] < bytes) {
+            if (ptr[d]) (void)hipFree(ptr[d]);
+            ptr[d] = nullptr;
+            cap[d] = 0;
+            if (hipMalloc(&ptr[d], bytes) == hipSuccess) cap[d] = bytes;
+        }
+        return ptr[d];
+    }
+};
+
+// the launch-side bookkeeping every contraction of a context carries
+inline void conv_ctx_args(sg_ctx* ctx, ConvGemmArgs& a) {
+    a.sk_slabs = ctx->sk_slabs;
+    a.sk_flags = ctx->sk_flags;
+    a.err_word = ctx->err_dev;
+    a.num_cus = ctx->num_cus;
+    a.no_streamk = ctx->use_streamk ? 0 : 1;
+    a.ablate = 0;
+    if (ctx->lose_handoffs > 0 && ctx->use_streamk) {  // test hook: this launch's stream-K hand-offs get lost
+        a.ablate = 8;
+        --ctx->lose_handoffs;
+    }
+}
 
 // tile: 0 = auto (stream-K 128x128 8-wave blocks when the shape qualifies, else 64x128), 1 = 128x32 (4x1 waves),
 //       2 = 64x128 (2x2 waves), one block per tile

@@ -25,6 +25,10 @@ from ..metric.metric import _context
 
 
 class FeCoDefense:
+    # the reference's `force` flag follows the size of the MODEL CALL (feature_level.py:33: feat.shape[0] > 1): a call with
+    # one utterance drops empty clusters, a larger one fills them in.  Whoever re-cuts a batch (shard.py) must not turn an
+    # utterance of a multi-utterance call into a call of its own, or the other way round.
+    batch_coupled = True
 
     def __init__(self, param=0.5, method='kmeans', other_param='L2', max_iter=10, init='even', seed=0):
         if method != 'kmeans':

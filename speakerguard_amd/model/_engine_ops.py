@@ -74,6 +74,12 @@ class EngineOps:
         stream-K hand-off wait that timed out).  No synchronisation: call it once the results were awaited."""
         self.ctx.call("sg_health")
 
+    def set_streamk(self, enable):
+        """sg_set_streamk: False = every contraction as one block per tile (same bits; no need for all blocks of a launch to
+        be resident at once -- the fallback on a GPU this process does not have to itself)."""
+        self.ctx.call("sg_set_streamk", int(bool(enable)))
+        self.streamk = bool(enable)
+
     def trace_stages(self, fn, max_records=4096):
         """Run fn() with the library's stage trace on (sg_trace_begin / sg_trace_end: a HIP-event pair around every launch
         of the pass sequences, on the launch stream) and return [(stage name, milliseconds)] in launch order.  Measurement

@@ -80,7 +80,7 @@ class audionet_csine(EngineOps):
     def eval(self):
         return self
 
-    def configure_frontend(self, fft_bits=32, spectrum_cache=False, fused_overlap_add=True):
+    def configure_frontend(self, fft_bits=32, spectrum_cache=True, fused_overlap_add=False):
         """How the STFT front-end runs on the engine (sg_an_configure): float32 transforms are the reference's own precision
         (_audionet/Preprocessor.py:100-105); 64 is the float64 form of rounds 1-4, kept as the counterpart."""
         self.ctx.call("sg_an_configure", int(fft_bits), int(bool(spectrum_cache)), int(bool(fused_overlap_add)))

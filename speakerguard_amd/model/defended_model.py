@@ -45,6 +45,11 @@ class defended_model:
     def eval(self):
         return self
 
+    @property
+    def batch_coupled(self):
+        """True if a defense's result depends on how many utterances share a model call (FeCo: feature_level.py:33)."""
+        return any(getattr(method, 'batch_coupled', False) for _, method in (self.defense or []))
+
     def _fwd(self, d, xx):
         """``d.fwd(xx)``; a randomised defense (FeCoDefense(init='random')) takes its generator key from the base
         model's noise bookkeeping (attack call, chunk, call number) instead of its own call counter."""

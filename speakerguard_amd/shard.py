@@ -25,6 +25,11 @@ Batch-coupled details that are preserved by construction rather than by communic
     64 sharded B/G per GPU"; reference attack/PGD.py:62-73 only chunks for memory) -- and a rank runs its shard in
     chunks of ``min(batch_size, shard)``.  Results do not depend on the chunking: per-utterance arithmetic is
     independent of batch composition (bit for bit on the engine), noise is keyed by the global utterance index;
+  * a model with a BATCH-COUPLED defense (FeCo: feature_level.py:33, `force = feat.shape[0] > 1` -- a one-utterance model
+    call drops empty clusters, a larger one fills them in; ``model.batch_coupled``) is cut so that no cut changes which
+    utterances sit alone in a model call: on multiples of ``batch_size`` when there are at least as many chunks as ranks,
+    otherwise inside the chunks with at least two utterances per rank, and a trailing one-utterance chunk of the unsharded
+    run (N mod batch_size == 1) stays a call of its own on the rank that holds it (``coupled_plan``);
   * random restarts draw the FULL (N,1,T) noise from the host RNG on every rank (seed all ranks
     alike) and slice it, so the noise an utterance sees does not depend on the shard layout;
   * device-generated noise (MFCC dither, NES queries, FeCo's random start) is keyed by (seed, attack call, restart,
@@ -60,8 +65,28 @@ def shard_bounds(n, world, granule=1):
     return bounds
 
 
+def coupled_plan(n, world, batch_size):
+    """Per rank the list of [start, end) ranges (each one ``attack`` call) for a model whose defense depends on the number
+    of utterances in a model call (see the module docstring).  The unsharded run makes calls of ``batch_size`` utterances
+    and one of ``n % batch_size``; a call has ONE utterance only if batch_size == 1 or n % batch_size == 1."""
+    bs = max(1, min(batch_size, n))
+    chunks = (n + bs - 1) // bs
+    if bs == 1 or chunks >= world:  # whole chunks per rank: every model call is one of the unsharded run's calls
+        return [[b] if b[1] > b[0] else [] for b in shard_bounds(n, world, bs)]
+    tail = 1 if n % bs == 1 else 0       # the unsharded run's trailing one-utterance call
+    body = n - tail
+    active = max(1, min(world, body // 2))  # ranks that get utterances: at least two each (fewer ranks than chunks: every shard < bs)
+    plan = [[b] if b[1] > b[0] else [] for b in shard_bounds(body, active)] + [[] for _ in range(world - active)]
+    if tail:
+        last = active - 1 if body > 0 else 0
+        plan[last] = plan[last] + [(n - 1, n)]
+    return plan
+
+
 class ShardedAttack:
-    """Wraps any attack object exposing ``attack(x, y) -> (adver_x, success)``."""
+    """Wraps an attack object exposing ``attack(x, y) -> (adver_x, success)``.  An attack class states how its chunks couple
+    their examples through ``chunk_coupling`` (None: not at all, 'mean': through a batch mean, 'chunk': otherwise); a class
+    that does not say is treated as 'chunk' -- cut on multiples of its ``batch_size`` only."""
 
     def __init__(self, attacker, group=None, gather_audio=True):
         self.attacker = attacker
@@ -83,15 +108,17 @@ class ShardedAttack:
         dist.all_gather(parts, pad, group=self.group)
         return torch.cat([p[: e - s] for p, (s, e) in zip(parts, bounds)], 0)
 
-    def _local_attack(self, x, y, lo, hi):
+    def _local_attack(self, x, y, ranges):
+        """This rank's part: one ``attack`` call per range (normally one range; a second one only for the trailing
+        one-utterance call of a batch-coupled model).  Returns (adver of the ranges concatenated, success list)."""
         a = self.attacker
-        a.index_offset = lo  # device-generated noise (dither, NES) is keyed by the GLOBAL chunk position
+        ranges = [r for r in ranges if r[1] > r[0]]
         try:
-            return self._local_attack_at(x, y, lo, hi)
+            return self._local_attack_at(x, y, ranges)
         finally:
             a.index_offset = 0
 
-    def _local_attack_at(self, x, y, lo, hi):
+    def _local_attack_at(self, x, y, ranges):
         a = self.attacker
         restarts = getattr(a, "num_random_init", 0)
         if restarts and restarts > 0:
@@ -105,10 +132,13 @@ class ShardedAttack:
             for init in range(restarts):
                 noise = torch.tensor(np.random.uniform(-a.epsilon, a.epsilon, tuple(x.shape)), device=x.device, dtype=x.dtype)
                 xi = x + noise
-                if hi > lo:
-                    adv, succ = a._run_batches(xi[lo:hi], y[lo:hi], lower[lo:hi], upper[lo:hi], tag=init)
-                else:
-                    adv, succ = xi[lo:hi], []
+                advs, succ = [], []
+                for lo, hi in ranges:
+                    a.index_offset = lo  # device-generated noise (dither, NES) is keyed by the GLOBAL chunk position
+                    adv_r, succ_r = a._run_batches(xi[lo:hi], y[lo:hi], lower[lo:hi], upper[lo:hi], tag=init)
+                    advs.append(adv_r)
+                    succ += succ_r
+                adv = torch.cat(advs, 0) if advs else xi[0:0]
                 cnt = torch.tensor([float(sum(succ))], device=x.device if x.is_cuda else "cpu")
                 if world > 1:
                     dist.all_reduce(cnt, group=self.group)
@@ -116,25 +146,52 @@ class ShardedAttack:
                 if rate > best_rate:
                     best_rate, best = rate, (adv, succ)
             return best
-        if hi > lo:
-            return a.attack(x[lo:hi], y[lo:hi])
-        base = getattr(getattr(a, "model", None), "base_model", getattr(a, "model", None))
-        if hasattr(base, "begin_attack"):  # an empty shard still counts the attack call: noise keys stay aligned over ranks
-            base.begin_attack()
-        return x[lo:hi], []
+        if not ranges:
+            base = getattr(getattr(a, "model", None), "base_model", getattr(a, "model", None))
+            if hasattr(base, "begin_attack"):  # an empty shard still counts the attack call: noise keys stay aligned over ranks
+                base.begin_attack()
+            return x[0:0], []
+        advs, succ = [], []
+        for i, (lo, hi) in enumerate(ranges):
+            a.index_offset = lo
+            if i > 0 and hasattr(a, "_begin_attack"):
+                a._begin_attack = lambda: None  # the rank's ranges are ONE attack call of the unsharded run: counted once
+            try:
+                adv_r, succ_r = a.attack(x[lo:hi], y[lo:hi])
+            finally:
+                if i > 0 and "_begin_attack" in vars(a):
+                    del a._begin_attack
+            advs.append(adv_r)
+            succ += list(succ_r)
+        return torch.cat(advs, 0), succ
 
     def granule(self):
-        """Utterances that must stay together on one rank: 1 unless the attack couples the examples of a chunk
-        through something other than an exchangeable mean (``chunk_coupling == 'chunk'``: FAKEBOB)."""
+        """Utterances that must stay together on one rank: 1 if the attack declares that nothing couples the examples of a
+        chunk (``chunk_coupling = None``: FGSM / PGD / CWinf; 'mean' takes its own path), otherwise -- 'chunk' (FAKEBOB) or an
+        attack object that does not declare anything -- its ``batch_size``."""
         a = self.attacker
-        if getattr(a, "chunk_coupling", None) == "chunk":
-            return max(1, getattr(a, "batch_size", 1))
-        return 1
+        if getattr(a, "chunk_coupling", "chunk") in (None, "mean"):
+            return 1
+        return max(1, getattr(a, "batch_size", 1))
+
+    def _batch_coupled(self):
+        return bool(getattr(getattr(self.attacker, "model", None), "batch_coupled", False))
+
+    def plan(self, n):
+        """Per rank the [start, end) ranges it attacks (each range one ``attack`` call; contiguous and ascending over ranks)."""
+        world, _ = self._world()
+        if self._batch_coupled() and self.granule() == 1:
+            return coupled_plan(n, world, max(1, getattr(self.attacker, "batch_size", 1)))
+        return [[b] if b[1] > b[0] else [] for b in shard_bounds(n, world, self.granule())]
 
     def bounds(self, n):
         """[start, end) of every rank's contiguous shard of a batch of n utterances."""
-        world, _ = self._world()
-        return shard_bounds(n, world, self.granule())
+        out, s = [], 0
+        for ranges in self.plan(n):
+            e = ranges[-1][1] if ranges else s
+            out.append((ranges[0][0] if ranges else s, e))
+            s = e
+        return out
 
     def attack(self, x, y):
         """x (N,1,T), y (N,) identical on every rank -> (adver_x, success list of length N).
@@ -145,9 +202,9 @@ class ShardedAttack:
         n = x.shape[0]
         if world > 1 and getattr(self.attacker, "chunk_coupling", None) == "mean":
             return self._attack_mean_coupled(x, y)
+        plan = self.plan(n)
         bounds = self.bounds(n)
-        lo, hi = bounds[rank]
-        adv, succ = self._local_attack(x, y, lo, hi)
+        adv, succ = self._local_attack(x, y, plan[rank])
         if world == 1:
             return adv, list(succ)
         flags = torch.tensor([bool(s) for s in succ], dtype=torch.uint8, device=x.device)

@@ -306,6 +306,35 @@ int main() {
         fp.k = 4;  // too few clusters for the conv stack
         EXPECT(sg_an_pgd_run_feco(ctx, x.data(), y.data(), lower.data(), upper.data(), B, T, &pp, &fp, succ.data(), dec.data(), sc.data(),
                                   loss.data(), nullptr, nullptr, nullptr) == SG_ERR_ARG);
+        {   // round 5: a SECOND context in the same process (per-context / per-device launcher state), and every
+            // front-end setting of sg_an_configure through the device loops (odd step counts end on the ping-pong twin)
+            sg_ctx* ctx2 = nullptr;
+            EXPECT(sg_create(0, &ctx2) == SG_OK && ctx2 != nullptr && ctx2 != ctx);
+            EXPECT(sg_an_configure(nullptr, 32, 0, 0) == SG_ERR_ARG);
+            EXPECT(sg_an_configure(ctx2, 16, 0, 0) == SG_ERR_ARG);
+            EXPECT(sg_an_load(ctx2, &an.desc) == SG_OK);
+            sg_pgd_params p3 = pp;
+            sg_feco_params f2{};
+            f2.k = Fa / 2; f2.max_iter = 3; f2.random_init = 1; f2.seed = 5;
+            for (int cfg = 0; cfg < 8; ++cfg) {
+                EXPECT(sg_an_configure(ctx2, (cfg & 1) ? 64 : 32, (cfg >> 1) & 1, (cfg >> 2) & 1) == SG_OK);
+                p3.max_iter = 1 + (cfg & 1) + ((cfg >> 2) & 1);
+                EXPECT(sg_an_pgd_run(ctx2, x.data(), y.data(), lower.data(), upper.data(), B, T, &p3, succ.data(), dec.data(), sc.data(),
+                                     loss.data(), nullptr, nullptr, nullptr) == SG_OK);
+                EXPECT(sg_an_loss_grad(ctx2, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+                EXPECT(sg_an_logmel(ctx2, x.data(), B, T, fe.data(), nullptr) == SG_OK);
+                EXPECT(sg_an_logmel_backward(ctx2, x.data(), B, T, fe.data(), grad.data(), 1, nullptr) == SG_OK);
+                EXPECT(sg_an_logmel_backward(ctx2, x.data(), B, T, fe.data(), grad.data(), 0, nullptr) == SG_OK);
+                EXPECT(sg_an_pgd_run_feco(ctx2, x.data(), y.data(), lower.data(), upper.data(), B, T, &p3, &f2, succ.data(), dec.data(),
+                                          sc.data(), loss.data(), nullptr, nullptr, nullptr) == SG_OK);
+            }
+            // the first context is untouched by all that
+            EXPECT(sg_an_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+            EXPECT(sg_set_streamk(nullptr, 0) == SG_ERR_ARG && sg_set_streamk(ctx2, 0) == SG_OK && sg_set_streamk(ctx2, 1) == SG_OK);
+            EXPECT(sg_debug_lose_handoffs(ctx2, -1) == SG_ERR_ARG && sg_debug_lose_handoffs(ctx2, 0) == SG_OK);
+            EXPECT(sg_sync(ctx2, nullptr) == SG_OK);
+            sg_destroy(ctx2);
+        }
         int32_t rows = 0, ch = 0;
         EXPECT(sg_an_debug_activation(ctx, 8, nullptr, 0, &rows, &ch, nullptr) == SG_OK && ch == 32);
         EXPECT(sg_an_debug_activation(ctx, 0, nullptr, 0, &rows, &ch, nullptr) != SG_OK);

@@ -575,3 +575,56 @@ def test_randomised_feco_is_shard_invariant():
         shifted.index_offset = 2  # utterances 0, 1 attacked as "global utterances 2, 3" see other clusterings
         assert not torch.equal(shifted.attack(x[0:2], y[0:2])[0], full[0][0:2])
     log("randomised FeCo (device loop and host-chained loop): halves == full batch bit for bit")
+
+
+def test_sharding_a_feco_defended_model_keeps_single_utterance_calls_where_they_were():
+    """FeCo is batch-coupled -- a model call with ONE utterance drops empty clusters, a larger one fills
+    them in (reference defense/feature_level.py:33).  ShardedAttack therefore never turns an utterance of a multi-utterance
+    call into a call of its own: N = world + 1 = 9 utterances on 8 ranks are 3 + 2 + 2 + 2 (four ranks idle), N = 65 with
+    batch_size 64 keeps the unsharded run's trailing one-utterance call on the last rank; the ranks' results put together
+    are the single-GPU result bit for bit."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    from speakerguard_amd.shard import ShardedAttack
+    hip = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=DEV)
+
+    class OneRank(ShardedAttack):
+        def __init__(self, attacker, world, rank):
+            super().__init__(attacker, gather_audio=True)
+            self.w, self.r = world, rank
+
+        def _world(self):
+            return self.w, self.r
+
+        def _gather_rows(self, local, bounds, n):
+            out = torch.zeros((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            s, e = bounds[self.r]
+            out[s:e] = local[: e - s]
+            return out
+
+    for n, bs, world in ((9, 64, 8), (65, 64, 8), (5, 2, 2)):
+        x = torch.from_numpy(synth.make_waveforms(n, 16000, seed=300 + n)).to(DEV)
+        y = hip.make_decision(x)[0]
+
+        def make():
+            dm = defended_model(hip, defense=[(1, FeCoDefense(0.5, init='random', seed=3))])
+            return PGD(dm, epsilon=0.002, step_size=0.0005, max_iter=2, batch_size=bs, EOT_size=2, EOT_batch_size=2, verbose=0)
+        hip._noise_epoch = 0
+        ref_adv, ref_succ = make().attack(x, y)
+        adv, flags, sizes = torch.zeros_like(ref_adv), [False] * n, []
+        for rank in range(world):
+            hip._noise_epoch = 0
+            atk = make()
+            calls = []
+            inner = atk.attack_batch
+            atk.attack_batch = lambda xb, *a, inner=inner, calls=calls: (calls.append(int(xb.shape[0])), inner(xb, *a))[1]
+            a, f = OneRank(atk, world, rank).attack(x, y)
+            adv += a
+            flags = [p or bool(q) for p, q in zip(flags, f)]
+            sizes.append(calls)
+        assert torch.equal(adv, ref_adv) and flags == [bool(v) for v in ref_succ], (n, bs, world, sizes)
+        log("FeCo-defended AudioNet, %d utterances, batch_size %d, %d emulated ranks: model calls per rank %s == the single-GPU attack bit for bit"
+            % (n, bs, world, sizes))

@@ -393,3 +393,26 @@ def test_config4_fakebob_twenty_iterations_with_early_stop(xv_weights):
     assert len(draws_h) >= 8 and draws_h[0] == 2 and draws_h[-1] == 1, "an early-stop hit during the run, the other voice goes on: %s" % draws_h
     _compare("configs[4] FAKEBOB OSI targeted S=50 x 2 x 3 s, 20 iterations", x, adv, succ, oadv, osucc,
              lambda a: hm.make_decision(a)[0], odec, eps, iters)
+
+
+def test_attack_survives_a_lost_streamk_handoff(xv_weights):
+    """include/speakerguard_hip.h, sg_set_streamk: stream-K needs the GPU to itself; when a hand-off wait times out (here:
+    provoked through the fault-injection hook in the middle of a PGD attack) the attack driver re-runs its batches once as
+    one block per tile -- the same fused multiply-add chains -- and the caller gets the result of an undisturbed run."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.model.xv_plda import xv_plda
+    m = xv_plda.from_weights(xv_weights, device=DEV, dither=0.0)
+    x = torch.from_numpy(synth.make_waveforms(64, 48000, seed=321)).to(DEV)
+    y = m.make_decision(x)[0]
+    kw = dict(task="CSI", epsilon=0.0005, step_size=0.0001, max_iter=3, batch_size=64, verbose=0)
+    clean_adv, clean_succ = PGD(m, **kw).attack(x, y)
+    m.ctx.call("sg_debug_lose_handoffs", 2)  # two contraction launches of the coming attack lose their hand-off flags
+    adv, succ = PGD(m, **kw).attack(x, y)
+    assert getattr(m, "streamk", True) is False, "the driver should have switched stream-K off for the retry"
+    assert torch.equal(adv, clean_adv) and succ == clean_succ
+    m.ctx.call("sg_health")  # nothing pending
+    m.set_streamk(True)
+    adv2, succ2 = PGD(m, **kw).attack(x, y)
+    assert torch.equal(adv2, clean_adv) and succ2 == clean_succ
+    log("PGD-3 x 64 x 3 s with two lost stream-K hand-offs: retried as tile launches, result equal to the undisturbed run (%d/64 fooled)" % sum(succ))

@@ -25,3 +25,34 @@ def test_shard_bounds_partition(n, world, granule):
     if full:
         assert max(full) - min(full) <= granule
     assert sum(sizes) == n
+
+
+def _single_calls(ranges, batch_size):
+    """utterances that end up alone in a model call when every range is attacked in chunks of min(batch_size, range)"""
+    singles = set()
+    for lo, hi in ranges:
+        n = hi - lo
+        if n <= 0:
+            continue
+        bs = min(batch_size, n)
+        for s in range(lo, hi, bs):
+            if min(hi, s + bs) - s == 1:
+                singles.add(s)
+    return singles
+
+
+@settings(max_examples=500, deadline=None)
+@given(n=st.integers(1, 700), world=st.integers(1, 16), batch_size=st.integers(1, 80))
+def test_coupled_plan_never_changes_which_utterances_sit_alone_in_a_model_call(n, world, batch_size):
+    """a batch-coupled defense (FeCo: reference defense/feature_level.py:33, force = feat.shape[0] > 1) treats a
+    one-utterance model call differently; the cut over the ranks must leave alone exactly the utterances the unsharded run
+    leaves alone."""
+    from speakerguard_amd.shard import coupled_plan
+    plan = coupled_plan(n, world, batch_size)
+    assert len(plan) == world
+    flat = [r for ranges in plan for r in ranges]
+    assert flat[0][0] == 0 and flat[-1][1] == n
+    for a, b in zip(flat, flat[1:]):
+        assert a[1] == b[0] and a[0] < a[1]  # contiguous, ascending over the ranks, no empty range
+    assert all(len(ranges) <= 2 for ranges in plan)
+    assert _single_calls(flat, batch_size) == _single_calls([(0, n)], batch_size)
