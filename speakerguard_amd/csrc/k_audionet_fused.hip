@@ -689,9 +689,28 @@ static int fz_plan(const int* Tin, const int* Tout, int Fnet, int rows, int num_
     return 0;
 }
 
+// The kernels ask for up to 160 KB of dynamic LDS (gfx950's per-CU LDS; the Makefile's ARCH is overridable): the opt-in is
+// made once per DEVICE, and a device that refuses it (less LDS) runs the per-layer sequence instead of failing every call.
+static bool fz_device_ok() {
+    static std::atomic<int> state[kMaxDevices];  // 0 unknown, 1 opted in, -1 refused
+    const int d = sg_device_slot();
+    int st = state[d].load(std::memory_order_relaxed);
+    if (st == 0) {
+        const void* fns[4] = {reinterpret_cast<const void*>(an_cnn_fwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_fwd_kernel<true>),
+                              reinterpret_cast<const void*>(an_cnn_bwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true>)};
+        st = 1;
+        for (const void* fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) st = -1;
+        if (st < 0) (void)hipGetLastError();  // the refusal is handled here: the per-layer path runs
+        state[d].store(st, std::memory_order_relaxed);
+    }
+    return st > 0;
+}
+
 bool an_fused_supported(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus) {
     int S, bf;
-    return fz_plan(Tin, Tout, Fnet, rows, num_cus, &S, &bf) == 0;
+    if (rows < 1 || rows > 65535) return false;  // gridDim.y = rows
+    return fz_plan(Tin, Tout, Fnet, rows, num_cus, &S, &bf) == 0 && fz_device_ok();
 }
 
 hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backward, int force_slices, hipStream_t s) {
@@ -718,17 +737,7 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
     a.S = S;
     a.buf_floats = bf;
     const size_t lds = (size_t)bf * 2 * sizeof(float);
-    static std::atomic<unsigned long long> attr_mask{0};  // per device (sg_internal.h: sg_device_slot)
-    const unsigned long long dev_bit = 1ull << sg_device_slot();
-    if (!(attr_mask.load(std::memory_order_relaxed) & dev_bit)) {
-        const void* fns[4] = {reinterpret_cast<const void*>(an_cnn_fwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_fwd_kernel<true>),
-                              reinterpret_cast<const void*>(an_cnn_bwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true>)};
-        for (const void* fn : fns) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        attr_mask.fetch_or(dev_bit, std::memory_order_relaxed);
-    }
+    if (rows > 65535 || !fz_device_ok()) return hipErrorNotSupported;
     // two builds of each kernel (fz_mac): small slices -- three or more per utterance, one 32-row tile per wave -- take the
     // deep W ring, whole / half utterances the compact multiply loop with the straight-path epilogues.  Same bits.
     const bool small = S >= 3;

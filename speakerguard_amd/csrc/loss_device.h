@@ -142,8 +142,10 @@ __device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, i
 
 // The same (maximum, first index holding it) by the whole block: per-thread scan in ascending index order, then merges
 // that prefer the larger value and, among equal values, the lower index -- order-independent, so the result is the serial
-// one whatever the reduction tree (scores are finite; -inf everywhere gives index 0 like the serial scan).  scratch: 2
-// floats per wave.  Ends with a barrier; valid on every thread.
+// one whatever the reduction tree (scores are finite; -inf everywhere gives index 0 like the serial scan).  NaN scores: every
+// comparison with a NaN is false, so a NaN never becomes the maximum, here or in the serial scan, but WHICH finite entry
+// wins can then depend on where the NaNs sit relative to the merge tree -- a pass that produced NaN scores is garbage
+// anyway (sg_xv_loss_grad and the device loops do not try to define it).  scratch: 2 floats per wave.  Ends with a barrier; valid on every thread.
 __device__ __forceinline__ void argmax_block(const float* sc, int S, int tid, int nt, float* scratch, float& mx, int& ja) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;

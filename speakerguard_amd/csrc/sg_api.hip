@@ -1,5 +1,6 @@
 // C-ABI entry points (include/speakerguard_hip.h): context, model load (BatchNorm folding and
 // weight re-layout), workspace, and the kernel sequences of one forward / backward / PGD pass.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -874,6 +875,21 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     // repeats of a step run as several passes (G < reps) every pass leaves its rows here and the last one reduces them
     const bool want_rec = loss_trace_dev || decision_trace_dev;
     if (want_rec && G < reps && w.eot_rows_cap < (size_t)reps * B) {
+        // grown: the old pair is released (nothing enqueued still uses it once the stream has drained), not left in the
+        // workspace's pool until sg_destroy
+        if (w.eot_loss_rows || w.eot_dec_rows) {
+            SG_HIP(hipStreamSynchronize(s));
+            for (void* old : {static_cast<void*>(w.eot_loss_rows), static_cast<void*>(w.eot_dec_rows)}) {
+                auto it = std::find(w.allocs.begin(), w.allocs.end(), old);
+                if (it != w.allocs.end()) {
+                    (void)hipFree(old);
+                    w.allocs.erase(it);
+                }
+            }
+            w.eot_loss_rows = nullptr;
+            w.eot_dec_rows = nullptr;
+            w.eot_rows_cap = 0;
+        }
         if ((rc = dev_alloc(ctx, w.allocs, &w.eot_loss_rows, (size_t)reps * B))) return rc;
         if ((rc = dev_alloc(ctx, w.allocs, &w.eot_dec_rows, (size_t)reps * B))) return rc;
         w.eot_rows_cap = (size_t)reps * B;

@@ -54,7 +54,17 @@ def test_kmeans_ids_bit_exact(hip_model):
              ("logmel-like 2x300x32", torch.from_numpy((rs.randn(2, 300, 32) * 10 - 40).astype(np.float32)), 0.5),
              ("duplicates", torch.from_numpy(np.repeat(rs.randn(1, 20, 8).astype(np.float32), 4, axis=1)), 0.5),
              # 15 s utterance: frames + centroids exceed one block's LDS -> the frames-in-HBM form of the kernel
-             ("long 2x1500x30", torch.from_numpy((rs.randn(2, 1500, 30) * 3).astype(np.float32)), 0.5)]
+             ("long 2x1500x30", torch.from_numpy((rs.randn(2, 1500, 30) * 3).astype(np.float32)), 0.5),
+             # more than 32 dimensions (64-column operands, one centroid row per wave in the update), close to the
+             # longest utterance one block accepts (slow member lists, no merge pass), a mid-size one (frames in LDS, slow lists
+             # or not depending on what fits), few clusters, and an offset far from zero (the centring matters)
+             ("wide 2x200x48", torch.from_numpy((rs.randn(2, 200, 48) * 2).astype(np.float32)), 0.5),
+             ("wide 1x90x64", torch.from_numpy(rs.randn(1, 90, 64).astype(np.float32)), 0.4),
+             ("longest 1x1850x32", torch.from_numpy((rs.randn(1, 1850, 32) * 5 - 30).astype(np.float32)), 0.5),
+             ("mid 2x700x32", torch.from_numpy((rs.randn(2, 700, 32) * 5).astype(np.float32)), 0.5),
+             ("mid 1x1000x20", torch.from_numpy((rs.randn(1, 1000, 20) * 5).astype(np.float32)), 0.25),
+             ("offset 2x300x32", torch.from_numpy((rs.randn(2, 300, 32) * 4 + 300).astype(np.float32)), 0.5),
+             ("few clusters 3x300x32", torch.from_numpy((rs.randn(3, 300, 32) * 4).astype(np.float32)), 0.04)]
     for name, feat, ratio in cases:
         _, ids, counts = _ids(feat, ratio)
         k = int(feat.shape[1] * ratio)
