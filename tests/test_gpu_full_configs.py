@@ -416,3 +416,136 @@ def test_attack_survives_a_lost_streamk_handoff(xv_weights):
     adv2, succ2 = PGD(m, **kw).attack(x, y)
     assert torch.equal(adv2, clean_adv) and succ2 == clean_succ
     log("PGD-3 x 64 x 3 s with two lost stream-K hand-offs: retried as tile launches, result equal to the undisturbed run (%d/64 fooled)" % sum(succ))
+
+
+def test_config3_timed_workload_random_start_eot2():
+    """the configs[3] workload as bench.py times it -- the RANDOMISED defense (every clustering starts from fresh
+    random frames) attacked with EOT 2, 64 utterances x 3 s through the one device loop (sg_an_pgd_run_feco) -- against the
+    oracle loop (reference-pinned AudioNet restatement + oracle.feco + torch autograd, adaptive_attack/EOT.py:16-54) whose
+    clusterings start from the Philox RESTATEMENT of the engine's draws (oracle/philox.py: pass (step it, repeat r) uses key
+    seed + it * 0x9E37.. + r * 0xC2B2.., utterance = global row), the way test_config1_..._default_dither feeds the dither.
+    PGD-5 (the suite's time budget; the bench runs 20 steps of the same loop)."""
+    from oracle import attacks as oatk
+    from oracle import feco, philox
+    from oracle.audionet import AudioNet
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    eps, step, K, B, ratio, R = 0.002, 0.0004, 5, 64, 0.5, 2
+    sd = synth.make_audionet_state_dict(seed=0, num_class=251)
+    hip, ora = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
+
+    class OracleDefended:
+        threshold = -np.inf
+        base_seed, it = 0, 0
+
+        def make_decision(self, xx):
+            feats = ora.compute_feat(xx, flag=1)
+            F = feats.shape[1]
+            k = int(F * ratio)
+            comp = []
+            for row in range(feats.shape[0]):
+                r, u = divmod(row, B)
+                init = philox.feco_random_init(hip.fused_pass_seed(self.base_seed, self.it, r), u, F, k)
+                ids = feco.kmeans_ids(feats[row].detach().numpy(), k, init_frames=init)
+                comp.append(feco.compress_from_ids(feats[row], ids, k, force=True))
+            self.it += 1
+            return ora.make_decision(torch.stack(comp), flag=1)
+
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=3))
+    y = hip.make_decision(x.to(DEV))[0].cpu()  # the undefended model's clean decisions
+    dm, om = defended_model(hip, defense=[(1, FeCoDefense(ratio, init='random', seed=11))]), OracleDefended()
+    atk = PGD(dm, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, EOT_size=R, EOT_batch_size=R, verbose=0)
+    assert atk._fused_feco(B) is not None  # the device loop, not the host-chained one
+    adv, succ = atk.attack(x.to(DEV), y.to(DEV))
+    om.base_seed, om.it = hip.last_fused_seed, 0
+    oadv, osucc = oatk.PGD(om, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, EOT_size=R, EOT_batch_size=R).attack(x, y)
+    succ, osucc = [bool(s) for s in succ], [bool(s) for s in osucc]
+    diff = (adv.cpu() - oadv).abs()
+    frac = float((diff > 1e-7).float().mean())
+    log("configs[3] as timed (random start, EOT %d, PGD-%d x %d x 3 s): success HIP %d/%d oracle %d/%d (equal per utterance: %s); samples "
+        "differing %.2f %%, max |diff| %.6f" % (R, K, B, sum(succ), B, sum(osucc), B, succ == osucc, 100 * frac, diff.max().item()))
+    assert succ == osucc
+    assert 0 < sum(succ) < B, "both outcomes: %d/%d" % (sum(succ), B)
+    assert (adv.cpu() - x).abs().max().item() <= eps + 1e-7
+    assert diff.max().item() <= 2 * eps + 1e-6 and frac <= 0.02 * K
+
+
+def test_config3_pgd100_on_eight_utterances():
+    """BASELINE configs[3] says PGD-100: one hundred sign steps against the FeCo-defended AudioNet (deterministic start) on 8
+    utterances x 3 s, device loop vs oracle.  sign() turns round-off on near-zero gradient entries into +-step flips that
+    feed back, so two float32 implementations drift apart sample by sample; what the hundred steps do to
+    the outcome is bounded here: flags and ids equal, every sample within 2 eps, the fraction of differing samples logged."""
+    from oracle import attacks as oatk
+    from oracle import feco
+    from oracle.audionet import AudioNet
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    from speakerguard_amd.defense.feature_level import FeCoDefense
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    from speakerguard_amd.model.defended_model import defended_model
+    eps, step, K, B, ratio = 0.0004, 0.00001, 100, 8, 0.5
+    sd = synth.make_audionet_state_dict(seed=0, num_class=251)
+    hip, ora = audionet_csine.from_weights(sd, device=DEV), AudioNet(sd)
+
+    class OracleDefended:
+        threshold = -np.inf
+
+        def make_decision(self, xx):
+            feats = ora.compute_feat(xx, flag=1)
+            k = int(feats.shape[1] * ratio)
+            comp = [feco.compress_from_ids(feats[b], feco.kmeans_ids(feats[b].detach().numpy(), k), k, force=True)
+                    for b in range(feats.shape[0])]
+            return ora.make_decision(torch.stack(comp), flag=1)
+
+    x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=3))
+    dm, om = defended_model(hip, defense=[(1, FeCoDefense(ratio))]), OracleDefended()
+    y = dm.make_decision(x.to(DEV))[0].cpu()
+    adv, succ = PGD(dm, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B, verbose=0).attack(x.to(DEV), y.to(DEV))
+    oadv, osucc = oatk.PGD(om, task="CSI", epsilon=eps, step_size=step, max_iter=K, batch_size=B).attack(x, y)
+    succ, osucc = [bool(s) for s in succ], [bool(s) for s in osucc]
+    diff = (adv.cpu() - oadv).abs()
+    frac = float((diff > 1e-7).float().mean())
+    with torch.no_grad():
+        hd, od = dm.make_decision(adv)[0].cpu(), om.make_decision(oadv)[0]
+    log("configs[3] PGD-100 vs FeCo-defended AudioNet x %d x 3 s (eps %g, step %g): success HIP %d/%d oracle %d/%d (equal per utterance: %s); "
+        "ids on own audio equal %d/%d; samples differing %.2f %%, max |diff| %.6f (2 eps = %.6f)"
+        % (B, eps, step, sum(succ), B, sum(osucc), B, succ == osucc, int((hd == od).sum()), B, 100 * frac, diff.max().item(), 2 * eps))
+    assert succ == osucc and hd.tolist() == od.tolist()
+    assert (adv.cpu() - x).abs().max().item() <= eps + 1e-7 and diff.max().item() <= 2 * eps + 1e-6
+
+
+def test_config2_cw2_three_search_steps_both_const_branches(xv_weights):
+    """configs[2] with the outer loop of attack/CW2.py:113-123 at full size: 3 binary-search steps x 8 iterations on 32
+    utterances x 3 s.  After the first step some voices have crossed the threshold (their `const` is bisected towards the lower
+    bound) and some have not (theirs is multiplied by 10): both branches of the update run, on both sides, and the outcomes,
+    ids and perturbation sizes agree with the oracle loop."""
+    from oracle import attacks as oatk
+    from oracle.xv_plda import XvPlda
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.CW2 import CW2
+    from speakerguard_amd.model.xv_plda import xv_plda
+    w = dict(xv_weights)
+    w["enroll"] = xv_weights["enroll"][:1].copy()  # SV: one enrolled speaker
+    x = torch.from_numpy(synth.make_waveforms(32, 48000, seed=35))
+    thr = 55.0
+    om, hm = XvPlda(w, threshold=thr, faithful=False, freeze=True), xv_plda.from_weights(w, threshold=thr, device=DEV, dither=0.0)
+    y = torch.zeros(32, dtype=torch.long)
+    lr, steps, iters = 2e-4, 3, 8
+    kw = dict(task="SV", targeted=True, confidence=0.0, initial_const=1e-2, binary_search_steps=steps, max_iter=iters,
+              stop_early=True, stop_early_iter=4, lr=lr, batch_size=32)
+    oatt, hatt = oatk.CW2(om, **kw), CW2(hm, verbose=0, **kw)
+    oadv, osucc = oatt.attack(x.clone(), y)
+    adv, succ = hatt.attack(x.to(DEV), y.to(DEV))
+    succ, osucc = [bool(a) for a in succ], [bool(a) for a in osucc]
+    d = (adv.cpu() - oadv).abs().numpy()
+    l2h, l2o = (adv.cpu() - x).flatten(1).norm(dim=1), (oadv - x).flatten(1).norm(dim=1)
+    log("configs[2] CW2 targeted SV x 32 x 3 s, %d search steps x %d iterations: success HIP %d/32 oracle %d/32 (equal per utterance: %s); "
+        "max |x_adv - oracle| %.3e; L2 of the perturbation %.4f vs %.4f (per utterance max rel. difference %.3f)"
+        % (steps, iters, sum(succ), sum(osucc), succ == osucc, d.max(), float(l2h.mean()), float(l2o.mean()),
+           float(((l2h - l2o).abs() / l2o.clamp_min(1e-6)).max())))
+    assert succ == osucc and 0 < sum(succ) < 32, "both outcomes: %d/32" % sum(succ)
+    assert hm.make_decision(adv)[0].cpu().tolist() == om.make_decision(oadv)[0].tolist()
+    assert abs(float(l2h.mean()) - float(l2o.mean())) < 0.03 * float(l2o.mean())
