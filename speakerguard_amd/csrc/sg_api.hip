@@ -265,17 +265,6 @@ int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const
     return SG_OK;
 }
 
-// tdnn1 on the 16 x 16 x 4 kernel (round 5 experiment -> see l1_mode): bit 0 forward, bit 1 data gradient as ONE fmaf chain per
-// output (one slab) instead of ten K-slabs summed by the CMVN backward
-int l1_mode() {
-    static const int m = [] {
-        const char* e = getenv("SG_L1_S16");
-        return e ? atoi(e) : 0;
-    }();
-    return m;
-}
-int l1_bwd_slabs() { return (l1_mode() & 2) ? 1 : kL1BwdSplitK; }
-
 ConvGemmArgs fwd_layer_args(sg_ctx* ctx, int l, int B, int F) {
     const Workspace& w = ctx->ws;
     ConvGemmArgs a{};
@@ -306,7 +295,6 @@ int run_tdnn_forward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
     Workspace& w = ctx->ws;
     for (int l = 0; l < kLayers; ++l) {
         ConvGemmArgs a = fwd_layer_args(ctx, l, d.B, d.F);
-        if (l == 0 && (l1_mode() & 1)) a.force = 5;
         SG_STAGE(l + 1, launch_conv_gemm(a, 0, EPI_BIAS_RELU, 1, s));
     }
     SG_STAGE(SG_STAGE_POOL_FWD, launch_pool_fwd(w.act[4], d.B, w.Fl[4], w.stats, s));
@@ -362,9 +350,6 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
             splits = kL1BwdSplitK;
             a.chunks_per_split = a.total_chunks / kL1BwdSplitK;
             a.split_stride = (long long)d.B * d.F * kFeatPad;
-            if (l1_mode() & 2) {
-                tile = 2; splits = 1; a.chunks_per_split = a.total_chunks; a.split_stride = 0; a.force = 5;
-            }
         }
         SG_STAGE(-(l + 1), launch_conv_gemm(a, tile, l == 0 ? EPI_NONE : EPI_RELU_MASK, splits, s));
     }
@@ -418,13 +403,13 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
     int rc = run_tdnn_backward(ctx, d, s);
     if (rc) return rc;
     if (flag == SG_FLAG_CMVN) {
-        SG_HIP(launch_sum_cols(w.dfeats, kFeatPad, l1_bwd_slabs(), (long long)d.B * d.F * kFeatPad, grad_out, kCep,
+        SG_HIP(launch_sum_cols(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep,
                                (int64_t)d.B * d.F, kCep, s));
     } else if (flag == SG_FLAG_RAW) {
-        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, l1_bwd_slabs(), (long long)d.B * d.F * kFeatPad, grad_out, kCep, d.B,
+        SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep, d.B,
                                d.F, s));
     } else {
-        SG_STAGE(SG_STAGE_CMVN_BWD, launch_cmvn_bwd(w.dfeats, kFeatPad, l1_bwd_slabs(), (long long)d.B * d.F * kFeatPad,
+        SG_STAGE(SG_STAGE_CMVN_BWD, launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad,
                                                     w.dfeats_raw, kCep, d.B, d.F, s));
         MfccTables tab = ctx->tab;
         static const bool use_cache = [] {

@@ -23,6 +23,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 XV_FWD_GFLOP, XV_STEP_GFLOP = 2.351, 4.70   # per utterance: forward only / forward + data gradient
 AN_FWD_GFLOP, AN_STEP_GFLOP = 0.078, 0.156  # AudioNet, same source
 T = 48000
+PEAK_HBM_TBS = 8.0  # MI355X_MICROARCH.md
+# AudioNet HBM bytes per utterance and gradient step (3 s, 300 frames; VERDICT r4 item 2d: the AudioNet step is front-end
+# bound, its MFMA fraction alone says little).  MANDATORY = what a fully fused step must move: read x, lower, upper, write x.
+# AS BUILT = every tensor the launch sequence hands from one kernel to the next, once each way: waveform in / bounds / out,
+# log-mel + mel energies (forward -> backward), the packed spectrum cache (300 x 512 complex float32, written and read), the
+# per-frame sample gradients (300 x 800, written and read), the CNN activations the backward masks need (written, read) and
+# the log-mel gradient.
+AN_BYTES_MANDATORY = 4 * T * 4
+AN_BYTES_AS_BUILT = (4 * T * 4 + 2 * 2 * 300 * 32 * 4 + 2 * 300 * 512 * 8 + 2 * 300 * 800 * 4 +
+                     2 * 4 * (300 * 64 + 150 * 64 + 150 * 128 * 3 + 75 * 128 + 75 * 64 + 37 * 64 + 35 * 32 + 300 * 32) + 2 * 300 * 32 * 4)
+
+
+def _hbm(bytes_per_utt_step, utt_steps, seconds):
+    return bytes_per_utt_step * utt_steps / seconds / 1e12 / PEAK_HBM_TBS
 
 
 def _timed(fn, reps):
@@ -66,6 +80,7 @@ def measure(dev, reps=3, xv_weights=None, extras=False):
     out["configs[0]"] = {"workload": "FGSM (1 step + final forward pass) on AudioNet CSI-NE, ONE 3 s utterance, attack() called %d times" % n0,
                          "value": 1e3 * dt / n0, "unit": "ms/attack", "samples": [1e3 * d / n0 for d in dts],
                          "frac_f32_mfma_peak": _frac((AN_STEP_GFLOP + AN_FWD_GFLOP) * n0, dt),
+                         "roofline_hbm": _hbm(AN_BYTES_MANDATORY, n0, dt), "roofline_hbm_as_built": _hbm(AN_BYTES_AS_BUILT, n0, dt),
                          "bound": "launch latency (one utterance: ~40 dependent launches of a few microseconds)"}
 
     # ---- configs[2]: CW2, SV (one enrolled speaker, finite threshold), batch 32
@@ -103,7 +118,8 @@ def measure(dev, reps=3, xv_weights=None, extras=False):
                                      "shard of the batch of 512, ONE device loop (sg_an_pgd_run_feco)" % K,
                          "value": 1e3 * dt / K, "unit": "ms/step", "samples": [1e3 * d / K for d in dts], "success": "%d/64" % sum(succ),
                          "frac_f32_mfma_peak": _frac(g3, dt),
-                         "bound": "VALU (k-means assignment, one CU per utterance and repeat) + latency of ~25 launches per step"}
+                         "roofline_hbm": _hbm(AN_BYTES_MANDATORY, 64 * K, dt), "roofline_hbm_as_built": _hbm(AN_BYTES_AS_BUILT, 64 * K, dt),
+                         "bound": "latency: k-means (one CU per utterance and repeat, ~5 Lloyd iterations of ~15 us) + ~25 launches per step"}
     for b in (64, 512):
         xb = torch.from_numpy(synth.make_waveforms(b, T, seed=5)).to(dev)
         yb = an.make_decision(xb)[0]
@@ -113,7 +129,11 @@ def measure(dev, reps=3, xv_weights=None, extras=False):
         out["audionet_pgd_b%d" % b] = {"workload": "PGD-%d on the undefended AudioNet, %d x 3 s, ONE device loop (sg_an_pgd_run)" % (K, b),
                                        "value": 1e3 * dt / K, "unit": "ms/step", "samples": [1e3 * d / K for d in dts],
                                        "utt_steps_per_s": b * K / dt,
-                                       "frac_f32_mfma_peak": _frac(b * (K * AN_STEP_GFLOP + AN_FWD_GFLOP), dt)}
+                                       "frac_f32_mfma_peak": _frac(b * (K * AN_STEP_GFLOP + AN_FWD_GFLOP), dt),
+                                       "roofline_hbm": _hbm(AN_BYTES_MANDATORY, b * K, dt),
+                                       "roofline_hbm_as_built": _hbm(AN_BYTES_AS_BUILT, b * K, dt),
+                                       "hbm_bytes_per_utt_step": {"mandatory": AN_BYTES_MANDATORY, "as_built": AN_BYTES_AS_BUILT},
+                                       "bound": "front-end VALU + LDS issue (float32 STFT, one wave per frame) and the CNN's per-layer serial parts"}
 
     # ---- configs[4]: FAKEBOB / NES, OSI, samples_per_draw 50
     osi = xv_plda.from_weights(w, threshold=-10.0, device=dev, dither=0.0)
