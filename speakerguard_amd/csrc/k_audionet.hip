@@ -69,11 +69,10 @@ __device__ __forceinline__ void an_lane_offsets(int lane, int (&m)[8]);
 // fills the block's table (all threads; the caller synchronises before the first frame) and the lane's registers
 template <typename R, bool MEL>
 __device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLaneTab<MEL>& tab, AnLaneConstT<R>& lc) {
-    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {
-        const int tap = e >> 6, l = e & 63;
-        const int n = 2 * (l + 64 * (tap >> 1)) + (tap & 1) - (kAnFft - kAnWin) / 2;
-        tab.win[tap][l] = (n >= 0 && n < kAnWin) ? t.window[n] : 0.f;
-    }
+    // the tables arrive laid out per lane (sg_api_audionet.hip an_build_tables): two linear copies
+    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) (&tab.win[0][0])[e] = t.lane_win[e];
+    if constexpr (MEL)
+        for (int e = threadIdx.x; e < kAnMelLaneBins * 64; e += blockDim.x) (&tab.mel_w[0][0])[e] = t.lane_melw[e];
     lc.win = &tab.win[0][lane];
     lc.mel_w = &tab.mel_w[0][lane];
 #pragma unroll
@@ -82,24 +81,7 @@ __device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLane
         lc.wk[i] = cmk<R>((R)w.x, (R)w.y);
     }
     an_lane_offsets(lane, lc.m);
-    lc.mel_k0 = 0;
-    if constexpr (MEL) {
-        auto half_filter = [&](int l, int& k0, int& cnt) {
-            const int m = l >> 1, h = l & 1;
-            const int lo = t.mel_lo[m], hi = t.mel_hi[m];
-            const int mid = lo + (hi - lo + 1) / 2;
-            k0 = h ? mid : lo;
-            cnt = (h ? hi : mid) - k0;
-        };
-        int k0, cnt;
-        half_filter(lane, k0, cnt);
-        lc.mel_k0 = k0;
-        for (int e = threadIdx.x; e < kAnMelLaneBins * 64; e += blockDim.x) {
-            const int j = e >> 6, l = e & 63;
-            half_filter(l, k0, cnt);
-            tab.mel_w[j][l] = j < cnt ? t.mel_w[(l >> 1) * kAnBins + min(k0 + j, kAnBins - 1)] : 0.f;
-        }
-    }
+    lc.mel_k0 = MEL ? t.lane_k0[lane] : 0;
 }
 
 // raw samples of frame f: x[p], x[p + 1] for the 16 FFT inputs of this lane
@@ -202,14 +184,14 @@ __device__ __forceinline__ void an_frame_forward(const cx<R>* tw1, const cx<R>* 
     }
 }
 
-// the 512-point transform's twiddles as its lanes read them (fft512.h: conflict-free tables), from the half circle of
-// W512^i = W1024^(2 i) staged in tw512
+// the 512-point transform's twiddles as its lanes read them (fft512.h: conflict-free tables): laid out and rounded by the
+// host (an_build_tables), copied to LDS
 template <typename R>
-__device__ __forceinline__ void an_stage_tw(const AnTables& t, double2* tw512, cx<R>* tw1, cx<R>* tw2) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) tw512[i] = t.twiddle[2 * i];
-    __syncthreads();
-    fft512_fill_tablesT<R>(tw512, tw1, tw2);
-    __syncthreads();
+__device__ __forceinline__ void an_stage_tw(const AnTables& t, cx<R>* tw1, cx<R>* tw2) {
+    const cx<R>* s1 = sizeof(R) == 4 ? reinterpret_cast<const cx<R>*>(t.tw1f) : reinterpret_cast<const cx<R>*>(t.tw1d);
+    const cx<R>* s2 = sizeof(R) == 4 ? reinterpret_cast<const cx<R>*>(t.tw2f) : reinterpret_cast<const cx<R>*>(t.tw2d);
+    for (int i = threadIdx.x; i < kFftTw1; i += blockDim.x) tw1[i] = s1[i];
+    for (int i = threadIdx.x; i < kFftTw2; i += blockDim.x) tw2[i] = s2[i];
 }
 
 // Which frames a wave of the persistent front-end kernels takes.  Blocks are dispatched round robin over the 8 XCDs, each
@@ -231,9 +213,8 @@ template <typename R>
 __global__ __launch_bounds__(256, sizeof(R) == 4 ? 3 : 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p, float* __restrict__ feats) {
     __shared__ AnFrameLdsT<R, true> lds[kAnWavesPerBlock];
-    __shared__ double2 tw512[256];
     __shared__ cx<R> tw1[kFftTw1], tw2[kFftTw2];
-    an_stage_tw<R>(t, tw512, tw1, tw2);
+    an_stage_tw<R>(t, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLdsT<R, true>& L = lds[wid];
@@ -366,11 +347,10 @@ __global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) vo
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
     constexpr bool POWER = !CACHED && !SPEC;
     __shared__ AnFrameLdsT<R, POWER> lds[kAnWavesPerBlock];
-    __shared__ double2 tw512[256];
     __shared__ cx<R> tw1[kFftTw1], tw2[kFftTw2];
     __shared__ AnBinLds bl;
     an_stage_bins(t, bl);
-    an_stage_tw<R>(t, tw512, tw1, tw2);
+    an_stage_tw<R>(t, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLdsT<R, POWER>& L = lds[wid];
@@ -504,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_ke
     AnBinLds& bl = S.bl;
     auto& ring = S.ring;
     an_stage_bins(t, bl);
-    an_stage_tw<R>(t, reinterpret_cast<double2*>(&ring[0][0]), tw1, tw2);  // (the ring is free until the first frame)
+    an_stage_tw<R>(t, tw1, tw2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
     const float scale = a.scale_p ? *a.scale_p : 1.f;
     AnFrameLdsT<R, false>& L = lds[wid];

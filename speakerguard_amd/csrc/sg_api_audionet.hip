@@ -123,6 +123,46 @@ int an_build_tables(sg_ctx* ctx) {
     rc |= an_upload(ctx, pool, &t.mel_w, melw);
     rc |= an_upload(ctx, pool, &t.mel_lo, lo);
     rc |= an_upload(ctx, pool, &t.mel_hi, hi);
+    {   // the per-lane views of window and filterbank the front-end kernels keep in LDS (k_audionet.hip, AnLaneTab)
+        constexpr int kLaneBins = 44;  // = kAnMelLaneBins
+        std::vector<float> lwin(16 * 64), lmelw((size_t)kLaneBins * 64, 0.f);
+        std::vector<int> lk0(64);
+        for (int tap = 0; tap < 16; ++tap)
+            for (int l = 0; l < 64; ++l) {
+                const int n = 2 * (l + 64 * (tap >> 1)) + (tap & 1) - (kAnFft - kAnWin) / 2;
+                lwin[tap * 64 + l] = (n >= 0 && n < kAnWin) ? window[n] : 0.f;
+            }
+        for (int l = 0; l < 64; ++l) {
+            const int m = l >> 1, h = l & 1;
+            const int mid = lo[m] + (hi[m] - lo[m] + 1) / 2;
+            const int k0 = h ? mid : lo[m], cnt = (h ? hi[m] : mid) - k0;
+            if (cnt > kLaneBins) return an_fail(ctx, SG_ERR_STATE, "half a mel filter spans %d bins (> %d)", cnt, kLaneBins);
+            lk0[l] = k0;
+            for (int j = 0; j < cnt; ++j) lmelw[(size_t)j * 64 + l] = melw[(size_t)m * kAnBins + k0 + j];
+        }
+        rc |= an_upload(ctx, pool, &t.lane_win, lwin);
+        rc |= an_upload(ctx, pool, &t.lane_melw, lmelw);
+        rc |= an_upload(ctx, pool, &t.lane_k0, lk0);
+    }
+    {   // twiddle tables of the 512-point complex transform (W512^m = W1024^(2 m)), as fft512_fill_tables lays them out
+        auto w512 = [&](int m) {
+            const double2 w = tw[(2 * (m & 255)) % (kAnFft / 2)];
+            return (m & 256) ? make_double2(-w.x, -w.y) : w;
+        };
+        std::vector<double2> t1(7 * 64), t2(72);
+        std::vector<float2> t1f(7 * 64), t2f(72);
+        for (int i = 0; i < 7 * 64; ++i) t1[i] = w512((i / 64 + 1) * (i % 64));
+        for (int i = 0; i < 72; ++i) {
+            const int b = i / 9, c = i - 9 * b;
+            t2[i] = c < 8 ? w512(8 * b * c) : make_double2(0.0, 0.0);
+        }
+        for (int i = 0; i < 7 * 64; ++i) t1f[i] = make_float2((float)t1[i].x, (float)t1[i].y);
+        for (int i = 0; i < 72; ++i) t2f[i] = make_float2((float)t2[i].x, (float)t2[i].y);
+        rc |= an_upload(ctx, pool, &t.tw1d, t1);
+        rc |= an_upload(ctx, pool, &t.tw2d, t2);
+        rc |= an_upload(ctx, pool, &t.tw1f, t1f);
+        rc |= an_upload(ctx, pool, &t.tw2f, t2f);
+    }
     rc |= an_upload(ctx, pool, &t.bin_m0, m0);
     rc |= an_upload(ctx, pool, &t.bin_w0, w0);
     rc |= an_upload(ctx, pool, &t.bin_w1, w1);
