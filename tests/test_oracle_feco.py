@@ -62,3 +62,35 @@ def test_compress_from_ids_reproduces_the_reference_run():
     assert z["single_drop_out"].shape[1] == int(z["single_drop_k"]) - 3
     ids = z["mfcc_b3_ids"]
     assert not (ids[1] == 3).any() and np.array_equal(z["mfcc_b3_out"][1, 3], z["mfcc_b3_feat"][1, 3])  # fallback = frame i
+
+
+def _lloyd_float64(x, k, max_iter=10):
+    """Textbook Lloyd iterations in float64 with the contract's start (centroid j = frame floor(j F / k)), stop rule and
+    empty-cluster rule: the literal 'nearest centroid by squared distance'."""
+    x = x.astype(np.float64)
+    F = x.shape[0]
+    c = x[[int(j * F // k) for j in range(k)]].copy()
+    ids = np.full(F, -1)
+    for _ in range(max_iter):
+        d = ((x[:, None, :] - c[None]) ** 2).sum(-1)
+        new = d.argmin(1)
+        if np.array_equal(new, ids):
+            break
+        ids = new
+        for j in range(k):
+            if (ids == j).any():
+                c[j] = x[ids == j].mean(0)
+    return ids
+
+
+def test_contract_version_2_is_the_literal_nearest_centroid_clustering():
+    """Round 5 turned the assignment into a contraction (largest x'.c - |c|^2 / 2 on centred frames instead of the
+    smallest sum of squared differences): on generic data -- no exact ties -- the float32 fmaf-chain scores must pick the
+    centroids the float64 distances pick, also when the features sit far from the origin (log-mel in dB, +300 offset)."""
+    rs = np.random.RandomState(5)
+    for name, x, k in (("randn 120x16", rs.randn(120, 16), 40), ("log-mel-like 300x32", rs.randn(300, 32) * 10 - 40, 150),
+                       ("offset +300", rs.randn(200, 32) * 4 + 300, 100), ("mfcc-like 300x30", rs.randn(300, 30) * [20] + 3, 150),
+                       ("wide 90x64", rs.randn(90, 64), 36)):
+        x = np.asarray(x, dtype=np.float32)
+        got, want = feco.kmeans_ids(x, k), _lloyd_float64(x, k)
+        assert np.array_equal(got, want), "%s: %d of %d ids differ" % (name, int((got != want).sum()), len(got))
