@@ -192,3 +192,59 @@ def test_query_sharded_fakebob_two_rank_gloo_matches_single_process(tmp_path):
             torch.testing.assert_close(got["sc"], ref[1], rtol=1e-5, atol=1e-5)
             torch.testing.assert_close(got["ls"], ref[2], rtol=1e-5, atol=1e-5)
             torch.testing.assert_close(got["g"], ref[3], rtol=1e-4, atol=1e-6)
+
+
+# ---- batch-coupled defense (FeCo, reference defense/feature_level.py:33): a one-utterance model call behaves differently ----
+class _CoupledEngine(AutogradEngine):
+    """CPU stand-in for a FeCo-defended model: a model call that holds ONE utterance scores differently from a larger one
+    (the reference drops empty clusters only when feat.shape[0] == 1)."""
+    batch_coupled = True
+
+    def _md(self, x):
+        dec, sc = super()._md(x)
+        if x.shape[0] == 1:
+            sc = sc * 0.5 + 0.25 * sc.flip(1)
+            dec = torch.argmax(sc, dim=1)
+        return dec, sc
+
+
+def _coupled_worker(rank, world, port, n, bs, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    x, y = _data(n)
+    rec = _Recording(_coupled_attack(bs))
+    adv, succ = ShardedAttack(rec).attack(x, y)
+    chunks = [None] * world
+    dist.all_gather_object(chunks, rec.seen)
+    if rank == 0:
+        torch.save({"adv": adv, "succ": succ, "chunks": chunks}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _coupled_attack(bs):
+    toy = ToyModel().eval()
+    for p in toy.parameters():
+        p.requires_grad_(False)
+    return PGD(_CoupledEngine(toy, per_row=True), epsilon=0.01, step_size=0.002, max_iter=4, batch_size=bs, verbose=0)
+
+
+def test_batch_coupled_model_is_cut_without_new_single_utterance_calls(tmp_path):
+    """with a batch-coupled model the cut must not change which utterances sit alone in a model call
+    (shard.coupled_plan), over real gloo ranks: whole chunks per rank (5 utterances, batch_size 2 / 4 on 2 ranks), a cut inside
+    the one chunk (9 utterances, batch_size 64), and the unsharded run's trailing one-utterance call kept as a second call
+    on the last busy rank with an idle rank behind it (5 utterances, batch_size 4, 3 ranks)."""
+    for n, bs, world, want in ((5, 2, 2, [[2, 2], [1]]), (5, 4, 2, [[4], [1]]), (9, 64, 2, [[5], [4]]), (5, 4, 3, [[2], [2, 1], []])):
+        x, y = _data(n)
+        ref_adv, ref_succ = _coupled_attack(bs).attack(x, y)
+        plain_adv, _ = PGD(AutogradEngine(ToyModel().eval(), per_row=True), epsilon=0.01, step_size=0.002, max_iter=4, batch_size=bs,
+                           verbose=0).attack(x, y)
+        out = str(tmp_path / ("coupled_%d_%d_%d.pt" % (n, bs, world)))
+        mp.spawn(_coupled_worker, args=(world, _free_port(), n, bs, out), nprocs=world, join=True)
+        got = torch.load(out)
+        assert got["chunks"] == want, (n, bs, world, got["chunks"])
+        assert got["succ"] == list(ref_succ) and torch.equal(got["adv"], ref_adv), (n, bs, world)
+        if n % bs == 1:  # the coupling is real: the lone utterance's result differs from the uncoupled model's
+            assert not torch.equal(ref_adv[-1], plain_adv[-1])
