@@ -139,6 +139,9 @@ class FGSM(Attack):
             # batches are run again, once, as one block per tile -- the same bits, no residency requirement.
             if 'hand-off' not in str(e) or not hasattr(base, 'set_streamk') or getattr(base, 'streamk', True) is False:
                 raise
+            import warnings
+            warnings.warn('a stream-K hand-off timed out (is another process using this GPU?): this model now runs its contractions '
+                          'as one block per tile (same results, a few percent slower); model.set_streamk(True) switches back')
             base.set_streamk(False)
             return self._run_batches_once(x, y, lower, upper, tag)
 
