@@ -108,6 +108,26 @@ def test_real_tdnn3_shape_is_the_restated_fmaf_chain(ctx, B, direction):
     assert np.array_equal(got.view(np.uint32), chain.view(np.uint32))
 
 
+@pytest.mark.parametrize("B,F", [(64, 300), (8, 300), (3, 125), (1, 100), (5, 208)])
+def test_real_tdnn1_forward_shape_is_the_restated_fmaf_chain(ctx, B, F):
+    """tdnn1 forward at its real shape (xvecTDNN.py:16-17: 30 -> 512 channels, 5 taps: K = 5 x 32, bias + ReLU epilogue):
+    through the launcher's choice (kernel 0) it must be, bit for bit, the C restatement oracle/conv_chain.c and the generic
+    one-block-per-tile launch (kernel 1), for full batches, a row count that is no multiple of 32 and short utterances.
+    (Round 5 ran this test against a weight-stationary kernel of its own for the layer, which passed it and was dropped for
+    not being faster: profiles/r05_experiments.txt.)"""
+    from oracle.conv_chain import conv_chain
+    Kc, n, taps = 32, 512, 5
+    Ta, Tc = F, F - 4
+    a, w = _case(300 + B, B, Ta, Tc, Kc, n, taps)
+    bias = np.random.RandomState(B).standard_normal(n).astype(np.float32)
+    got = _run(ctx, a, w, B, Ta, Tc, taps, 1, 0, 1, 0, bias=bias)
+    tiles = _run(ctx, a, w, B, Ta, Tc, taps, 1, 0, 1, 1, bias=bias)
+    chain = conv_chain(a, w, B, Ta, Tc, taps, 1, 0, bias=bias)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got.view(np.uint32), tiles.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), chain.view(np.uint32))
+
+
 def test_streamk_slabs_reused_back_to_back(ctx):
     """the stream-K hand-off parks accumulators in slabs that every launch of a context reuses, published by
     write-through (sc1) stores and a relaxed flag -- a stale line would not raise the health word.  Many launches in a
