@@ -443,6 +443,87 @@ __global__ __launch_bounds__(256) void an_frames_to_wave_kernel(const float* __r
     an_emit(g, (size_t)b * T + t, grad_out, x_io, x_io, lower, upper, step, grad_sign);
 }
 
+// Four signal positions per thread (T % 4 == 0).  The one-position kernel above ran at 2.1 TB/s on the 491 MB of a
+// batch-512 step (236 us; 86 % of its wave cycles waiting, r05 PMC): a data-dependent loop of up to 5 dependent scalar
+// loads per thread.  Positions q .. q + 3 with q % 4 == 0 never straddle a frame start (160 f), so all four are covered by
+// the SAME frames q / 160 - 4 .. q / 160: five independent float4 loads, added in ascending frame order like an_at_pos
+// (same bits).  A block whose positions touch what the reflect padding folds back (the first 401 and last ~400 samples)
+// takes the one-position expressions instead.
+constexpr int kAnF2wPerBlock = 1024;
+__global__ __launch_bounds__(256) void an_frames_to_wave4_kernel(const float* __restrict__ dframes, int T, int F,
+                                                                 const float* __restrict__ scale_p,
+                                                                 float* __restrict__ grad_out, float* __restrict__ x_io,
+                                                                 const float* __restrict__ lower,
+                                                                 const float* __restrict__ upper, float step, int grad_sign) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float scale = scale_p ? *scale_p : 1.f;
+    const float* df = dframes + (size_t)b * F * kAnWin;
+    const int Lp = T - 1;
+    __shared__ __attribute__((aligned(16))) float dp[4 + kAnF2wPerBlock];  // dp[3 + i] = d pre[t0 - 1 + i]
+    const int t0 = blockIdx.x * kAnF2wPerBlock, s0 = t0 + 4 * tid;
+    const int pmax = (F - 1) * kAnHop + kAnWin / 2 - 1;
+    const int s_last = t0 + kAnF2wPerBlock - 1;
+    const bool interior = t0 - 1 >= kAnWin / 2 + 1 && s_last <= Lp - 1 && 2 * (Lp - 1) - s_last > pmax;
+    if (interior) {
+        const int q = s0 + kAnWin / 2, k = q / kAnHop, r = q - k * kAnHop;
+        float4 v[5];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            const int f = k - 4 + d;  // >= 0 here: q >= 802
+            v[d] = f <= F - 1 ? *reinterpret_cast<const float4*>(df + (size_t)f * kAnWin + (r + kAnHop * (4 - d)))
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float pre = 0.f;
+        if (tid == 0) pre = an_at_pos(df, F, t0 - 1) + 0.f + 0.f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            if (k - 4 + d <= F - 1) {
+                g.x += v[d].x;
+                g.y += v[d].y;
+                g.z += v[d].z;
+                g.w += v[d].w;
+            }
+        }
+        // an_dpre's two reflection terms are 0.f here; adding them keeps a -0.f sum what the one-position form makes of it
+        g.x = g.x + 0.f + 0.f;
+        g.y = g.y + 0.f + 0.f;
+        g.z = g.z + 0.f + 0.f;
+        g.w = g.w + 0.f + 0.f;
+        *reinterpret_cast<float4*>(&dp[4 + 4 * tid]) = g;
+        if (tid == 0) dp[3] = pre;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sidx = t0 + tid + 256 * j;
+            dp[4 + tid + 256 * j] = sidx <= Lp - 1 ? an_dpre(df, F, Lp, sidx) : 0.f;
+        }
+        if (tid == 0) dp[3] = t0 >= 1 ? an_dpre(df, F, Lp, t0 - 1) : 0.f;
+    }
+    __syncthreads();
+    if (s0 >= T) return;
+    const float4 c = *reinterpret_cast<const float4*>(&dp[4 + 4 * tid]);
+    const float pm1 = dp[3 + 4 * tid];
+    const size_t o = (size_t)b * T + s0;
+    float4 gx;
+    gx.x = an_dx(pm1, c.x, s0, Lp, scale);
+    gx.y = an_dx(c.x, c.y, s0 + 1, Lp, scale);
+    gx.z = an_dx(c.y, c.z, s0 + 2, Lp, scale);
+    gx.w = an_dx(c.z, c.w, s0 + 3, Lp, scale);
+    if (grad_out) *reinterpret_cast<float4*>(grad_out + o) = gx;
+    if (x_io) {
+        const float4 xi = *reinterpret_cast<const float4*>(x_io + o), lo = *reinterpret_cast<const float4*>(lower + o),
+                     up = *reinterpret_cast<const float4*>(upper + o);
+        const float fs = (float)grad_sign;
+        auto upd = [&](float g, float x, float l, float u) {
+            const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+            return fminf(fmaxf(x + step * sg * fs, l), u);
+        };
+        *reinterpret_cast<float4*>(x_io + o) =
+            make_float4(upd(gx.x, xi.x, lo.x, up.x), upd(gx.y, xi.y, lo.y, up.y), upd(gx.z, xi.z, lo.z, up.z), upd(gx.w, xi.w, lo.w, up.w));
+    }
+}
+
 // ---- round 5: the overlap-add INSIDE the adjoint.  The separate pair wrote every frame's 800 gradient samples to HBM and
 // read them back (491 MB each way at 512 utterances: 242 us of an_frames_to_wave_kernel + the write half of the adjoint's
 // 558).  Here a block owns a run of consecutive frames [fa, fb) of ONE utterance and walks it in groups of NW frames (one
@@ -839,8 +920,13 @@ hipError_t launch_an_logmel_bwd_ola(const AnTables& t, AnOlaArgs a, int fft32, i
 hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
                                     float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                     hipStream_t s) {
-    hipLaunchKernelGGL(an_frames_to_wave_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, dframes, T, F, scale, grad_out,
-                       x_io, lower, upper, step, grad_sign);
+    const auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (T % 4 == 0 && al16(dframes) && al16(grad_out) && al16(x_io) && al16(lower) && al16(upper))
+        hipLaunchKernelGGL(an_frames_to_wave4_kernel, dim3((T + kAnF2wPerBlock - 1) / kAnF2wPerBlock, B), dim3(256), 0, s, dframes, T,
+                           F, scale, grad_out, x_io, lower, upper, step, grad_sign);
+    else
+        hipLaunchKernelGGL(an_frames_to_wave_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, dframes, T, F, scale, grad_out,
+                           x_io, lower, upper, step, grad_sign);
     return hipGetLastError();
 }
 hipError_t launch_an_prefilter(const float* in, float* out, int B, int T, const float* w25, float bias, int transpose,
