@@ -17,8 +17,17 @@ template <> struct Cx<float> { using type = float2; };
 template <> struct Cx<double> { using type = double2; };
 template <typename T> using cx = typename Cx<T>::type;
 
+// No implicit contraction in the front-end's arithmetic (round 5): the same per-frame functions are instantiated in five
+// kernels (forward, adjoint with / without the caches, with / without the fused overlap-add) that must give the SAME bits,
+// and what -ffp-contract fuses depends on the code around an expression.  Every fused multiply-add is written out.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T> __device__ __forceinline__ cx<T> cmk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
-template <typename T> __device__ __forceinline__ cx<T> cmulT(cx<T> a, cx<T> b) { return cmk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename T> __device__ __forceinline__ cx<T> cmulT(cx<T> a, cx<T> b) {
+    return cmk<T>(fmaT(a.x, b.x, -(a.y * b.y)), fmaT(a.x, b.y, a.y * b.x));
+}
 template <typename T> __device__ __forceinline__ cx<T> caddT(cx<T> a, cx<T> b) { return cmk<T>(a.x + b.x, a.y + b.y); }
 template <typename T> __device__ __forceinline__ cx<T> csubT(cx<T> a, cx<T> b) { return cmk<T>(a.x - b.x, a.y - b.y); }
 template <typename T> __device__ __forceinline__ cx<T> cconjT(cx<T> a) { return cmk<T>(a.x, -a.y); }
@@ -126,5 +135,63 @@ __device__ __forceinline__ void fft512T_regin(cx<T>* buf, const cx<T>* __restric
     w[0] = v[0]; w[72] = v[1]; w[144] = v[2]; w[216] = v[3]; w[288] = v[4]; w[360] = v[5]; w[432] = v[6]; w[504] = v[7];
     wave_sync();
 }
+
+// registers in (v_j = x[lane + 64 j]), registers out (lane (k1, c) = (lane >> 3, lane & 7): out[d] = X[k1 + 8 c + 64 d] -- "transform
+// order"); the buffer is free again on return
+template <typename T>
+__device__ __forceinline__ void fft512T_regs(cx<T>* buf, const cx<T>* __restrict__ tw1, const cx<T>* __restrict__ tw2, int lane, T sgn,
+                                             const cx<T> (&in)[8], cx<T> (&out)[8]) {
+    fft512_pass1T<T>(buf, tw1, lane, sgn, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7]);
+    fft512_pass2T<T>(buf, tw2, lane, sgn);
+    fft512_pass3T<T>(buf, lane, sgn, out);
+}
+// element k = k1 + 8 c + 64 d of a spectrum kept in transform order sits at 64 d + lane, lane = 8 k1 + c
+__host__ __device__ __forceinline__ int fft512_transform_pos(int k) { return (k & ~63) + 8 * (k & 7) + ((k >> 3) & 7); }
+
+// The TRANSPOSED network (round 5): the three passes run backwards, each one transposed.  The DFT matrix is symmetric, so
+// this is the same transform with the roles of the two layouts swapped: input in transform order (lane (k1, c):
+// v[d] = G[k1 + 8 c + 64 d]), output in natural order (v[j] = g[lane + 64 j]), both in registers.  After a spectrum that
+// was produced in transform order by fft512T_regs, the inverse needs no exchange in front of it and none behind it: two LDS
+// round trips instead of five (the adjoint of the log-mel front-end, k_audionet.hip).
+//   T3: DFT-8 over d -> b, times W64^(b c), to 72 k1 + 9 b + c        (the pass-2 gather pattern, as a scatter)
+//   T2: lane (k1, b) reads c = 0..7, DFT-8 over c -> a, to 72 k1 + 9 a + b  (the pass-2 scatter / gather patterns swapped)
+//   T1: lane n2 reads SP(n2) + 72 k1, times W512^(k1 n2), DFT-8 over k1 -> j
+template <typename T>
+__device__ __forceinline__ void fft512T_transposed(cx<T>* buf, const cx<T>* __restrict__ tw1, const cx<T>* __restrict__ tw2, int lane, T sgn,
+                                                   cx<T> (&v)[8]) {
+    const int k1 = lane >> 3, c = lane & 7;
+    dft8T<T>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], sgn);
+    {
+        const cx<T>* t2 = tw2 + 9 * c;
+        cx<T>* w = buf + k1 * 72 + c;
+        w[0] = v[0];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) w[9 * b] = cmulT<T>(v[b], tw_sgnT<T>(t2[b], sgn));
+    }
+    wave_sync();
+    {
+        const cx<T>* r = buf + k1 * 72 + 9 * c;  // this lane as (k1, b = lane & 7)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r[i];
+    }
+    wave_sync();
+    dft8T<T>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], sgn);
+    {
+        cx<T>* w = buf + k1 * 72 + c;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) w[9 * a] = v[a];
+    }
+    wave_sync();
+    {
+        const cx<T>* p1 = buf + SP(lane);
+        v[0] = p1[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) v[j] = cmulT<T>(p1[72 * j], tw_sgnT<T>(tw1[(j - 1) * 64 + lane], sgn));
+    }
+    wave_sync();
+    dft8T<T>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], sgn);
+}
+
+#pragma clang fp contract(fast)
 
 }  // namespace sg

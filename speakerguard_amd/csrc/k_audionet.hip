@@ -17,13 +17,15 @@ namespace sg {
 constexpr int kAnWavesPerBlock = 4;
 constexpr int kAnMaxBlocks = 768;   // up to 3 blocks per CU x 256 CUs
 constexpr int kAnHalf = kAnFft / 2; // 512: a 1024-point REAL frame is one 512-point complex transform + a split step
-constexpr int kAnMelLaneBins = 44;  // >= bins per half filter (exactly 44 for 32 slaney filters over 513 bins; host-checked)
+constexpr int kAnMelLaneBins = 20;  // bins per lane of the mel stage: a filter's bins in runs of <= 20 (an_build_tables)
 
 __device__ __forceinline__ float an_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+#pragma clang fp contract(off)  // see fft512t.h: every fused multiply-add of the log-mel front-end is written out
 
 // Log-mel front-end, one wave per frame (same recipe as the MFCC kernels, k_mfcc.hip):
 //   * the 1024 real samples x[q] of a frame are packed as z[n] = x[2n] + i x[2n+1] and transformed by ONE 512-point
@@ -41,9 +43,10 @@ __device__ __forceinline__ float an_wave_sum(float v) {
 template <typename R, bool POWER>
 struct AnFrameLdsT {
     cx<R> spec[kAnHalf + kAnHalf / 8];  // element i at SP(i)
-    float power[POWER ? kAnBins + 3 + kAnMelLaneBins : 4];  // bins past 512 stay zero: a lane's 44 taps need no clamp
+    float power[POWER ? kAnBins + 3 + kAnMelLaneBins : 4];  // bins past 512 stay zero: a lane's 20 taps need no clamp
     float mel[32];
     float dmel[36];
+    float part[64];  // the mel stage's per-lane sums
 };
 
 __device__ __forceinline__ int an_reflect(int p, int L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
@@ -54,16 +57,35 @@ __device__ __forceinline__ int an_reflect(int p, int L) { return p < 0 ? -p : (p
 template <bool MEL>
 struct AnLaneTab {
     float win[16][64];                        // [tap of FFT input q = 2 (lane + 64 i) + {0, 1}][lane] (0 outside the 800-tap window)
-    float mel_w[MEL ? kAnMelLaneBins : 1][64];  // [tap][lane]: weights of the lane's half mel filter, ascending bins, zero-padded
+    float mel_w[MEL ? kAnMelLaneBins : 1][64];  // [tap][lane]: weights of the lane's run of mel-filter bins, ascending, zero-padded
 };
 template <typename R>
 struct AnLaneConstT {
     const float* win;         // &tab.win[0][lane]: tap i at win[64 i]
     const float* mel_w;       // &tab.mel_w[0][lane]
-    cx<R> wk[4];              // W^j for this lane's pairs j = lane + 64 i
+    cx<R> c2[4];              // -i W^e / 2 for the lane's pairs in transform order, e = (lane >> 3) + 8 (lane & 7) + 64 d, d < 4
     int m[8];                 // an_lane_offsets
     int mel_k0;
+    int mel_seg;              // lane m < 32: first lane | runs << 8 of filter m
 };
+// Pairs in transform order (round 5).  After fft512T_regs lane l = (k1, c) holds Z[e_d], e_d = k1 + 8 c + 64 d.  The bin that
+// pairs with e_d, 512 - e_d, is element 7 - d of ONE other lane: (8 - k1, 7 - c) = lane 71 - l for l >= 8, lane 8 - l for
+// 1 <= l <= 7 (lane 4 pairs with itself).  Lane 0 holds the multiples of 64 and pairs with itself at 8 - d (d = 0: bins 0 and
+// 512, d = 4: the self-paired bin 256).  So a lane takes the pairs of its elements d = 0..3 (every pair exactly once over the
+// wave) and the partner values cross by ds_bpermute: no LDS buffer, no bank conflicts, half the bytes of a write + read.
+__device__ __forceinline__ int an_partner_lane(int lane) { return lane == 0 ? 0 : (lane < 8 ? 8 - lane : 71 - lane); }
+__device__ __forceinline__ float an_from_lane(int lane4, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(lane4, __float_as_int(v)));
+}
+__device__ __forceinline__ double an_from_lane(int lane4, double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(lane4, (int)(b & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(lane4, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename R>
+__device__ __forceinline__ cx<R> an_from_lane(int lane4, cx<R> v) {
+    return cmk<R>(an_from_lane(lane4, v.x), an_from_lane(lane4, v.y));
+}
 
 __device__ __forceinline__ void an_lane_offsets(int lane, int (&m)[8]);
 // fills the block's table (all threads; the caller synchronises before the first frame) and the lane's registers
@@ -76,12 +98,13 @@ __device__ __forceinline__ void an_lane_init(const AnTables& t, int lane, AnLane
     lc.win = &tab.win[0][lane];
     lc.mel_w = &tab.mel_w[0][lane];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double2 w = t.twiddle[lane + 64 * i];
-        lc.wk[i] = cmk<R>((R)w.x, (R)w.y);
+    for (int d = 0; d < 4; ++d) {
+        const double2 w = t.twiddle[(lane >> 3) + 8 * (lane & 7) + 64 * d];
+        lc.c2[d] = cmk<R>((R)(0.5 * w.y), (R)(-0.5 * w.x));
     }
     an_lane_offsets(lane, lc.m);
     lc.mel_k0 = MEL ? t.lane_k0[lane] : 0;
+    lc.mel_seg = MEL && lane < kAnMel ? t.mel_seg[lane] : 0;
 }
 
 // raw samples of frame f: x[p], x[p + 1] for the 16 FFT inputs of this lane
@@ -125,61 +148,73 @@ __device__ __forceinline__ void an_load_frame(const float* __restrict__ xr, int 
     }
 }
 
-// X[k] and X[512 - k] from the pair (Z[k], Z[512 - k]); w = W^k.  A_k = (1 - i w)/2, B_k = (1 + i w)/2,
-// and W^(512-k) = -conj(W^k).
+// X[k] and X[512 - k] from the pair (Z[k], Z[512 - k]): X[k] = A_k Z[k] + B_k conj(Z[512-k]), A_k = (1 - i W^k)/2,
+// B_k = (1 + i W^k)/2, and W^(512-k) = -conj(W^k) -- with the common factors taken out (round 5: 12 operations, not ~30):
+//   e = (Z[k] + conj Z[512-k]) / 2,  t = c2 (Z[k] - conj Z[512-k]),  c2 = -i W^k / 2:   X[k] = e + t,  X[512-k] = conj(e - t)
 template <typename R>
-__device__ __forceinline__ void an_split(cx<R> zk, cx<R> zr, cx<R> w, cx<R>& xk, cx<R>& xr) {
-    const R half = (R)0.5, one = (R)1;
-    const cx<R> iw = cmk<R>(-w.y, w.x);                       // i w
-    const cx<R> ak = cmk<R>(half * (one - iw.x), -half * iw.y);
-    const cx<R> bk = cmk<R>(half * (one + iw.x), half * iw.y);
-    const cx<R> t0 = cmulT<R>(ak, zk), t1 = cmulT<R>(bk, cconjT<R>(zr));
-    xk = cmk<R>(t0.x + t1.x, t0.y + t1.y);
-    const cx<R> wr = cmk<R>(-w.x, w.y);                       // W^(512-k)
-    const cx<R> iwr = cmk<R>(-wr.y, wr.x);
-    const cx<R> ar = cmk<R>(half * (one - iwr.x), -half * iwr.y);
-    const cx<R> br = cmk<R>(half * (one + iwr.x), half * iwr.y);
-    const cx<R> u0 = cmulT<R>(ar, zr), u1 = cmulT<R>(br, cconjT<R>(zk));
-    xr = cmk<R>(u0.x + u1.x, u0.y + u1.y);
+__device__ __forceinline__ void an_split2(cx<R> zk, cx<R> zr, cx<R> c2, cx<R>& xk, cx<R>& xr) {
+    const R half = (R)0.5;
+    const cx<R> s = cmk<R>(zk.x + zr.x, zk.y - zr.y), d = cmk<R>(zk.x - zr.x, zk.y + zr.y);
+    const cx<R> t = cmulT<R>(c2, d);
+    xk = cmk<R>(fmaT(half, s.x, t.x), fmaT(half, s.y, t.y));
+    xr = cmk<R>(fmaT(half, s.x, -t.x), fmaT(-half, s.y, t.y));
+}
+// ... and its adjoint: from gk = d L / d X[k], gr = d L / d X[512-k] to d L / d Z[k], d L / d Z[512-k]
+//   d e = gk + conj gr,  d t = gk - conj gr:   d Z[k] = d e / 2 + conj(c2) d t,   d Z[512-k] = conj(d e / 2 - conj(c2) d t)
+template <typename R>
+__device__ __forceinline__ void an_split2_adjoint(cx<R> gk, cx<R> gr, cx<R> c2, cx<R>& dzk, cx<R>& dzr) {
+    const R half = (R)0.5;
+    const cx<R> de = cmk<R>(gk.x + gr.x, gk.y - gr.y), dt = cmk<R>(gk.x - gr.x, gk.y + gr.y);
+    const cx<R> gd = cmulT<R>(cconjT<R>(c2), dt);
+    dzk = cmk<R>(fmaT(half, de.x, gd.x), fmaT(half, de.y, gd.y));
+    dzr = cmk<R>(fmaT(half, de.x, -gd.x), fmaT(-half, de.y, gd.y));
 }
 
-// packed spectrum Z of the frame into L.spec (element i at SP(i)); WITH_MEL: power of bins 0..512 into L.power, mel into
-// L.mel (false: only the packed spectrum -- the cached backward takes the mel energies from the forward pass)
+// One frame forward: the packed spectrum Z in TRANSFORM order in z (lane (k1, c): z[d] = Z[k1 + 8 c + 64 d]); WITH_MEL: power
+// of bins 0..512 into L.power, mel into L.mel (false: only the packed spectrum -- the cached backward takes the mel energies
+// from the forward pass)
 template <typename R, bool WITH_MEL, bool POWER>
 __device__ __forceinline__ void an_frame_forward(const cx<R>* tw1, const cx<R>* tw2, AnFrameLdsT<R, POWER>& L, const AnLaneConstT<R>& lc,
-                                                 const AnRaw& r, float scale, int lane) {
+                                                 const AnRaw& r, float scale, int lane, cx<R> (&z)[8]) {
     static_assert(POWER || !WITH_MEL, "the mel energies need the power buffer");
     cx<R> in[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float v0 = (r.b[2 * i] - 0.97f * r.a[2 * i]) * scale * lc.win[64 * (2 * i)];
-        const float v1 = (r.b[2 * i + 1] - 0.97f * r.a[2 * i + 1]) * scale * lc.win[64 * (2 * i + 1)];
+        const float v0 = fmaT(-0.97f, r.a[2 * i], r.b[2 * i]) * scale * lc.win[64 * (2 * i)];
+        const float v1 = fmaT(-0.97f, r.a[2 * i + 1], r.b[2 * i + 1]) * scale * lc.win[64 * (2 * i + 1)];
         in[i] = cmk<R>((R)v0, (R)v1);
     }
-    fft512T_regin<R>(L.spec, tw1, tw2, lane, (R)-1, in);
+    fft512T_regs<R>(L.spec, tw1, tw2, lane, (R)-1, in, z);
     if constexpr (WITH_MEL) {
+        const int e0 = (lane >> 3) + 8 * (lane & 7), p4 = 4 * an_partner_lane(lane);
+        const bool l0 = lane == 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = lane + 64 * i;  // pairs (k, 512 - k), k = 0..255
-            const cx<R> zk = L.spec[SP(k)], zr = L.spec[SP((kAnHalf - k) & (kAnHalf - 1))];
+        for (int d = 0; d < 4; ++d) {
+            // what this lane shows its partner for the partner's pair d: element 7 - d (lane 0, to itself: 8 - d, Z[0] for d = 0)
+            const cx<R> show = l0 ? z[(8 - d) & 7] : z[7 - d];
+            const cx<R> zr = an_from_lane<R>(p4, show);
             cx<R> xk, xr;
-            an_split<R>(zk, zr, lc.wk[i], xk, xr);
-            L.power[k] = (float)(xk.x * xk.x + xk.y * xk.y);
-            L.power[kAnHalf - k] = (float)(xr.x * xr.x + xr.y * xr.y);  // k = 0: X[512] = Re Z[0] - Im Z[0] (split with w = 1)
+            an_split2<R>(z[d], zr, lc.c2[d], xk, xr);
+            L.power[e0 + 64 * d] = (float)fmaT(xk.x, xk.x, xk.y * xk.y);
+            L.power[kAnHalf - e0 - 64 * d] = (float)fmaT(xr.x, xr.x, xr.y * xr.y);  // lane 0, d = 0: X[512] = Re Z[0] - Im Z[0]
         }
-        if (lane == 0) {  // the self-paired bin 256: w = W^256 = -i
-            const cx<R> z = L.spec[SP(256)];
-            cx<R> xk, xr;
-            an_split<R>(z, z, cmk<R>((R)0, (R)-1), xk, xr);
-            L.power[256] = (float)(xk.x * xk.x + xk.y * xk.y);
-        }
+        if (l0) L.power[256] = (float)fmaT(z[4].x, z[4].x, z[4].y * z[4].y);  // the self-paired bin: X[256] = conj Z[256]
         wave_sync();
-        // 32 slaney-mel filters, two lanes per filter (each takes half of the filter's bin range, ascending)
+        // 32 slaney-mel filters: a lane sums one run of <= 20 consecutive bins of one filter (ascending), lane m < 32 the runs
+        // of filter m (ascending)
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < kAnMelLaneBins; ++j) acc += L.power[lc.mel_k0 + j] * lc.mel_w[64 * j];  // weights past the filter are 0
-        acc += __shfl_xor(acc, 1, 64);
-        if ((lane & 1) == 0) L.mel[lane >> 1] = acc;
+        for (int j = 0; j < kAnMelLaneBins; ++j) acc = fmaT(L.power[lc.mel_k0 + j], lc.mel_w[64 * j], acc);  // weights past the run are 0
+        L.part[lane] = acc;
+        wave_sync();
+        if (lane < kAnMel) {
+            const int first = lc.mel_seg & 255, runs = lc.mel_seg >> 8;
+            float m = L.part[first];
+#pragma unroll
+            for (int i = 1; i < 5; ++i)
+                if (i < runs) m += L.part[first + i];
+            L.mel[lane] = m;
+        }
         wave_sync();
     }
 }
@@ -228,14 +263,12 @@ __global__ __launch_bounds__(256, sizeof(R) == 4 ? 3 : 2) void an_logmel_fwd_ker
     for (int gf = fr.first; gf < fr.end; gf += fr.stride) {
         const int bb = gf / F;
         an_load_frame(x + (size_t)bb * T, T, gf - bb * F, lane, lc.m, cur);
-        an_frame_forward<R, true, true>(tw1, tw2, L, lc, cur, scale, lane);
-        if (t.spec_cache) {  // packed spectrum for the backward of the same pass (float32 whatever R is)
-            float2* sc = t.spec_cache + (size_t)gf * kAnHalf;
+        cx<R> z[8];
+        an_frame_forward<R, true, true>(tw1, tw2, L, lc, cur, scale, lane, z);
+        if (t.spec_cache) {  // packed spectrum for the backward of the same pass (float32 whatever R is), in TRANSFORM order
+            float2* sc = t.spec_cache + (size_t)gf * kAnHalf;  // (fft512_transform_pos): straight from the registers
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const cx<R> z = L.spec[SP(lane + 64 * i)];
-                sc[lane + 64 * i] = make_float2((float)z.x, (float)z.y);
-            }
+            for (int d = 0; d < 8; ++d) sc[lane + 64 * d] = make_float2((float)z[d].x, (float)z[d].y);
         }
         if (lane < kAnMel) {
             feats[(size_t)gf * kAnMel + lane] = 10.f * log10f(fmaxf(L.mel[lane], 1e-16f));
@@ -259,25 +292,46 @@ __device__ __forceinline__ void an_stage_bins(const AnTables& t, AnBinLds& bl) {
 }
 
 // One frame of the adjoint: from d loss / d log-mel (32 values of frame gf) to the 512 complex dz[n] = (d x[2n], d x[2n+1])
-// of the frame's 1024 FFT inputs, left in L.spec (element n at SP(n)); the caller multiplies by the window.
-// CACHED: the forward kernel of the same pass left the mel energies in t.mel_cache; SPEC: and the packed spectrum in
-// t.spec_cache (else the frame is transformed again from the waveform row xr).
+// of the frame's 1024 FFT inputs, n = lane + 64 j in dz[j]; the caller multiplies by the window.
+// Entirely in transform order (round 5): a lane takes its four pairs Z[e_d], Z[512 - e_d] (an_partner_lane) -- SPEC: straight
+// from the spectrum cache the forward kernel of the same pass left (any lane can read any address); else from a second
+// forward transform of the waveform row xr, the partner's half by ds_bpermute --, forms d Z for both bins of every pair,
+// hands the partner its half by ds_bpermute and runs the TRANSPOSED inverse transform (fft512T_transposed), which takes
+// transform order in and leaves natural order in registers.  LDS exchanges per frame: the transform's 2; the natural-order
+// form of rounds 3-4 (spectrum to LDS, pair loop in LDS, five exchanges of the inverse, LDS to the window multiply) made 8.
+// CACHED: the mel energies come from t.mel_cache (else from the same second forward pass).
 template <typename R, bool CACHED, bool SPEC, bool POWER>
 __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>* tw1, const cx<R>* tw2, const AnBinLds& bl,
                                                   AnFrameLdsT<R, POWER>& L, const AnLaneConstT<R>& lc, const float* __restrict__ xr, int T,
-                                                  int f, size_t gf, float scale, const float* __restrict__ dfeats, int lane) {
+                                                  int f, size_t gf, float scale, const float* __restrict__ dfeats, int lane,
+                                                  cx<R> (&dz)[8]) {
+    static_assert(CACHED || !SPEC, "the spectrum cache comes with the mel cache");
+    const int e0 = (lane >> 3) + 8 * (lane & 7), pl = an_partner_lane(lane), p4 = 4 * pl;
+    const bool l0 = lane == 0;
+    cx<R> zk[4], zr[4], z4;  // z4: lane 0's Z[256]
     if constexpr (SPEC) {
         const float2* sc = t.spec_cache + gf * kAnHalf;
+        const int z64 = l0 ? 64 : 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float2 z = sc[lane + 64 * i];
-            L.spec[SP(lane + 64 * i)] = cmk<R>((R)z.x, (R)z.y);
+        for (int d = 0; d < 4; ++d) {
+            const float2 a = sc[lane + 64 * d];
+            const float2 b = sc[(pl + 64 * (7 - d) + z64) & (kAnHalf - 1)];  // lane 0: its own element 8 - d (d = 0: Z[0] again)
+            zk[d] = cmk<R>((R)a.x, (R)a.y);
+            zr[d] = cmk<R>((R)b.x, (R)b.y);
         }
-        wave_sync();
+        const float2 c = sc[lane + 64 * 4];
+        z4 = cmk<R>((R)c.x, (R)c.y);
     } else {
         AnRaw cur;
         an_load_frame(xr, T, f, lane, lc.m, cur);
-        an_frame_forward<R, !CACHED, POWER>(tw1, tw2, L, lc, cur, scale, lane);
+        cx<R> z[8];
+        an_frame_forward<R, !CACHED, POWER>(tw1, tw2, L, lc, cur, scale, lane, z);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            zk[d] = z[d];
+            zr[d] = an_from_lane<R>(p4, l0 ? z[(8 - d) & 7] : z[7 - d]);
+        }
+        z4 = z[4];
     }
     if (lane < 34) {
         float dm = 0.f;
@@ -289,57 +343,34 @@ __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>
         L.dmel[lane] = dm;
     }
     wave_sync();
-    // G[k] = 2 X[k] dP[k] for both bins of every pair, folded straight into dZ (in place: a lane owns its pair)
-    auto dpow = [&](int k) {
+    auto dpow = [&](int k) {  // 2 dP[k]: G[k] = 2 X[k] dP[k]
         const int m0 = bl.m0[k];
-        return m0 >= 0 ? (R)2 * (R)(L.dmel[m0] * bl.w0[k] + L.dmel[m0 + 1] * bl.w1[k]) : (R)0;
+        return m0 >= 0 ? (R)2 * (R)fmaT(L.dmel[m0], bl.w0[k], L.dmel[m0 + 1] * bl.w1[k]) : (R)0;
     };
-    const R half = (R)0.5, one = (R)1;
+    cx<R> theirs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = lane + 64 * i;
-        const int kr = (kAnHalf - k) & (kAnHalf - 1);
-        const cx<R> zk = L.spec[SP(k)], zr = L.spec[SP(kr)];
-        const cx<R> w = lc.wk[i];
+    for (int d = 0; d < 4; ++d) {
+        const int k = e0 + 64 * d;
         cx<R> xk, xr2;
-        an_split<R>(zk, zr, w, xk, xr2);
+        an_split2<R>(zk[d], zr[d], lc.c2[d], xk, xr2);
         const R dpk = dpow(k), dpr = dpow(kAnHalf - k);
-        const cx<R> gk = cmk<R>(xk.x * dpk, xk.y * dpk), gr = cmk<R>(xr2.x * dpr, xr2.y * dpr);
-        const cx<R> iw = cmk<R>(-w.y, w.x);
-        const cx<R> ak = cmk<R>(half * (one - iw.x), -half * iw.y), bk = cmk<R>(half * (one + iw.x), half * iw.y);
-        const cx<R> wr = cmk<R>(-w.x, w.y);
-        const cx<R> iwr = cmk<R>(-wr.y, wr.x);
-        const cx<R> ar = cmk<R>(half * (one - iwr.x), -half * iwr.y), br = cmk<R>(half * (one + iwr.x), half * iwr.y);
-        // dZ[k] = conj(A_k) G[k] + B_{512-k} conj(G[512-k]);  dZ[512-k] = conj(A_{512-k}) G[512-k] + B_k conj(G[k])
-        const cx<R> d0 = cmulT<R>(cconjT<R>(ak), gk), d1 = cmulT<R>(br, cconjT<R>(gr));
-        const cx<R> e0 = cmulT<R>(cconjT<R>(ar), gr), e1 = cmulT<R>(bk, cconjT<R>(gk));
-        if (k == 0) {
-            // bins 0 and 512 both fold onto dZ[0]
-            L.spec[SP(0)] = cmk<R>(d0.x + d1.x + e0.x + e1.x, d0.y + d1.y + e0.y + e1.y);
-        } else {
-            L.spec[SP(k)] = cmk<R>(d0.x + d1.x, d0.y + d1.y);
-            L.spec[SP(kr)] = cmk<R>(e0.x + e1.x, e0.y + e1.y);
-        }
+        an_split2_adjoint<R>(cmk<R>(xk.x * dpk, xk.y * dpk), cmk<R>(xr2.x * dpr, xr2.y * dpr), lc.c2[d], dz[d], theirs[d]);
     }
-    wave_sync();
-    if (lane == 0) {  // self-paired bin 256
-        const cx<R> z = L.spec[SP(256)];
-        const cx<R> w = cmk<R>((R)0, (R)-1);
-        cx<R> xk, xr2;
-        an_split<R>(z, z, w, xk, xr2);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dz[7 - d] = an_from_lane<R>(p4, theirs[d]);  // the partner's pair d is this lane's element 7 - d
+    if (l0) {  // lane 0 is its own partner at 8 - d: its pair d belongs at element 8 - d; pair 0 folds bins 0 and 512 onto dz[0]
         const R dp = dpow(256);
-        const cx<R> g = cmk<R>(xk.x * dp, xk.y * dp);
-        const cx<R> iw = cmk<R>(-w.y, w.x);
-        const cx<R> ak = cmk<R>(half * (one - iw.x), -half * iw.y), bk = cmk<R>(half * (one + iw.x), half * iw.y);
-        const cx<R> d0 = cmulT<R>(cconjT<R>(ak), g), d1 = cmulT<R>(bk, cconjT<R>(g));
-        L.spec[SP(256)] = cmk<R>(d0.x + d1.x, d0.y + d1.y);
+        dz[0] = cmk<R>(dz[0].x + theirs[0].x, dz[0].y + theirs[0].y);
+        dz[7] = theirs[1];
+        dz[6] = theirs[2];
+        dz[5] = theirs[3];
+        dz[4] = cmk<R>(z4.x * dp, z4.y * dp);  // the self-paired bin: X[256] = conj Z[256], so d Z[256] = conj(G[256]) = 2 dP Z[256]
     }
-    wave_sync();
-    fft512T<R>(L.spec, tw1, tw2, lane, (R)1);
+    fft512T_transposed<R>(L.spec, tw1, tw2, lane, (R)1, dz);
 }
 
 // dfeats (B,F,32) -> dframes (B,F,800): gradient wrt the pre-emphasised, reflect-padded frame samples (the overlap-add is
-// an_frames_to_wave_kernel's).  Instantiations by (R, CACHED, SPEC): the cached ones do not carry the 44 mel-weight
+// an_frames_to_wave_kernel's).  Instantiations by (R, CACHED, SPEC): the cached ones do not carry the mel-weight
 // registers.
 template <typename R, bool CACHED, bool SPEC>
 __global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
@@ -362,16 +393,17 @@ __global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) vo
     const AnFrameRange fr = an_frame_range(B * F, wid);
     for (int gf = fr.first; gf < fr.end; gf += fr.stride) {
         const int bb = gf / F;
+        cx<R> dzv[8];  // dz[n], n = lane + 64 i
         an_frame_backward<R, CACHED || SPEC, SPEC, POWER>(t, tw1, tw2, bl, L, lc, x + (size_t)bb * T, T, gf - bb * F, (size_t)gf, scale, dfeats,
-                                                          lane);
+                                                          lane, dzv);
         float* out = dframes + (size_t)gf * kAnWin;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = lane + 64 * i;
             const int q = 2 * n - (kAnFft - kAnWin) / 2;  // window index of FFT input 2n (even, since (1024-800)/2 = 112)
-            const cx<R> dz = L.spec[SP(n)];
             if (q >= 0 && q < kAnWin)
-                *reinterpret_cast<float2*>(out + q) = make_float2((float)dz.x * lc.win[64 * (2 * i)], (float)dz.y * lc.win[64 * (2 * i + 1)]);
+                *reinterpret_cast<float2*>(out + q) =
+                    make_float2((float)dzv[i].x * lc.win[64 * (2 * i)], (float)dzv[i].y * lc.win[64 * (2 * i + 1)]);
         }
         wave_sync();
     }
@@ -382,7 +414,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) vo
 __device__ __forceinline__ float an_dx(float dpm1, float dp0, int t, int Lp, float scale) {
     float g = 0.f;
     if (t >= 1) g += dpm1;
-    if (t <= Lp - 1) g -= 0.97f * dp0;
+    if (t <= Lp - 1) g = fmaT(-0.97f, dp0, g);
     return g * scale;
 }
 __device__ __forceinline__ void an_emit(float g, size_t o, float* __restrict__ grad_out, const float* __restrict__ x_in,
@@ -602,14 +634,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_ke
         const int f = g0 + wid;
         if (f < fb) {
             const size_t gf = (size_t)b * F + f;
-            an_frame_backward<R, true, SPEC, false>(t, tw1, tw2, bl, L, lc, xr, T, f, gf, scale, a.dfeats, lane);
+            cx<R> dzv[8];  // dz[n], n = lane + 64 i (the same expressions as an_logmel_bwd_kernel: same bits)
+            an_frame_backward<R, true, SPEC, false>(t, tw1, tw2, bl, L, lc, xr, T, f, gf, scale, a.dfeats, lane, dzv);
             float* slot = ring[f % RING];
             float* edge = (f >= fa && (f < a.edge_lo || f >= a.edge_hi)) ? a.dframes + gf * kAnWin : nullptr;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int n = lane + 64 * i;
                 const int q = 2 * n - (kAnFft - kAnWin) / 2;
-                const cx<R> dz = L.spec[SP(n)];
+                const cx<R> dz = dzv[i];
                 if (q >= 0 && q < kAnWin) {
                     const float2 v = make_float2((float)dz.x * lc.win[64 * (2 * i)], (float)dz.y * lc.win[64 * (2 * i + 1)]);
                     *reinterpret_cast<float2*>(slot + q) = v;
@@ -661,6 +694,7 @@ __global__ __launch_bounds__(256) void an_edge_to_wave_kernel(AnOlaArgs a) {
     const float g = an_dx(dpm1, dp0, t, Lp, scale);
     an_emit(g, (size_t)b * a.T + t, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
 }
+#pragma clang fp contract(fast)  // end of the log-mel front-end
 
 // ---------------------------------------------------------------- 5x5 pre-filter over (time, mel)
 // out[t][m] = b + sum_{i,j} w[i][j] in[t + j - 2][m + i - 2]   (Conv2d on the (mel, time) image, zero pad)

@@ -124,22 +124,30 @@ int an_build_tables(sg_ctx* ctx) {
     rc |= an_upload(ctx, pool, &t.mel_lo, lo);
     rc |= an_upload(ctx, pool, &t.mel_hi, hi);
     {   // the per-lane views of window and filterbank the front-end kernels keep in LDS (k_audionet.hip, AnLaneTab)
-        constexpr int kLaneBins = 44;  // = kAnMelLaneBins
+        // mel: every filter is cut into ceil(width / 20) runs of consecutive bins of (nearly) equal length, one lane per run
+        // (971 filter taps over 63 lanes, <= 20 each; the two-lanes-per-filter split of rounds 3-4 was bound by its widest
+        // half, 44 taps, 64 % of them zero padding).  mel_seg[m] = first lane | runs << 8: lane m adds the runs' sums up in
+        // ascending order.
+        constexpr int kLaneBins = 20;  // = kAnMelLaneBins
         std::vector<float> lwin(16 * 64), lmelw((size_t)kLaneBins * 64, 0.f);
-        std::vector<int> lk0(64);
+        std::vector<int> lk0(64, 0), seg(kAnMel, 0);
         for (int tap = 0; tap < 16; ++tap)
             for (int l = 0; l < 64; ++l) {
                 const int n = 2 * (l + 64 * (tap >> 1)) + (tap & 1) - (kAnFft - kAnWin) / 2;
                 lwin[tap * 64 + l] = (n >= 0 && n < kAnWin) ? window[n] : 0.f;
             }
-        for (int l = 0; l < 64; ++l) {
-            const int m = l >> 1, h = l & 1;
-            const int mid = lo[m] + (hi[m] - lo[m] + 1) / 2;
-            const int k0 = h ? mid : lo[m], cnt = (h ? hi[m] : mid) - k0;
-            if (cnt > kLaneBins) return an_fail(ctx, SG_ERR_STATE, "half a mel filter spans %d bins (> %d)", cnt, kLaneBins);
-            lk0[l] = k0;
-            for (int j = 0; j < cnt; ++j) lmelw[(size_t)j * 64 + l] = melw[(size_t)m * kAnBins + k0 + j];
+        int lanes = 0;
+        for (int m = 0; m < kAnMel; ++m) {
+            const int w = hi[m] - lo[m], runs = w > 0 ? (w + kLaneBins - 1) / kLaneBins : 1;
+            if (lanes + runs > 64 || runs > 5) return an_fail(ctx, SG_ERR_STATE, "mel filterbank needs more than 64 runs of %d bins", kLaneBins);
+            seg[m] = lanes | (runs << 8);
+            for (int i = 0; i < runs; ++i, ++lanes) {
+                const int k0 = lo[m] + (int)((long long)w * i / runs), k1 = lo[m] + (int)((long long)w * (i + 1) / runs);
+                lk0[lanes] = k0;
+                for (int j = 0; j < k1 - k0; ++j) lmelw[(size_t)j * 64 + lanes] = melw[(size_t)m * kAnBins + k0 + j];
+            }
         }
+        rc |= an_upload(ctx, pool, &t.mel_seg, seg);
         rc |= an_upload(ctx, pool, &t.lane_win, lwin);
         rc |= an_upload(ctx, pool, &t.lane_melw, lmelw);
         rc |= an_upload(ctx, pool, &t.lane_k0, lk0);

@@ -64,8 +64,9 @@ struct AnTables {            // device pointers
     float2* spec_cache;      // [B*F][512] packed spectrum Z of every frame, same hand-over (null: the backward transforms again)
     // what a block's waves read lane by lane (k_audionet.hip AnLaneTab), laid out by the host: a block copies them to LDS
     float* lane_win;         // [16][64] window tap of FFT input 2 (lane + 64 i) + {0, 1} (0 outside the 800-tap window)
-    float* lane_melw;        // [44][64] weights of the lane's half mel filter, ascending bins, zero-padded
-    int* lane_k0;            // [64] first bin of the lane's half filter
+    float* lane_melw;        // [20][64] weights of the lane's run of a mel filter's bins, ascending, zero-padded
+    int* lane_k0;            // [64] first bin of the lane's run
+    int* mel_seg;            // [32] filter m: first lane | number of runs << 8 (an_build_tables)
     // the 512-point transform's twiddle tables as its lanes read them (fft512.h: tw1[(j - 1) * 64 + lane] = W512^(j lane),
     // tw2[9 b + c] = W64^(b c)), float64 values and the same rounded once to float32
     double2* tw1d;           // [448]
