@@ -292,13 +292,15 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
  * or shape differ, the forward is recomputed. */
 int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* dfeats_dev, float* grad_dev,
                           int32_t reuse_forward, void* stream);
-/* How the log-mel front-end and its adjoint run on this context (round 5; defaults 32, 1, 0 = the fastest measured):
+/* How the log-mel front-end and its adjoint run on this context (round 5; defaults 32, 1, -1 = the fastest measured):
  *   fft_bits 32 | 64: the scalar type of the STFT's transforms.  The reference computes its STFT in float32
  *     (model/_audionet/Preprocessor.py:100-105, torch.stft on a float32 signal); 64 is the form of rounds 1-4.
  *   spectrum_cache: the forward of a pass keeps every frame's packed spectrum (B x F x 4 KB) for the backward of the same
  *     pass instead of the backward transforming the frame again.
  *   fused_overlap_add: the adjoint adds the frames' gradients up on chip (and applies the attack's update there) instead
- *     of writing B x F x 800 floats for a second kernel; same sums in the same order, same bits.
+ *     of writing B x F x 800 floats for a second kernel; same sums in the same order, same bits.  1 / 0, or -1: the
+ *     library decides per call from the batch (the fused form cuts utterances into runs with 5 halo frames each and pays
+ *     from ~200 utterances of 3 s; below that the separate pair is faster).
  * Takes effect from the next pass; results of the two transform precisions differ by float32 round-off. */
 int sg_an_configure(sg_ctx* ctx, int32_t fft_bits, int32_t spectrum_cache, int32_t fused_overlap_add);
 /* audionet_csine.make_decision / score / embedding (:149-257): decisions (B), scores (B,num_class), emb (B,32) */

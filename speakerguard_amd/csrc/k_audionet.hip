@@ -15,7 +15,7 @@
 namespace sg {
 
 constexpr int kAnWavesPerBlock = 4;
-constexpr int kAnMaxBlocks = 768;   // up to 3 blocks per CU x 256 CUs
+constexpr int kAnCus = 256;
 constexpr int kAnHalf = kAnFft / 2; // 512: a 1024-point REAL frame is one 512-point complex transform + a split step
 constexpr int kAnMelLaneBins = 20;  // bins per lane of the mel stage: a filter's bins in runs of <= 20 (an_build_tables)
 
@@ -42,11 +42,15 @@ __device__ __forceinline__ float an_wave_sum(float v) {
 // bound by; double: the form of rounds 1-4 (sg_an_configure).  Twiddles are float64 values rounded once in both.
 template <typename R, bool POWER>
 struct AnFrameLdsT {
-    cx<R> spec[kAnHalf + kAnHalf / 8];  // element i at SP(i)
-    float power[POWER ? kAnBins + 3 + kAnMelLaneBins : 4];  // bins past 512 stay zero: a lane's 20 taps need no clamp
-    float mel[32];
+    union {
+        cx<R> spec[kAnHalf + kAnHalf / 8];  // the transform's exchange buffer, element i at SP(i)
+        // the power spectrum shares it (the transform is done with the buffer when the powers are written: 4 blocks per CU
+        // instead of 3); bins past 512 are zeroed every frame: a lane's 20 mel taps need no clamp
+        float power[POWER ? kAnBins + 3 + kAnMelLaneBins : 4];
+    };
+    float mel[POWER ? 32 : 1];
     float dmel[36];
-    float part[64];  // the mel stage's per-lane sums
+    float part[POWER ? 64 : 1];  // the mel stage's per-lane sums
 };
 
 __device__ __forceinline__ int an_reflect(int p, int L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
@@ -199,6 +203,7 @@ __device__ __forceinline__ void an_frame_forward(const cx<R>* tw1, const cx<R>* 
             L.power[kAnHalf - e0 - 64 * d] = (float)fmaT(xr.x, xr.x, xr.y * xr.y);  // lane 0, d = 0: X[512] = Re Z[0] - Im Z[0]
         }
         if (l0) L.power[256] = (float)fmaT(z[4].x, z[4].x, z[4].y * z[4].y);  // the self-paired bin: X[256] = conj Z[256]
+        if (lane < 3 + kAnMelLaneBins) L.power[kAnBins + lane] = 0.f;  // the pad the mel taps may reach into (weight 0 there)
         wave_sync();
         // 32 slaney-mel filters: a lane sums one run of <= 20 consecutive bins of one filter (ascending), lane m < 32 the runs
         // of filter m (ascending)
@@ -245,7 +250,7 @@ __device__ __forceinline__ AnFrameRange an_frame_range(int total, int wid) {
 }
 
 template <typename R>
-__global__ __launch_bounds__(256, sizeof(R) == 4 ? 3 : 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
+__global__ __launch_bounds__(256, sizeof(R) == 4 ? 4 : 2) void an_logmel_fwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p, float* __restrict__ feats) {
     __shared__ AnFrameLdsT<R, true> lds[kAnWavesPerBlock];
     __shared__ cx<R> tw1[kFftTw1], tw2[kFftTw2];
@@ -253,7 +258,6 @@ __global__ __launch_bounds__(256, sizeof(R) == 4 ? 3 : 2) void an_logmel_fwd_ker
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLdsT<R, true>& L = lds[wid];
-    if (lane < 3 + kAnMelLaneBins) L.power[kAnBins + lane] = 0.f;  // the pad the mel taps may reach into (weight 0 there)
     __shared__ AnLaneTab<true> ltab;
     AnLaneConstT<R> lc;
     an_lane_init<R, true>(t, lane, ltab, lc);
@@ -300,27 +304,45 @@ __device__ __forceinline__ void an_stage_bins(const AnTables& t, AnBinLds& bl) {
 // transform order in and leaves natural order in registers.  LDS exchanges per frame: the transform's 2; the natural-order
 // form of rounds 3-4 (spectrum to LDS, pair loop in LDS, five exchanges of the inverse, LDS to the window multiply) made 8.
 // CACHED: the mel energies come from t.mel_cache (else from the same second forward pass).
+// what a frame's adjoint reads from the forward pass's caches (SPEC): the lane's pairs in transform order, lane 0's Z[256],
+// and for lanes < 32 the mel energy and its gradient.  A separate step so that a kernel can issue the next frame's loads
+// before it transforms the current one (an_logmel_bwd_kernel).
+struct AnSpecIn {
+    float2 zk[4], zr[4], z4;
+    float mel, dfeat;
+};
+__device__ __forceinline__ void an_spec_load(const AnTables& t, const float* __restrict__ dfeats, size_t gf, int lane, AnSpecIn& in) {
+    const float2* sc = t.spec_cache + gf * kAnHalf;
+    const int pl = an_partner_lane(lane), z64 = lane == 0 ? 64 : 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        in.zk[d] = sc[lane + 64 * d];
+        in.zr[d] = sc[(pl + 64 * (7 - d) + z64) & (kAnHalf - 1)];  // lane 0: its own element 8 - d (d = 0: Z[0] again)
+    }
+    in.z4 = sc[lane + 64 * 4];
+    in.mel = in.dfeat = 0.f;
+    if (lane < kAnMel) {
+        in.mel = t.mel_cache[gf * kAnMel + lane];
+        in.dfeat = dfeats[gf * kAnMel + lane];
+    }
+}
+
 template <typename R, bool CACHED, bool SPEC, bool POWER>
 __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>* tw1, const cx<R>* tw2, const AnBinLds& bl,
                                                   AnFrameLdsT<R, POWER>& L, const AnLaneConstT<R>& lc, const float* __restrict__ xr, int T,
                                                   int f, size_t gf, float scale, const float* __restrict__ dfeats, int lane,
-                                                  cx<R> (&dz)[8]) {
+                                                  const AnSpecIn& pre, cx<R> (&dz)[8]) {
     static_assert(CACHED || !SPEC, "the spectrum cache comes with the mel cache");
     const int e0 = (lane >> 3) + 8 * (lane & 7), pl = an_partner_lane(lane), p4 = 4 * pl;
     const bool l0 = lane == 0;
     cx<R> zk[4], zr[4], z4;  // z4: lane 0's Z[256]
     if constexpr (SPEC) {
-        const float2* sc = t.spec_cache + gf * kAnHalf;
-        const int z64 = l0 ? 64 : 0;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const float2 a = sc[lane + 64 * d];
-            const float2 b = sc[(pl + 64 * (7 - d) + z64) & (kAnHalf - 1)];  // lane 0: its own element 8 - d (d = 0: Z[0] again)
-            zk[d] = cmk<R>((R)a.x, (R)a.y);
-            zr[d] = cmk<R>((R)b.x, (R)b.y);
+            zk[d] = cmk<R>((R)pre.zk[d].x, (R)pre.zk[d].y);
+            zr[d] = cmk<R>((R)pre.zr[d].x, (R)pre.zr[d].y);
         }
-        const float2 c = sc[lane + 64 * 4];
-        z4 = cmk<R>((R)c.x, (R)c.y);
+        z4 = cmk<R>((R)pre.z4.x, (R)pre.z4.y);
     } else {
         AnRaw cur;
         an_load_frame(xr, T, f, lane, lc.m, cur);
@@ -336,9 +358,10 @@ __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>
     if (lane < 34) {
         float dm = 0.f;
         if (lane < kAnMel) {
-            const float mel = CACHED ? t.mel_cache[gf * kAnMel + lane] : L.mel[lane];
+            const float mel = SPEC ? pre.mel : (CACHED ? t.mel_cache[gf * kAnMel + lane] : L.mel[lane]);
+            const float df = SPEC ? pre.dfeat : dfeats[gf * kAnMel + lane];
             // d/d mel of 10 log10(max(mel, 1e-16))
-            dm = mel > 1e-16f ? dfeats[gf * kAnMel + lane] * (10.f / 2.302585092994046f) / mel : 0.f;
+            dm = mel > 1e-16f ? df * (10.f / 2.302585092994046f) / mel : 0.f;
         }
         L.dmel[lane] = dm;
     }
@@ -373,7 +396,7 @@ __device__ __forceinline__ void an_frame_backward(const AnTables& t, const cx<R>
 // an_frames_to_wave_kernel's).  Instantiations by (R, CACHED, SPEC): the cached ones do not carry the mel-weight
 // registers.
 template <typename R, bool CACHED, bool SPEC>
-__global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
+__global__ __launch_bounds__(256, sizeof(R) == 4 && SPEC ? 4 : (sizeof(R) == 4 && CACHED ? 3 : 2)) void an_logmel_bwd_kernel(AnTables t, const float* __restrict__ x, int B, int T, int F,
                                                             const float* __restrict__ scale_p,
                                                             const float* __restrict__ dfeats, float* __restrict__ dframes) {
     constexpr bool POWER = !CACHED && !SPEC;
@@ -385,17 +408,20 @@ __global__ __launch_bounds__(256, sizeof(R) == 4 && (CACHED || SPEC) ? 3 : 2) vo
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     AnFrameLdsT<R, POWER>& L = lds[wid];
-    if (POWER && lane < 3 + kAnMelLaneBins) L.power[kAnBins + lane] = 0.f;
     __shared__ AnLaneTab<POWER> ltab;
     AnLaneConstT<R> lc;
     an_lane_init<R, POWER>(t, lane, ltab, lc);
     __syncthreads();
     const AnFrameRange fr = an_frame_range(B * F, wid);
+    AnSpecIn cur, nxt;  // SPEC: the next frame's cache lines are on their way while this one is transformed
+    if (SPEC && fr.first < fr.end) an_spec_load(t, dfeats, (size_t)fr.first, lane, cur);
     for (int gf = fr.first; gf < fr.end; gf += fr.stride) {
         const int bb = gf / F;
+        if (SPEC && gf + fr.stride < fr.end) an_spec_load(t, dfeats, (size_t)(gf + fr.stride), lane, nxt);
         cx<R> dzv[8];  // dz[n], n = lane + 64 i
         an_frame_backward<R, CACHED || SPEC, SPEC, POWER>(t, tw1, tw2, bl, L, lc, x + (size_t)bb * T, T, gf - bb * F, (size_t)gf, scale, dfeats,
-                                                          lane, dzv);
+                                                          lane, cur, dzv);
+        if (SPEC) cur = nxt;
         float* out = dframes + (size_t)gf * kAnWin;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -556,127 +582,99 @@ __global__ __launch_bounds__(256) void an_frames_to_wave4_kernel(const float* __
     }
 }
 
-// ---- round 5: the overlap-add INSIDE the adjoint.  The separate pair wrote every frame's 800 gradient samples to HBM and
-// read them back (491 MB each way at 512 utterances: 242 us of an_frames_to_wave_kernel + the write half of the adjoint's
-// 558).  Here a block owns a run of consecutive frames [fa, fb) of ONE utterance and walks it in groups of NW frames (one
-// per wave): the waves leave their frame's windowed gradient in an LDS ring of NW + 4 frame slots, the block then adds up
-// -- in ascending frame order, like an_at_pos -- every signal position whose last covering frame is in the group
-// (position q = p + 400 is covered by frames (q - 799) / 160 .. q / 160), and turns the d pre values into d x (+ the fused
-// sign / project / clamp update).  A block starts 5 frames before fa (its first d x needs d pre one position to the left
-// of its first own position, which reaches 5 frames back); those halo frames are transformed twice -- 64 utterances x 8
-// slices: +13 %, 512 x 1: none.  What reaches across the utterance's ends -- the reflect padding of torch.stft, the first
-// 402 and the last ~400 samples -- is left to an_edge_to_wave_kernel, for which the first 6 and last 5 frames also go to HBM.
-// Same sums in the same order as the separate pair: same bits (tests/test_gpu_audionet.py).
-// The update reads x_in and writes x_out, two DIFFERENT buffers: a neighbour block still reads the waveform around the cut
-// (its halo frames) while this one writes its positions.
-// frame slots of the ring: a group's position sums read frames g0 - 4 .. g0 + NW - 1.  With 2 NW + 4 slots the next group's
-// frames land in slots nobody reads, so ONE block barrier per group is enough (float, NW = 4: 12 slots); the float64 form
-// (NW = 8, one block per CU) has LDS for NW + 4 slots only and pays a second barrier.
-template <typename R, int NW>
-constexpr int an_ola_ring() { return sizeof(R) == 4 ? 2 * NW + 4 : NW + 4; }
-
-template <typename R, int NW>
-struct AnOlaLds {  // dynamic LDS of the fused kernel (float, NW = 4: 69 KB, two blocks per CU; double, NW = 8: 129 KB, one)
-    AnFrameLdsT<R, false> lds[NW];
-    cx<R> tw1[kFftTw1], tw2[kFftTw2];
-    AnBinLds bl;
-    AnLaneTab<false> ltab;
-    __attribute__((aligned(16))) float ring[an_ola_ring<R, NW>()][kAnWin];
-    float carry[2];  // d pre of a group's last position, for the first d x of the next group
-};
-
-template <typename R, int NW, bool SPEC>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void an_logmel_bwd_ola_kernel(AnTables t, AnOlaArgs a) {
-    constexpr int RING = an_ola_ring<R, NW>(), NPOS = NW * kAnHop, NT = NW * 64, NJ = (NPOS + NT - 1) / NT;
-    constexpr bool kSecondBarrier = RING < 2 * NW + 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ola_lds_raw[];
-    AnOlaLds<R, NW>& S = *reinterpret_cast<AnOlaLds<R, NW>*>(ola_lds_raw);
-    auto& lds = S.lds;
-    cx<R>* tw1 = S.tw1;
-    cx<R>* tw2 = S.tw2;
-    AnBinLds& bl = S.bl;
-    auto& ring = S.ring;
+// ---- round 5: the overlap-add INSIDE the adjoint.  The separate pair writes every frame's 800 gradient samples to HBM and
+// reads them back (491 MB each way at 512 utterances; both kernels of the pair are HBM-bound there).  Here a WAVE owns a run
+// of consecutive frames [fa, fb) of ONE utterance and walks it in ascending order, adding every frame's windowed gradient
+// into a circular 800-position accumulator in LDS (position q = p + 400 at q mod 800; q is covered by frames
+// (q - 799) / 160 .. q / 160, so the first frame to touch a position is the one that has it in its last hop: it stores,
+// the next four add -- ascending frames, like an_at_pos: same sums in the same order, same bits as the separate pair,
+// tests/test_gpu_audionet.py).  After frame f the 160 positions of its FIRST hop are complete: the wave turns them into
+// d x (+ the fused sign / project / clamp update).  A run starts 5 frames before fa (its first d x needs d pre one position
+// to the left of its first own position, which reaches 5 frames back); those halo frames are transformed twice -- the price
+// of cutting an utterance: 512 utterances x 6 runs of 50 frames: +10 %; 64 utterances are too few frames for this form
+// (runs of 6 frames: +80 %), sg_an_configure's automatic choice keeps the separate pair there.
+// (The first version of this round kept a ring of whole frames per BLOCK, 38 KB: two blocks per CU, slower than the pair.)
+// What reaches across the utterance's ends -- the reflect padding of torch.stft, the first 402 and the last ~400 samples --
+// is left to an_edge_to_wave_kernel, for which the first 6 and last 5 frames also go to HBM.
+// The update reads x_in and writes x_out, two DIFFERENT buffers: without the spectrum cache a neighbour run still reads the
+// waveform around the cut (its halo frames) while this one writes its positions.
+// NW waves per block.  float: 4 (48 KB: three blocks = 12 waves per CU, 143 registers; blocks of 8 waves -- 78 KB, two per CU,
+// 16 waves at 128 registers with 8 spilled -- measured 1.333 against 1.312 ms per step at 512 utterances); double: 4 (69 KB, two).
+template <typename R, bool SPEC, int NW>
+__global__ __launch_bounds__(NW * 64, sizeof(R) == 4 ? 3 : 2) void an_logmel_bwd_ola_kernel(AnTables t, AnOlaArgs a) {
+    __shared__ AnFrameLdsT<R, false> lds[NW];
+    __shared__ cx<R> tw1[kFftTw1], tw2[kFftTw2];
+    __shared__ AnBinLds bl;
+    __shared__ AnLaneTab<false> ltab;
+    __shared__ __attribute__((aligned(16))) float acc_all[NW][kAnWin];
     an_stage_bins(t, bl);
     an_stage_tw<R>(t, tw1, tw2);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = a.scale_p ? *a.scale_p : 1.f;
     AnFrameLdsT<R, false>& L = lds[wid];
     AnLaneConstT<R> lc;
-    an_lane_init<R, false>(t, lane, S.ltab, lc);
+    an_lane_init<R, false>(t, lane, ltab, lc);
     __syncthreads();
-    const int b = blockIdx.y, F = a.F, T = a.T, Lp = T - 1;
-    const int fa = (int)((long long)F * blockIdx.x / a.S), fb = (int)((long long)F * (blockIdx.x + 1) / a.S);
+    const int run = blockIdx.x * NW + wid;
+    if (run >= a.B * a.S) return;  // (no block barrier below)
+    const int b = run / a.S, r = run - b * a.S, F = a.F, T = a.T, Lp = T - 1;
+    const int fa = (int)((long long)F * r / a.S), fb = (int)((long long)F * (r + 1) / a.S);
     const int fs = fa > 5 ? fa - 5 : 0;
-    const int q_lo = kAnHop * fa, q_hi = kAnHop * fb;  // own positions q = t + 400; d pre is needed from q_lo - 1
     const float* xr = a.x + (size_t)b * T;
-    // position i = tid + NT j of a group: frame fi past the group's first, sample ri of that frame's first hop
-    int fi[NJ], ri[NJ];
+    float* acc = acc_all[wid];
+    float carry = 0.f;  // d pre of the position before the hop being finished (wave-uniform)
+    AnSpecIn cur, nxt;
+    if (SPEC && fs < fb) an_spec_load(t, a.dfeats, (size_t)b * F + fs, lane, cur);
+    int ph = kAnHop * (fs % 5);  // 160 f mod 800
+    for (int f = fs; f < fb; ++f) {
+        const size_t gf = (size_t)b * F + f;
+        if (SPEC && f + 1 < fb) an_spec_load(t, a.dfeats, gf + 1, lane, nxt);
+        cx<R> dzv[8];  // dz[n], n = lane + 64 i (the same expressions as an_logmel_bwd_kernel: same bits)
+        an_frame_backward<R, true, SPEC, false>(t, tw1, tw2, bl, L, lc, xr, T, f, gf, scale, a.dfeats, lane, cur, dzv);
+        if (SPEC) cur = nxt;
+        float* edge = (f >= fa && (f < a.edge_lo || f >= a.edge_hi)) ? a.dframes + gf * kAnWin : nullptr;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int i = tid + NT * j;
-        fi[j] = i / kAnHop;
-        ri[j] = i - fi[j] * kAnHop;
-    }
-    // sum over the (up to five) frames that cover position q = 160 (g0 + fq) + rq, ascending frames like an_at_pos;
-    // sg0: ring slot of frame g0
-    auto at_q = [&](int g0, int sg0, int fq, int rq) __attribute__((always_inline)) -> float {
-        float g = 0.f;
-#pragma unroll
-        for (int d = 4; d >= 0; --d) {
-            int sl = sg0 + fq - d;
-            sl = sl < 0 ? sl + RING : (sl >= RING ? sl - RING : sl);
-            if (g0 + fq - d >= 0) g += ring[sl][rq + kAnHop * d];
-        }
-        return g;
-    };
-    int par = 0;
-    for (int g0 = fs; g0 < fb; g0 += NW, par ^= 1) {
-        const int f = g0 + wid;
-        if (f < fb) {
-            const size_t gf = (size_t)b * F + f;
-            cx<R> dzv[8];  // dz[n], n = lane + 64 i (the same expressions as an_logmel_bwd_kernel: same bits)
-            an_frame_backward<R, true, SPEC, false>(t, tw1, tw2, bl, L, lc, xr, T, f, gf, scale, a.dfeats, lane, dzv);
-            float* slot = ring[f % RING];
-            float* edge = (f >= fa && (f < a.edge_lo || f >= a.edge_hi)) ? a.dframes + gf * kAnWin : nullptr;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int n = lane + 64 * i;
-                const int q = 2 * n - (kAnFft - kAnWin) / 2;
-                const cx<R> dz = dzv[i];
-                if (q >= 0 && q < kAnWin) {
-                    const float2 v = make_float2((float)dz.x * lc.win[64 * (2 * i)], (float)dz.y * lc.win[64 * (2 * i + 1)]);
-                    *reinterpret_cast<float2*>(slot + q) = v;
-                    if (edge) *reinterpret_cast<float2*>(edge + q) = v;
+        for (int i = 0; i < 8; ++i) {
+            const int n = lane + 64 * i;
+            const int q = 2 * n - (kAnFft - kAnWin) / 2;  // window index (even): positions 160 f + q, + 1
+            if (q >= 0 && q < kAnWin) {
+                const float2 v = make_float2((float)dzv[i].x * lc.win[64 * (2 * i)], (float)dzv[i].y * lc.win[64 * (2 * i + 1)]);
+                int p = ph + q;
+                p = p >= kAnWin ? p - kAnWin : p;
+                float2* slot = reinterpret_cast<float2*>(acc + p);
+                float2 sum;
+                if (f == fs || q >= kAnWin - kAnHop) {  // the first frame to reach the position: 0.f + v, like an_at_pos
+                    sum = make_float2(0.f + v.x, 0.f + v.y);
+                } else {
+                    const float2 o = *slot;
+                    sum = make_float2(o.x + v.x, o.y + v.y);
                 }
+                *slot = sum;
+                if (edge) *reinterpret_cast<float2*>(edge + q) = v;
             }
         }
-        __syncthreads();
-        const int sg0 = g0 % RING;
+        wave_sync();
+        if (f >= fa) {
+            float last = 0.f;  // d pre of the previous 64 positions' last one
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int i = tid + NT * j;
-            if (NPOS % NT != 0 && j == NJ - 1 && i >= NPOS) break;  // (whole waves: NPOS and NT are multiples of 64)
-            const int q = kAnHop * g0 + i;
-            const bool need = q >= q_lo - 1 && q < q_hi;
-            const float dp0 = need ? at_q(g0, sg0, fi[j], ri[j]) : 0.f;
-            // d pre of the position before: the lane below holds it; a wave's first lane adds it up itself -- or, for the
-            // group's first position, takes what the previous group left
-            float dpm1 = __shfl_up(dp0, 1);
-            if (lane == 0) {
-                if (i == 0) dpm1 = S.carry[par ^ 1];
-                else if (q - 1 >= q_lo - 1 && q - 1 < q_hi) {
-                    const int i1 = i - 1, f1 = i1 / kAnHop;
-                    dpm1 = at_q(g0, sg0, f1, i1 - f1 * kAnHop);
-                } else dpm1 = 0.f;
+            for (int j = 0; j < 3; ++j) {
+                const int i = lane + 64 * j;  // position 160 f + i of the finished hop (i < 160)
+                const float dp0 = i < kAnHop ? acc[ph + i] : 0.f;  // (ph + i < 800: ph <= 640)
+                float dpm1 = __shfl_up(dp0, 1);
+                if (lane == 0) dpm1 = j == 0 ? carry : last;
+                last = __shfl(dp0, 63);
+                const int tt = kAnHop * f + i - kAnWin / 2;
+                if (i < kAnHop && tt >= a.t_lo && tt <= a.t_hi) {
+                    const float g = an_dx(dpm1, dp0, tt, Lp, scale);
+                    an_emit(g, (size_t)b * T + tt, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
+                }
+                if (j == 2) carry = __shfl(dp0, kAnHop - 1 - 128);
             }
-            if (i == NPOS - 1) S.carry[par] = dp0;
-            const int tt = q - kAnWin / 2;
-            if (q >= q_lo && q < q_hi && tt >= a.t_lo && tt <= a.t_hi) {
-                const float g = an_dx(dpm1, dp0, tt, Lp, scale);
-                an_emit(g, (size_t)b * T + tt, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
-            }
+        } else if (f == fa - 1) {
+            carry = acc[ph + kAnHop - 1];  // d pre of position 160 fa - 1, complete after frame fa - 1
         }
-        if (kSecondBarrier) __syncthreads();
+        wave_sync();  // the next frame stores into the hop just read
+        ph = ph + kAnHop >= kAnWin ? 0 : ph + kAnHop;
     }
 }
 
@@ -859,23 +857,23 @@ __global__ __launch_bounds__(256) void an_tail_kernel(const float* __restrict__ 
 }
 
 // persistent blocks of the front-end kernels: a multiple of 8 (one share per XCD) once there is work for 16 blocks
-static int an_front_blocks(int frames) {
+static int an_front_blocks(int frames, int per_cu) {
     int want = (frames + kAnWavesPerBlock - 1) / kAnWavesPerBlock;
-    if (want > kAnMaxBlocks) want = kAnMaxBlocks;
+    if (want > per_cu * kAnCus) want = per_cu * kAnCus;
     if (want >= 16) want &= ~7;
     return want;
 }
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 int fft32, hipStream_t s) {
-    const dim3 grid(an_front_blocks(B * F));
+    const dim3 grid(an_front_blocks(B * F, fft32 ? 4 : 2));  // = the kernels' blocks per CU (__launch_bounds__)
     if (fft32) hipLaunchKernelGGL(an_logmel_fwd_kernel<float>, grid, dim3(256), 0, s, t, x, B, T, F, scale, feats);
     else hipLaunchKernelGGL(an_logmel_fwd_kernel<double>, grid, dim3(256), 0, s, t, x, B, T, F, scale, feats);
     return hipGetLastError();
 }
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,
                                 const float* dfeats, float* dframes, int fft32, hipStream_t s) {
-    const dim3 grid(an_front_blocks(B * F));
     const int kind = (t.mel_cache ? 1 : 0) + (t.mel_cache && t.spec_cache ? 2 : 0) + (fft32 ? 4 : 0);
+    const dim3 grid(an_front_blocks(B * F, kind == 7 ? 4 : (kind == 5 ? 3 : 2)));
 #define AN_BWD(R, C, SP) hipLaunchKernelGGL((an_logmel_bwd_kernel<R, C, SP>), grid, dim3(256), 0, s, t, x, B, T, F, scale, dfeats, dframes)
     switch (kind) {
         case 0: AN_BWD(double, false, false); break;
@@ -909,40 +907,45 @@ static void an_ola_ranges(int T, int F, AnOlaArgs& a) {
     a.edge_hi = q > kAnWin - 1 ? (q - (kAnWin - 1) + kAnHop - 1) / kAnHop : 0;
 }
 
-hipError_t launch_an_logmel_bwd_ola(const AnTables& t, AnOlaArgs a, int fft32, int num_cus, hipStream_t s) {
-    if (!t.mel_cache) return hipErrorInvalidValue;  // the fused form is for the pass whose forward has just run
-    an_ola_ranges(a.T, a.F, a);
-    const int nw = fft32 ? 4 : 8, slots = (num_cus > 0 ? num_cus : 256) * (fft32 ? 2 : 1);
-    // slices per utterance: rounds of resident blocks x groups of nw frames per block (5 halo frames per slice)
+// runs per utterance of the fused overlap-add: rounds of resident waves x frames per run (5 halo frames each)
+static int an_ola_slices(int B, int F, int slots, long* cost_out = nullptr) {
     int best_s = 1;
     long best_cost = -1;
-    const int smax = a.F / 8 > 0 ? a.F / 8 : 1;
+    const int smax = F / 8 > 0 ? F / 8 : 1;
     for (int sl = 1; sl <= smax; ++sl) {
-        const long rounds = ((long)a.B * sl + slots - 1) / slots;
-        const long groups = ((a.F + sl - 1) / sl + 5 + nw - 1) / nw;
-        const long cost = rounds * groups;
+        const long rounds = ((long)B * sl + slots - 1) / slots;
+        const long cost = rounds * ((F + sl - 1) / sl + (sl > 1 ? 5 : 0));
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best_s = sl;
         }
     }
-    a.S = best_s;
-    const dim3 grid(a.S, a.B);
+    if (cost_out) *cost_out = best_cost;
+    return best_s;
+}
+static int an_ola_slots(int fft32, int num_cus) { return (num_cus > 0 ? num_cus : kAnCus) * (fft32 ? 12 : 8); }  // resident waves
+// Is the fused form the faster one?  Its halo frames are transformed twice; the separate pair moves 2 x 3.2 KB per frame
+// through HBM instead.  Measured (profiles/r05_an_frontend_ab.txt): the fused form wins once the halo costs < ~25 %.
+bool an_ola_pays(int B, int F, int fft32, int num_cus) {
+    const int slots = an_ola_slots(fft32, num_cus);
+    long cost = 0;
+    an_ola_slices(B, F, slots, &cost);
+    return 4 * cost * slots <= 5 * (long)B * F;
+}
+hipError_t launch_an_logmel_bwd_ola(const AnTables& t, AnOlaArgs a, int fft32, int num_cus, hipStream_t s) {
+    if (!t.mel_cache) return hipErrorInvalidValue;  // the fused form is for the pass whose forward has just run
+    an_ola_ranges(a.T, a.F, a);
+    const int slots = an_ola_slots(fft32, num_cus);  // resident waves
+    a.S = an_ola_slices(a.B, a.F, slots);
     const bool spec = t.spec_cache != nullptr;
     hipError_t e = hipSuccess;
-#define AN_OLA(R, NW, SP)                                                                                                   \
-    do {                                                                                                                    \
-        const int bytes = (int)sizeof(AnOlaLds<R, NW>);                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(an_logmel_bwd_ola_kernel<R, NW, SP>),                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                          \
-        if (e == hipSuccess) hipLaunchKernelGGL((an_logmel_bwd_ola_kernel<R, NW, SP>), grid, dim3(NW * 64), bytes, s, t, a);   \
-    } while (0)
+#define AN_OLA(R, SP, NW) hipLaunchKernelGGL((an_logmel_bwd_ola_kernel<R, SP, NW>), dim3((a.B * a.S + NW - 1) / NW), dim3(NW * 64), 0, s, t, a)
     if (fft32) {
-        if (spec) AN_OLA(float, 4, true);
-        else AN_OLA(float, 4, false);
+        if (spec) AN_OLA(float, true, 4);
+        else AN_OLA(float, false, 4);
     } else {
-        if (spec) AN_OLA(double, 8, true);
-        else AN_OLA(double, 8, false);
+        if (spec) AN_OLA(double, true, 4);
+        else AN_OLA(double, false, 4);
     }
 #undef AN_OLA
     if (e != hipSuccess) return e;

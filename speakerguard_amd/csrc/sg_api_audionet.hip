@@ -424,6 +424,12 @@ int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t
     return SG_OK;
 }
 
+// the overlap-add inside the adjoint, or the separate pair?  (AnFrontCfg::ola: 1 / 0, or -1 = whichever the batch favours:
+// the fused form cuts utterances into runs with 5 halo frames each, k_audionet.hip an_ola_pays)
+static bool an_use_ola(const sg_ctx* ctx, int B, int F) {
+    return ctx->an_cfg.ola > 0 || (ctx->an_cfg.ola < 0 && an_ola_pays(B, F, ctx->an_cfg.fft32, ctx->num_cus));
+}
+
 // d loss / d log-mel (B, F, 32) -> d loss / d waveform: written to grad_out and / or applied as the fused PGD update
 // x_update: the iterate to step from (== x); x_next: where the stepped iterate goes.  The fused overlap-add needs
 // x_next != x_update (neighbour blocks still read x around their cut); the separate pair updates in place and copies if
@@ -434,7 +440,7 @@ int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const flo
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
     tab.spec_cache = w.cache_spec ? w.spec_cache : nullptr;
-    if (ctx->an_cfg.ola && (!x_update || x_next != x_update)) {
+    if (an_use_ola(ctx, d.B, d.F) && (!x_update || x_next != x_update)) {
         AnOlaArgs a{};
         a.x = x; a.dfeats = dfeats; a.dframes = w.dframes; a.grad_out = grad_out;
         a.x_in = x_update; a.x_out = x_update ? x_next : nullptr; a.lower = lower; a.upper = upper; a.scale_p = w.scale;
@@ -452,7 +458,7 @@ int an_frontend_backward(sg_ctx* ctx, const float* x, const AnDims& d, const flo
 // the buffer the fused overlap-add steps into (null: the separate pair updates in place)
 float* an_step_target(sg_ctx* ctx, const AnDims& d) {
     AnWorkspace& w = ctx->an_ws;
-    if (!ctx->an_cfg.ola) return nullptr;
+    if (!an_use_ola(ctx, d.B, d.F)) return nullptr;
     if (!w.x_alt) {
         void* p = nullptr;
         if (hipMalloc(&p, (size_t)w.B * w.T * sizeof(float)) != hipSuccess) return nullptr;  // falls back to the separate pair
@@ -576,7 +582,7 @@ int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T,
         tab.spec_cache = w.cache_spec ? w.spec_cache : nullptr;
     }
     AN_HIP(launch_input_scale(x_dev, (int64_t)B * T, ctx->range_scratch, w.scale, 1, s));
-    if (tab.mel_cache && ctx->an_cfg.ola) {  // the attack loops' form of the adjoint (same sums in the same order as the pair below)
+    if (tab.mel_cache && an_use_ola(ctx, d.B, d.F)) {  // the attack loops' form of the adjoint (same sums in the same order as the pair below)
         AnOlaArgs a{};
         a.x = x_dev; a.dfeats = dfeats_dev; a.dframes = w.dframes; a.grad_out = grad_dev; a.scale_p = w.scale;
         a.B = d.B; a.T = d.T; a.F = d.F;
@@ -593,7 +599,7 @@ int sg_an_configure(sg_ctx* ctx, int32_t fft_bits, int32_t spectrum_cache, int32
     if (fft_bits != 32 && fft_bits != 64) return an_fail(ctx, SG_ERR_ARG, "fft_bits must be 32 or 64");
     ctx->an_cfg.fft32 = fft_bits == 32;
     ctx->an_cfg.spec_cache = spectrum_cache != 0;
-    ctx->an_cfg.ola = fused_overlap_add != 0;
+    ctx->an_cfg.ola = fused_overlap_add < 0 ? -1 : (fused_overlap_add != 0);
     ctx->an_ws.cache_x = nullptr;  // what an earlier forward left behind was computed under the old settings
     ctx->an_ws.cache_spec = false;
     return SG_OK;

@@ -79,7 +79,7 @@ struct AnFrontCfg {
     // defaults = the fastest measured combination (profiles/r05_an_frontend_ab.txt)
     int fft32 = 1;       // transforms in float32 (the reference's precision) or float64
     int spec_cache = 1;  // the forward keeps every frame's packed spectrum for the backward of the same pass
-    int ola = 0;         // overlap-add (+ update) inside the log-mel adjoint (built and bit-equal; not faster: see DESIGN.md)
+    int ola = -1;        // overlap-add (+ update) inside the log-mel adjoint: 1 / 0, -1 = where it pays (an_ola_pays: large batches)
 };
 struct AnOlaArgs {
     const float* x;        // (B, T) waveform the frames are re-transformed from (spectrum cache: unused)
@@ -437,6 +437,7 @@ hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T,
                                 const float* dfeats, float* dframes, int fft32, hipStream_t s);
 // the adjoint with the overlap-add (+ update) inside: needs t.mel_cache of the same pass; x_out != x_in
 hipError_t launch_an_logmel_bwd_ola(const AnTables& t, AnOlaArgs a, int fft32, int num_cus, hipStream_t s);
+bool an_ola_pays(int B, int F, int fft32, int num_cus);
 hipError_t launch_an_frames_to_wave(const float* dframes, int B, int T, int F, const float* scale, float* grad_out,
                                     float* x_io, const float* lower, const float* upper, float step, int grad_sign,
                                     hipStream_t s);
