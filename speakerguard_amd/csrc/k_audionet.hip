@@ -629,6 +629,22 @@ __global__ __launch_bounds__(NW * 64, sizeof(R) == 4 ? 3 : 2) void an_logmel_bwd
     for (int f = fs; f < fb; ++f) {
         const size_t gf = (size_t)b * F + f;
         if (SPEC && f + 1 < fb) an_spec_load(t, a.dfeats, gf + 1, lane, nxt);
+        // what the update of this frame's finished hop reads, requested before the transform (an HBM round trip is a fifth
+        // of a frame's time here)
+        float xi[3], lo[3], up[3];
+        if (a.x_out && f >= fa) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int i = lane + 64 * j, tt = kAnHop * f + i - kAnWin / 2;
+                xi[j] = lo[j] = up[j] = 0.f;
+                if (i < kAnHop && tt >= a.t_lo && tt <= a.t_hi) {
+                    const size_t o = (size_t)b * T + tt;
+                    xi[j] = a.x_in[o];
+                    lo[j] = a.lower[o];
+                    up[j] = a.upper[o];
+                }
+            }
+        }
         cx<R> dzv[8];  // dz[n], n = lane + 64 i (the same expressions as an_logmel_bwd_kernel: same bits)
         an_frame_backward<R, true, SPEC, false>(t, tw1, tw2, bl, L, lc, xr, T, f, gf, scale, a.dfeats, lane, cur, dzv);
         if (SPEC) cur = nxt;
@@ -666,7 +682,12 @@ __global__ __launch_bounds__(NW * 64, sizeof(R) == 4 ? 3 : 2) void an_logmel_bwd
                 const int tt = kAnHop * f + i - kAnWin / 2;
                 if (i < kAnHop && tt >= a.t_lo && tt <= a.t_hi) {
                     const float g = an_dx(dpm1, dp0, tt, Lp, scale);
-                    an_emit(g, (size_t)b * T + tt, a.grad_out, a.x_in, a.x_out, a.lower, a.upper, a.step, a.grad_sign);
+                    const size_t o = (size_t)b * T + tt;
+                    if (a.grad_out) a.grad_out[o] = g;
+                    if (a.x_out) {  // an_emit's expressions on the values requested above
+                        const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+                        a.x_out[o] = fminf(fmaxf(xi[j] + a.step * sg * (float)a.grad_sign, lo[j]), up[j]);
+                    }
                 }
                 if (j == 2) carry = __shfl(dp0, kAnHop - 1 - 128);
             }
