@@ -522,6 +522,14 @@ __global__ __launch_bounds__(256) void an_frames_to_wave4_kernel(const float* __
     const int pmax = (F - 1) * kAnHop + kAnWin / 2 - 1;
     const int s_last = t0 + kAnF2wPerBlock - 1;
     const bool interior = t0 - 1 >= kAnWin / 2 + 1 && s_last <= Lp - 1 && 2 * (Lp - 1) - s_last > pmax;
+    // the update's operands do not depend on the sums: requested first, one memory round trip instead of two
+    const size_t o = (size_t)b * T + s0;
+    float4 xi = make_float4(0.f, 0.f, 0.f, 0.f), lo = xi, up = xi;
+    if (x_io && s0 < T) {
+        xi = *reinterpret_cast<const float4*>(x_io + o);
+        lo = *reinterpret_cast<const float4*>(lower + o);
+        up = *reinterpret_cast<const float4*>(upper + o);
+    }
     if (interior) {
         const int q = s0 + kAnWin / 2, k = q / kAnHop, r = q - k * kAnHop;
         float4 v[5];
@@ -562,7 +570,6 @@ __global__ __launch_bounds__(256) void an_frames_to_wave4_kernel(const float* __
     if (s0 >= T) return;
     const float4 c = *reinterpret_cast<const float4*>(&dp[4 + 4 * tid]);
     const float pm1 = dp[3 + 4 * tid];
-    const size_t o = (size_t)b * T + s0;
     float4 gx;
     gx.x = an_dx(pm1, c.x, s0, Lp, scale);
     gx.y = an_dx(c.x, c.y, s0 + 1, Lp, scale);
@@ -570,8 +577,6 @@ __global__ __launch_bounds__(256) void an_frames_to_wave4_kernel(const float* __
     gx.w = an_dx(c.z, c.w, s0 + 3, Lp, scale);
     if (grad_out) *reinterpret_cast<float4*>(grad_out + o) = gx;
     if (x_io) {
-        const float4 xi = *reinterpret_cast<const float4*>(x_io + o), lo = *reinterpret_cast<const float4*>(lower + o),
-                     up = *reinterpret_cast<const float4*>(upper + o);
         const float fs = (float)grad_sign;
         auto upd = [&](float g, float x, float l, float u) {
             const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
