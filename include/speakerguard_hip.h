@@ -59,6 +59,12 @@ int sg_set_streamk(sg_ctx* ctx, int32_t enable);
 /* TEST HOOK (fault injection for the health path; no production use): the next `launches` stream-K launches of this
  * context publish no hand-off flags, so their waiting blocks time out (after a shortened bound) and raise the health word. */
 int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches);
+/* The FeCo k-means (sg_feco_kmeans*) runs an instance on TWO compute units when the batch leaves room for it (2 x instances
+ * <= compute units): both blocks compute the same clustering and share only the assignment step's work through device
+ * memory, every wait bounded (20 us) -- a block whose partner does not show up (GPU shared with something else) computes
+ * everything itself: same bits, the one-unit speed.  mode -1: where it fits (default); 0: never.
+ * (sg_debug_lose_handoffs also covers this protocol: a launch it counts makes every second block publish nothing.) */
+int sg_feco_set_two_cu(sg_ctx* ctx, int32_t mode);
 
 /* ---- x-vector + PLDA model ----------------------------------------------------------------
  * Replaces the tensors the reference holds after model/xv_plda.py:17-47 ran: the xvecTDNN

@@ -78,6 +78,33 @@ struct FecoSched {
     unsigned u[kFecoThreads / 64][2];
 };
 
+// Two CUs per instance (round 5, VERDICT r4 item 1: "off the single CU").  An instance's k-means is bound by the MFMA +
+// VALU issue of the four SIMDs of the one CU its block gets, and a batch of 64 x 2 instances leaves half of the chip idle.
+// With `on` the grid's z dimension is the HALF: two blocks run the same instance redundantly -- same set-up, same lists,
+// same update, bit for bit -- and split only the assignment's units (sched / sched1; bit u of `owner` says whose unit
+// u = frame tile * JC + chunk is).  After its units a block stores its chunk maxima into its exchange buffer (two of them,
+// alternating by iteration) as self-describing 8-byte words -- score | index << 32 | tag << 43, tag = launch and iteration --
+// with write-through (sc1) stores, and polls the partner's words (sc1 loads) until they carry the tag it expects: one
+// store -> load visibility delay per iteration, no flag, no fence (the first version published a flag after draining the
+// stores: 3.2 us per iteration, as much as the split saved).  A word is accepted only with the exact tag, so stale or
+// overwritten data cannot be taken for the partner's; the buffers are zeroed when the launch counter wraps.
+// No block ever waits unboundedly, and no result depends on the partner showing up: if any word is not there after
+// kFecoPairWait the block computes the partner's units itself from then on (and says so in `flags`, which saves the
+// partner its own time-out).  The partner not showing up is what happens when something else occupies the GPU: same bits,
+// the single-CU speed (+ one time-out).
+struct FecoPair {
+    int on;
+    unsigned owner;
+    FecoSched sched1;
+    unsigned long long* xchg;  // [instance][half][buffer 0 / 1][kFecoMergeCap]
+    unsigned* flags;           // [instance][half]: launch id of the launch in which the block went on alone
+    unsigned tag0;             // this launch's tag base: (launch counter mod 2^15) << 6; a word's tag = tag0 + iteration + 1
+    unsigned launch;           // launch id
+    int drop;                  // test hook (sg_debug_lose_handoffs): half 1 publishes nothing
+};
+constexpr int kFecoPairMaxIter = 62;                // tag = 15 bits of launch counter, 6 of iteration
+constexpr unsigned long long kFecoPairWait = 2000;  // 20 us of the 100 MHz clock
+
 // Dynamic LDS of feco_kmeans_kernel in 4-byte words (every array 16-byte aligned); host and device use the same function.
 struct FecoLds {
     int cq, hq, mu, part, ids, cnt, start, members, cw, spart, wtot, pd, pj, xq, total;
@@ -151,7 +178,7 @@ template <int DPAD>
 __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* __restrict__ feats, int F, int D, int k,
                                                                    int max_iter, int seeded, uint64_t seed, int64_t index_base,
                                                                    int x_in_lds, int fast_lists, int JC, FecoSched sched,
-                                                                   int* __restrict__ assign, float* __restrict__ out,
+                                                                   FecoPair pr, int* __restrict__ assign, float* __restrict__ out,
                                                                    int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FecoLds L = feco_layout(F, k, DPAD, JC, fast_lists, x_in_lds);
@@ -175,8 +202,15 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
     const int lane = tid & 63, lh = lane >> 5, ln = lane & 31;
     // blockIdx.y = repeat: the same utterances clustered again from other random frames (EOT over the defense); repeat r
     // uses key seed + r * 0xC2B2AE3D27D4EB4F and writes slot r * gridDim.x + utterance of every output
-    const float* x = feats + (size_t)blockIdx.x * F * D;
-    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    // Two CUs per instance: the grid's z dimension is the half.  (Blocks go to the 8 XCDs round robin by linear index: with
+    // the instances a multiple of 8 the two halves share an XCD -- a speed assumption only.  Halves as neighbours in x --
+    // different XCDs -- measured 97 us per call against 90; x and x ^ 8 -- same XCD, dispatched together -- 92.)
+    const int half = pr.on ? (int)blockIdx.z : 0;
+    const int bx = (int)blockIdx.x, nbx = (int)gridDim.x;
+    const float* x = feats + (size_t)bx * F * D;
+    const size_t slot = (size_t)blockIdx.y * nbx + bx;
+    __shared__ int pair_solo;
+    if (tid == 0) pair_solo = 0;
     seed += (uint64_t)blockIdx.y * 0xC2B2AE3D27D4EB4Full;
     FECO_STAMP(4 * kFecoTraceIters + 2)
     for (int i = tid; i < al4(F); i += kFecoThreads) ids[i] = -1;  // the pad entries stay -1: no cluster
@@ -233,7 +267,7 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
         // (both are free until the first update)
         unsigned* keys = reinterpret_cast<unsigned*>(members);
         int* chosen = cnt;
-        const int64_t utt = index_base + blockIdx.x;
+        const int64_t utt = index_base + bx;
         for (int i = tid; i < al4(F); i += kFecoThreads)
             keys[i] = i < F ? philox4x32_10_w0(seed, (uint32_t)i, 0u, (uint32_t)utt, (uint32_t)((uint64_t)utt >> 32)) : 0xFFFFFFFFu;
         __syncthreads();
@@ -335,13 +369,13 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
             float tb = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tb = fmaxf(tb, acc[r]);
-            int tj = 0x7fffffff;
-            const int mb = ct * 32 + 4 * lh;
+            // (rows ascend with the register index: the last match of a descending walk is the lowest row)
+            int rr = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tj = min(tj, acc[r] == tb ? mb + (r & 3) + 8 * (r >> 2) : 0x7fffffff);
+            for (int r = 15; r >= 0; --r) rr = acc[r] == tb ? r : rr;
             if (tb > best) {
                 best = tb;
-                bj = tj;
+                bj = ct * 32 + 4 * lh + (rr & 3) + 8 * (rr >> 2);
             }
         }
         {  // the other half of the tile's rows sits in lane ^ 32
@@ -353,7 +387,7 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
             }
         }
         if (lh == 0 && frame < F) {
-            if (JC > 1) {
+            if (JC > 1) {  // (the two-CU form needs JC > 1: host)
                 pd[jc * F + frame] = best;
                 pj[jc * F + frame] = bj;
             } else if (ids[frame] != bj) {
@@ -365,7 +399,8 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
     // (D > 32: two resident operands of 32 registers do not fit the 128 of a 1024-thread block -- round robin there)
     const bool table = DPAD == 32 && sched.table;
     float4 xb0[DPAD / 8], xb1[DPAD == 32 ? DPAD / 8 : 1];
-    const unsigned u0 = table ? sched.u[tid >> 6][0] : kFecoNoUnit, u1 = table ? sched.u[tid >> 6][1] : kFecoNoUnit;
+    const unsigned u0 = table ? (half ? pr.sched1.u[tid >> 6][0] : sched.u[tid >> 6][0]) : kFecoNoUnit;
+    const unsigned u1 = table ? (half ? pr.sched1.u[tid >> 6][1] : sched.u[tid >> 6][1]) : kFecoNoUnit;
     if (u0 != kFecoNoUnit) load_b(u0 & 255, xb0);
     if constexpr (DPAD == 32)
         if (u1 != kFecoNoUnit) load_b(u1 & 255, xb1);
@@ -390,6 +425,66 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
         }
         __syncthreads();
         if (it == 0) { FECO_DETAIL(3) }
+        if (pr.on) {
+            // ---- the partner's half of the chunk maxima (FecoPair above)
+            const int nE = JC * F;
+            bool have_theirs = false;
+            if (!pair_solo) {
+                const size_t buf = ((size_t)(slot * 2 + half) * 2 + (it & 1)) * kFecoMergeCap;
+                const size_t buf_p = ((size_t)(slot * 2 + (half ^ 1)) * 2 + (it & 1)) * kFecoMergeCap;
+                const unsigned long long tag = pr.tag0 + (unsigned)it + 1u;
+                if (!(pr.drop && half == 1))
+                    for (int r = tid; r < nE; r += kFecoThreads) {
+                        const int jc = r / F, fr = r - jc * F;
+                        if ((int)((pr.owner >> ((fr >> 5) * JC + jc)) & 1u) == half)
+                            __hip_atomic_store(pr.xchg + buf + r,
+                                               (unsigned long long)(unsigned)__float_as_int(pd[r]) | (unsigned long long)(unsigned)pj[r] << 32 | tag << 43,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                int bad = 0;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (int r = tid; r < nE && !bad; r += kFecoThreads) {
+                    const int jc = r / F, fr = r - jc * F;
+                    if ((int)((pr.owner >> ((fr >> 5) * JC + jc)) & 1u) == half) continue;
+                    for (;;) {
+                        const unsigned long long v = __hip_atomic_load(pr.xchg + buf_p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((v >> 43) == tag) {
+                            pd[r] = __int_as_float((int)(unsigned)v);
+                            pj[r] = (int)((v >> 32) & 0x7FFu);
+                            break;
+                        }
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > kFecoPairWait ||
+                            __hip_atomic_load(pr.flags + slot * 2 + (half ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.launch) {
+                            bad = 1;  // not there in time, or the partner has said it went on alone
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                bad = __syncthreads_or(bad);
+                if (bad) {
+                    if (tid == 0) {
+                        pair_solo = 1;
+                        if (!(pr.drop && half == 1))
+                            __hip_atomic_store(pr.flags + slot * 2 + half, pr.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    have_theirs = true;
+                }
+            }
+            if (!have_theirs) {  // on its own: the partner's units, dealt round the waves; then this wave's operand again
+                int n = 0;
+                for (int u = 0; u < nunits; ++u) {
+                    if ((int)((pr.owner >> u) & 1u) == half) continue;
+                    if ((n++ & (kFecoThreads / 64 - 1)) != (tid >> 6)) continue;
+                    const int ft = u / JC, jc = u - ft * JC;
+                    load_b(ft, xb0);
+                    run_unit(ft, ntc * jc / JC, ntc * (jc + 1) / JC, jc, xb0);
+                }
+                if (u0 != kFecoNoUnit) load_b(u0 & 255, xb0);
+            }
+            __syncthreads();
+        }
         if (JC > 1) {
             for (int r = tid; r < F; r += kFecoThreads) {  // merge the chunks in ascending centroid order: the lowest index wins ties
                 float b = pd[r];
@@ -525,9 +620,11 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
     FECO_CYCLES(21)
     // cnt / start / members describe the final ids in both exits: "nothing changed" leaves the previous iteration's lists
     // valid, the max_iter exit has just rebuilt them.  (max_iter >= 1 and ids start at -1: the lists exist.)
+    // (two CUs: both blocks hold the same result; each writes half of it)
+    const int e_lo = pr.on && half ? (k * D) / 2 : 0, e_hi = pr.on && !half ? (k * D) / 2 : k * D;
     if (out) {
         float* o = out + slot * k * D;
-        for (int e = tid; e < k * D; e += kFecoThreads) {
+        for (int e = e_lo + tid; e < e_hi; e += kFecoThreads) {
             const int j = e / D, d = e - j * D;
             const int n = cnt[j];
             float v;
@@ -550,9 +647,11 @@ __global__ __launch_bounds__(kFecoThreads) void feco_kmeans_kernel(const float* 
             }
             o[e] = v;
         }
-        for (int j = tid; j < k; j += kFecoThreads) counts[slot * k + j] = cnt[j];
+        if (half == 0)
+            for (int j = tid; j < k; j += kFecoThreads) counts[slot * k + j] = cnt[j];
     }
-    for (int i = tid; i < F; i += kFecoThreads) assign[slot * F + i] = ids[i];
+    if (!pr.on || half == 1)
+        for (int i = tid; i < F; i += kFecoThreads) assign[slot * F + i] = ids[i];
     FECO_STAMP(4 * kFecoTraceIters + 1)
 }
 
@@ -637,6 +736,11 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     if (const char* ev = getenv("SG_FECO_ABLATE")) { const int a = atoi(ev); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_ablate), &a, sizeof(a)); }
     if (const char* ev = getenv("SG_FECO_JC")) { JC = atoi(ev); JC = JC < 1 ? 1 : (JC > ntc ? ntc : JC); while (JC > 1 && JC * F > kFecoMergeCap) --JC; }
 #endif
+    // two CUs per instance (FecoPair): same units as one block would get (cutting them finer -- 30 units of 1-2 tiles for
+    // the 32 waves -- measured 94.3 against 92.5 us per call: the SIMDs are throughput-bound, the merge grows)
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const bool pair_ok = ctx->feco_two_cu != 0 && dpad == 32 && 2 * (long)B * reps <= cus;
+    const int kp_host = (k + 31) & ~31;
     auto bytes = [&](int jc, int fast, int xin) { return (size_t)feco_layout(F, k, dpad, jc, fast, xin).total * sizeof(float); };
     if (bytes(JC, 0, 0) > kLdsMax) JC = 1;
     if (bytes(JC, 0, 0) > kLdsMax)
@@ -646,26 +750,75 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     // largest first, each to the least loaded SIMD (waves w, w + 4, w + 8, w + 12) and there to the least loaded wave with a
     // free slot -- 300 x 150: 20 units of 2 / 3 tiles -> 12 / 13 / 12 / 13 tiles per SIMD
     FecoSched sched{};
+    FecoPair pr{};
     const int nunits = ntf * JC;
     constexpr int kWaves = kFecoThreads / 64;
+    // two CUs per instance (FecoPair): when every instance can have two resident blocks, the units fit the tables and a bit
+    // mask, and the flag values have room for the iterations
+    if (pair_ok && JC > 1 && nunits <= 32 && max_iter <= kFecoPairMaxIter && kp_host <= 2048) {
+        const size_t inst_max = (size_t)cus / 2, words = inst_max * 2 * 2 * kFecoMergeCap;
+        if (!ctx->feco_xchg) {  // room for the most instances that can be paired
+            void *px = nullptr, *pf = nullptr;
+            if (hipMalloc(&px, words * sizeof(unsigned long long)) == hipSuccess && hipMalloc(&pf, inst_max * 2 * sizeof(unsigned)) == hipSuccess &&
+                hipMemset(pf, 0, inst_max * 2 * sizeof(unsigned)) == hipSuccess) {
+                ctx->feco_xchg = static_cast<unsigned long long*>(px);
+                ctx->feco_flags = static_cast<unsigned*>(pf);
+                ctx->model_allocs.push_back(px);
+                ctx->model_allocs.push_back(pf);
+                ctx->feco_epoch = 0;
+            } else {  // no room: one block per instance
+                if (px) (void)hipFree(px);
+                if (pf) (void)hipFree(pf);
+                (void)hipGetLastError();
+            }
+        }
+        if (ctx->feco_xchg) {
+            const unsigned launch = ++ctx->feco_epoch;  // (0 is what a fresh flag word holds: never a launch id)
+            if (launch == 0) ctx->feco_epoch = 1;
+            // tags repeat every 2^15 launches: the words of the last cycle are wiped before they could be taken for new ones
+            if ((ctx->feco_epoch & 0x7FFFu) == 1u &&
+                hipMemsetAsync(ctx->feco_xchg, 0, words * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
+                return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: hipMemsetAsync failed");
+            pr.on = 1;
+            pr.xchg = ctx->feco_xchg;
+            pr.flags = ctx->feco_flags;
+            pr.launch = ctx->feco_epoch;
+            pr.tag0 = (ctx->feco_epoch & 0x7FFFu) << 6;
+            if (ctx->lose_handoffs > 0) {  // test hook (sg_debug_lose_handoffs): this launch's second halves publish nothing
+                pr.drop = 1;
+                --ctx->lose_handoffs;
+            }
+        }
+    }
+    const int halves = pr.on ? 2 : 1;
     if (nunits <= 2 * kWaves) {
         sched.table = 1;
-        int simd_load[4] = {0, 0, 0, 0}, wave_load[kWaves] = {}, wave_n[kWaves] = {};
-        for (int w = 0; w < kWaves; ++w) sched.u[w][0] = sched.u[w][1] = kFecoNoUnit;
+        pr.sched1.table = 1;
+        // bins: the SIMDs of the block (of both blocks): a unit goes to the least loaded SIMD and there to the least loaded
+        // wave with a free slot
+        int simd_load[8] = {}, wave_load[2 * kWaves] = {}, wave_n[2 * kWaves] = {};
+        for (int w = 0; w < kWaves; ++w) sched.u[w][0] = sched.u[w][1] = pr.sched1.u[w][0] = pr.sched1.u[w][1] = kFecoNoUnit;
+        auto bin = [&](int w) { return (w / kWaves) * 4 + (w & 3); };
         for (int size = ntc; size >= 1; --size)
             for (int u = 0; u < nunits; ++u) {
                 const int ft = u / JC, jc = u - ft * JC, lo = ntc * jc / JC, hi = ntc * (jc + 1) / JC;
                 if (hi - lo != size) continue;
                 int best_w = -1;
-                for (int w = 0; w < kWaves; ++w) {
+                for (int w = 0; w < halves * kWaves; ++w) {
                     if (wave_n[w] >= 2) continue;
-                    if (best_w < 0 || simd_load[w & 3] < simd_load[best_w & 3] ||
-                        (simd_load[w & 3] == simd_load[best_w & 3] && wave_load[w] < wave_load[best_w]))
+                    if (best_w < 0 || simd_load[bin(w)] < simd_load[bin(best_w)] ||
+                        (simd_load[bin(w)] == simd_load[bin(best_w)] && wave_load[w] < wave_load[best_w]))
                         best_w = w;
                 }
-                sched.u[best_w][wave_n[best_w]++] = (unsigned)ft | (unsigned)lo << 8 | (unsigned)hi << 16 | (unsigned)jc << 24;
+                const unsigned word = (unsigned)ft | (unsigned)lo << 8 | (unsigned)hi << 16 | (unsigned)jc << 24;
+                if (best_w < kWaves) sched.u[best_w][wave_n[best_w]] = word;
+                else {
+                    pr.sched1.u[best_w - kWaves][wave_n[best_w]] = word;
+                    pr.owner |= 1u << u;
+                }
+                ++wave_n[best_w];
                 wave_load[best_w] += size;
-                simd_load[best_w & 3] += size;
+                simd_load[bin(best_w)] += size;
             }
     }
     const int x_in_lds = bytes(JC, 0, 1) <= kLdsMax;
@@ -676,11 +829,11 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     if (dpad == 32)
-        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B, reps), dim3(kFecoThreads), lds, (hipStream_t)stream, feats_dev, F, D, k,
-                           max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, assign_dev, out_dev, counts_dev);
+        hipLaunchKernelGGL(feco_kmeans_kernel<32>, dim3(B, reps, pr.on ? 2 : 1), dim3(kFecoThreads), lds, (hipStream_t)stream, feats_dev, F,
+                           D, k, max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, pr, assign_dev, out_dev, counts_dev);
     else
         hipLaunchKernelGGL(feco_kmeans_kernel<64>, dim3(B, reps), dim3(kFecoThreads), lds, (hipStream_t)stream, feats_dev, F, D, k,
-                           max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, assign_dev, out_dev, counts_dev);
+                           max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, pr, assign_dev, out_dev, counts_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
     static const bool tr_on = getenv("SG_FECO_TRACE") != nullptr;
@@ -709,6 +862,12 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
             }
         }
     }
+    return SG_OK;
+}
+
+extern "C" int sg_feco_set_two_cu(sg_ctx* ctx, int32_t mode) {
+    if (!ctx || mode < -1 || mode > 0) return SG_ERR_ARG;
+    ctx->feco_two_cu = mode;
     return SG_OK;
 }
 

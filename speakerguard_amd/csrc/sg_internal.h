@@ -245,6 +245,12 @@ struct sg_ctx {
     unsigned* err_dev = nullptr;
     bool use_streamk = true;         // sg_set_streamk
     int lose_handoffs = 0;           // sg_debug_lose_handoffs: stream-K launches left that publish no hand-off flags
+    // FeCo k-means over two CUs per instance (k_feco.hip): exchange buffers + flags, the launch counter the flag values
+    // are derived from, and the switch (sg_feco_set_two_cu: -1 where it fits, 0 never)
+    unsigned long long* feco_xchg = nullptr;
+    unsigned* feco_flags = nullptr;
+    unsigned feco_epoch = 0;
+    int feco_two_cu = -1;
     sg::AnTables an_tab{};
     sg::AnFrontCfg an_cfg{};
     bool an_tables_ready = false;

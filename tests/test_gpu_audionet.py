@@ -353,6 +353,31 @@ def test_fused_cnn_random_shapes(hip, dev, monkeypatch):
     log("audionet fused CNN: %d random shapes (B 1..7, 0.25..9 s, random cuts) equal the per-layer sequence bit for bit; 180 s falls back" % len(shapes))
 
 
+def test_frontend_picks_the_fused_overlap_add_for_large_batches(sd, dev):
+    """sg_an_configure's default (fused_overlap_add = -1): the library takes the overlap-add inside the adjoint where cutting
+    utterances into runs (5 halo frames each) costs little -- 256 utterances of 3 s --, the separate pair for a handful; the
+    iterate it steps to is the same either way (the runs here are real cuts: 12 per utterance)."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.audionet_csine import audionet_csine
+    m = audionet_csine.from_weights(sd, device=dev)
+    spec = SEC4SR_CrossEntropy()
+    got = {}
+    for B in (4, 256):
+        x = torch.from_numpy(synth.make_waveforms(B, 48000, seed=70 + B)).to(dev)
+        y = m.make_decision(x)[0]
+        lower, upper = torch.clamp(x - 0.002, min=-1), torch.clamp(x + 0.002, max=1)
+        for ola in (None, False, True):
+            m.configure_frontend(32, True, ola)
+            tags = [t for t, _ in m.trace_stages(lambda: got.__setitem__((B, ola), m.pgd_run(x, y, lower, upper, spec, 0.0004, 2, 1)[0]),
+                                                 max_records=128)]
+            fused = "an_logmel_bwd" in tags and "an_overlap_add" not in tags
+            assert "an_logmel_bwd" in tags, tags
+            assert fused == (ola is True or (ola is None and B == 256)), (B, ola, tags)
+        assert torch.equal(got[(B, None)], got[(B, False)]) and torch.equal(got[(B, None)], got[(B, True)]), B
+    m.configure_frontend()
+
+
 @pytest.mark.parametrize("bits", [32, 64])
 @pytest.mark.parametrize("B,T", [(3, 48000), (2, 20011), (1, 16000), (5, 4000), (2, 6000), (9, 65000)])
 def test_overlap_add_inside_the_adjoint_equals_the_separate_pair(sd, dev, bits, B, T):

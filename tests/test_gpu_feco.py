@@ -113,6 +113,39 @@ def test_seeded_random_init_matches_restatement_and_is_keyed_by_position():
         log("FeCo k-means, seeded random init %s: ids bit-exact vs Philox restatement; fresh per call; shard-invariant" % name)
 
 
+def test_two_compute_units_per_instance_give_the_same_clustering():
+    """Round 5: an instance's k-means runs on two compute units when the batch leaves room (both blocks compute the same
+    clustering and share the assignment step's work, sg_feco_set_two_cu).  Same ids, means and counts as one block per
+    instance -- and as a run whose second blocks publish NOTHING (fault injection): the first blocks time out after 20 us and
+    compute everything themselves, the second ones find the give-up mark and do the same."""
+    from speakerguard_amd import _native as N
+    from speakerguard_amd.metric.metric import _context
+    ctx = _context(DEV)
+    rs = np.random.RandomState(31)
+    for B, F, D, reps in ((64, 300, 32, 2), (5, 300, 30, 1), (3, 130, 13, 4)):
+        feat = torch.from_numpy((rs.randn(B, F, D) * 10 - 40).astype(np.float32)).to(DEV)
+        k = F // 2
+        got = {}
+        for mode in ("one", "two", "two, partner silent"):
+            ctx.call("sg_feco_set_two_cu", 0 if mode == "one" else -1)
+            if mode.endswith("silent"):
+                ctx.call("sg_debug_lose_handoffs", 1)
+            ids = torch.empty(reps * B, F, device=DEV, dtype=torch.int32)
+            out = torch.empty(reps * B, k, D, device=DEV)
+            counts = torch.empty(reps * B, k, device=DEV, dtype=torch.int32)
+            ctx.call("sg_feco_kmeans_compress", N._ptr(feat), B, F, D, k, 10, 1, 77, 3, reps, N._ptr(ids), N._ptr(out), N._ptr(counts),
+                     N.current_stream_ptr(DEV))
+            torch.cuda.synchronize()
+            got[mode] = (ids.clone(), out.clone(), counts.clone())
+        ctx.call("sg_debug_lose_handoffs", 0)
+        ctx.call("sg_feco_set_two_cu", -1)
+        for mode in ("two", "two, partner silent"):
+            for a, b in zip(got["one"], got[mode]):
+                assert torch.equal(a, b), (B, F, D, reps, mode)
+        assert got["one"][0].min().item() >= 0 and got["one"][2].sum().item() == reps * B * F
+    log("FeCo k-means on two compute units per instance: ids, means, counts equal to one block per instance, also with a silent partner")
+
+
 def test_kmeans_refuses_what_does_not_fit():
     from speakerguard_amd import _native as N
     from speakerguard_amd.defense.feature_level import FeCoDefense
