@@ -122,7 +122,7 @@ def measure(dev, reps=3, xv_weights=None, extras=False):
                          "value": 1e3 * dt / K, "unit": "ms/step", "samples": [1e3 * d / K for d in dts], "success": "%d/64" % sum(succ),
                          "frac_f32_mfma_peak": _frac(g3, dt),
                          "roofline_hbm": _hbm(AN_BYTES_MANDATORY, 64 * K, dt), "roofline_hbm_as_built": _hbm(AN_BYTES_AS_BUILT, 64 * K, dt),
-                         "bound": "latency: k-means (one CU per utterance and repeat, ~5 Lloyd iterations of ~15 us) + ~25 launches per step"}
+                         "bound": "latency: k-means (two CUs per utterance and repeat, ~5 Lloyd iterations of ~13 us + 16 us set-up) + the fused CNN at 128 rows"}
     for b in (64, 512):
         xb = torch.from_numpy(synth.make_waveforms(b, T, seed=5)).to(dev)
         yb = an.make_decision(xb)[0]
