@@ -143,7 +143,25 @@ def test_two_compute_units_per_instance_give_the_same_clustering():
             for a, b in zip(got["one"], got[mode]):
                 assert torch.equal(a, b), (B, F, D, reps, mode)
         assert got["one"][0].min().item() >= 0 and got["one"][2].sum().item() == reps * B * F
-    log("FeCo k-means on two compute units per instance: ids, means, counts equal to one block per instance, also with a silent partner")
+    # the exchange words carry 15 bits of launch counter: past 2^15 launches of one context the buffers are wiped and the
+    # tags start over -- 33 000 small clusterings later the answer is still the one-block one
+    feat = torch.from_numpy(rs.randn(2, 96, 8).astype(np.float32)).to(DEV)
+    ids = torch.empty(2, 96, device=DEV, dtype=torch.int32)
+    out = torch.empty(2, 48, 8, device=DEV)
+    counts = torch.empty(2, 48, device=DEV, dtype=torch.int32)
+    args = (N._ptr(feat), 2, 96, 8, 48, 10, 1, 5, 0, 1, N._ptr(ids), N._ptr(out), N._ptr(counts), N.current_stream_ptr(DEV))
+    ctx.call("sg_feco_set_two_cu", 0)
+    ctx.call("sg_feco_kmeans_compress", *args)
+    torch.cuda.synchronize()
+    want = (ids.clone(), out.clone(), counts.clone())
+    ctx.call("sg_feco_set_two_cu", -1)
+    for i in range(33000):
+        ctx.call("sg_feco_kmeans_compress", *args)
+        if i % 8192 == 8191 or i == 32999:
+            torch.cuda.synchronize()
+            assert torch.equal(ids, want[0]) and torch.equal(out, want[1]) and torch.equal(counts, want[2]), i
+    log("FeCo k-means on two compute units per instance: ids, means, counts equal to one block per instance, also with a silent partner "
+        "and across the wrap of the exchange tags (33 000 launches)")
 
 
 def test_kmeans_refuses_what_does_not_fit():
