@@ -21,7 +21,7 @@ $(ORACLE_SO): oracle/conv_chain.c
 
 oracle: $(ORACLE_SO)
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h $(CSRC)/fft512.h $(CSRC)/loss_device.h include/speakerguard_hip.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h $(CSRC)/fft512.h $(CSRC)/fft512t.h $(CSRC)/loss_device.h include/speakerguard_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
