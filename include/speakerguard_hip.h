@@ -65,6 +65,16 @@ int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches);
  * everything itself: same bits, the one-unit speed.  mode -1: where it fits (default); 0: never.
  * (sg_debug_lose_handoffs also covers this protocol: a launch it counts makes every second block publish nothing.) */
 int sg_feco_set_two_cu(sg_ctx* ctx, int32_t mode);
+/* TEST HOOK (no production use): parks the launch counter of the two-unit k-means protocol, so that a test reaches the wrap
+ * of the exchange words' 15-bit launch tag (and of the 32-bit counter itself) in a handful of launches instead of 2^15.  The
+ * counter only moves the way real launches move it from there on -- the wipe of the exchange buffer at a tag wrap included. */
+int sg_debug_feco_epoch(sg_ctx* ctx, uint32_t epoch);
+
+/* How the x-vector front-end's 512-point transforms run (forward and adjoint): fft_bits 32 (default) = float32, the
+ * reference's own precision (torchaudio 0.6's kaldi.mfcc is float32 end to end, model/xv_plda.py:114-148); 64 = float64
+ * transforms around the same float32 stages (the form of rounds 1-5, kept as the counterpart).  Takes effect from the next
+ * pass; results of the two differ by float32 round-off of the spectrum. */
+int sg_xv_configure(sg_ctx* ctx, int32_t fft_bits);
 
 /* ---- x-vector + PLDA model ----------------------------------------------------------------
  * Replaces the tensors the reference holds after model/xv_plda.py:17-47 ran: the xvecTDNN

@@ -23,7 +23,7 @@ EXPORTS = (
     "sg_an_load", "sg_an_num_frames", "sg_an_logmel", "sg_an_forward", "sg_an_debug_activation", "sg_an_loss_grad",
     "sg_an_pgd_run", "sg_an_pgd_run_feco", "sg_conv1d_rows", "sg_wav_finalize", "sg_eer_threshold",
     "sg_xv_mfcc_backward", "sg_xv_cmvn_backward", "sg_feco_kmeans", "sg_feco_kmeans_seeded", "sg_feco_kmeans_compress", "sg_feco_compress_backward_reps", "sg_feco_compress", "sg_feco_compress_backward",
-    "sg_an_logmel_backward", "sg_an_configure", "sg_xv_enroll_override", "sg_health", "sg_set_streamk", "sg_debug_lose_handoffs", "sg_feco_set_two_cu", "sg_trace_begin", "sg_trace_end",
+    "sg_an_logmel_backward", "sg_an_configure", "sg_xv_configure", "sg_xv_enroll_override", "sg_health", "sg_set_streamk", "sg_debug_lose_handoffs", "sg_debug_feco_epoch", "sg_feco_set_two_cu", "sg_trace_begin", "sg_trace_end",
 )
 
 # stage tags of sg_trace_end (include/speakerguard_hip.h); +l / -l = forward / data-gradient contraction of TDNN layer l
@@ -108,6 +108,8 @@ def load():
         "sg_health": (C.c_int, [vp]),
         "sg_set_streamk": (C.c_int, [vp, i32]),
         "sg_debug_lose_handoffs": (C.c_int, [vp, i32]),
+        "sg_debug_feco_epoch": (C.c_int, [vp, C.c_uint32]),
+        "sg_xv_configure": (C.c_int, [vp, i32]),
         "sg_feco_set_two_cu": (C.c_int, [vp, i32]),
         "sg_trace_begin": (C.c_int, [vp, i32]),
         "sg_trace_end": (C.c_int, [vp, vp, vp, i32, C.POINTER(i32)]),

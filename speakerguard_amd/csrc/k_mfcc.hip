@@ -21,16 +21,30 @@
 // place and is transformed back by the same FFT with conjugate twiddles.  It writes per-frame sample
 // gradients (B,F,400); frames_to_wave_kernel does the deterministic overlap-add.
 #include "sg_internal.h"
-#include "fft512.h"
+#include "fft512t.h"
 
 namespace sg {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kMfccMaxBlocks = 512;  // 2 blocks (59 KB LDS each) per CU x 256 CUs
+constexpr int kMfccMaxBlocks = 512;  // 2 blocks (~60 KB LDS each) per CU x 256 CUs
 
-struct FrameLds {
-    double2 spec[kFft + kFft / 8];  // FFT work buffer (element i at SP(i)): spectrum, then its gradient; fp64
-    float samp[kFft];    // DC-removed samples, later windowed-gradient
+// Round 6: the per-frame functions are templates over the transform's scalar type R.
+//   R = float  (default): the reference's own precision -- torchaudio 0.6's kaldi.mfcc is float32 end to end, torch.rfft
+//              included (model/xv_plda.py:114-148) -- on the transform-order / transposed-network pair of fft512t.h: the
+//              forward transform leaves bin k1 + 8 c + 64 d in registers of lane (k1, c), power, spectrum cache and the
+//              gradient spectrum are formed right there, and the TRANSPOSED inverse takes that layout and returns
+//              samples lane + 64 j in registers, where window, pre-emphasis adjoint (a whole-wave DPP shift), energy and DC
+//              terms are applied: two LDS exchanges per transform and none around it (rounds 1-5: five, plus the spectrum
+//              and sample round trips).  8-byte LDS elements, 8 waves per block, 4 waves per SIMD.
+//   R = double (sg_xv_configure(ctx, 64)): the same code on float64 transforms, the form of rounds 1-5 kept as the
+//              counterpart (a windowed speech frame has > 80 dB between its strongest harmonic and the weak bins; a float32
+//              transform leaves a round-off floor of ~1e-7 of the strongest bin on every bin, float64 does not).
+template <typename R> struct MfccCfg;
+template <> struct MfccCfg<float> { static constexpr int kWaves = 8; };
+template <> struct MfccCfg<double> { static constexpr int kWaves = 4; };
+
+template <typename R>
+struct FrameLdsT {
+    cx<R> spec[kFft + kFft / 8];  // the transform's exchange buffer (element i at SP(i))
     float power[256];
     float mel[32];
     float lmel[32];
@@ -40,12 +54,13 @@ struct FrameLds {
 // Every LDS buffer in this file is private to one wave, and a wave's DS instructions execute in
 // program order, so cross-lane hand-offs through LDS need no s_barrier -- only a fence that stops
 // the compiler from moving LDS accesses across it (a block-wide __syncthreads() here coupled the
-// four independent waves at ~25 points per frame).
+// independent waves at ~25 points per frame).
 // Constant tables staged once per block into LDS: every per-frame table access was a dependent global
-// load (L1/L2 hit, but ~0.3 us of latency each with only 2 waves per SIMD to hide it).
-struct TabLds {
-    double2 tw1[kFftTw1];  // pass-1 / pass-2 twiddles as the lanes read them (fft512.h)
-    double2 tw2[kFftTw2];
+// load (L1/L2 hit, but ~0.3 us of latency each with few waves per SIMD to hide it).
+template <typename R>
+struct TabLdsT {
+    cx<R> tw1[kFftTw1];  // pass-1 / pass-2 twiddles as the lanes read them (fft512.h), float64 values rounded once to R
+    cx<R> tw2[kFftTw2];
     float window[kWin];
     float dct[kMel * kCep];
     float lifter[32];
@@ -56,8 +71,9 @@ struct TabLds {
     int mel_hi[32];
 };
 
-__device__ __forceinline__ void stage_tables(const MfccTables& t, TabLds& tb) {
-    fft512_fill_tables(t.twiddle, tb.tw1, tb.tw2);
+template <typename R>
+__device__ __forceinline__ void stage_tables(const MfccTables& t, TabLdsT<R>& tb) {
+    fft512_fill_tablesT<R>(t.twiddle, tb.tw1, tb.tw2);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         tb.bin_m0[i] = t.bin_m0[i];
         tb.bin_w0[i] = t.bin_w0[i];
@@ -129,7 +145,6 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ x, int T, i
     }
 }
 
-// Forward of one frame up to the cepstra; leaves spectrum in L.spec, mel in L.mel, samples in L.samp.
 // Table entries a lane needs for EVERY frame, hoisted into registers once per kernel: the weights of the bins
 // its half of a mel filter sums (ascending bin order, zero-padded: adding power * 0 leaves the sum unchanged, so
 // the result is bit-identical to a loop over the exact range), and its column of the DCT matrix.  Per frame the
@@ -142,7 +157,8 @@ struct LaneConst {
     float dct_col[kMel];        // dct[m][lane] * 1 (lane < kCep)
 };
 
-__device__ __forceinline__ void lane_const_init(const TabLds& tb, int lane, LaneConst& lc) {
+template <typename R>
+__device__ __forceinline__ void lane_const_init(const TabLdsT<R>& tb, int lane, LaneConst& lc) {
     const int m = lane >> 1, h = lane & 1;
     int k0 = 0, cnt = 0;
     if (m < kMel) {
@@ -161,24 +177,26 @@ __device__ __forceinline__ void lane_const_init(const TabLds& tb, int lane, Lane
     for (int mm = 0; mm < kMel; ++mm) lc.dct_col[mm] = lane < kCep ? tb.dct[mm * kCep + lane] : 0.f;
 }
 
+// No implicit contraction in the per-frame arithmetic (as in fft512t.h): the same functions are instantiated in the forward
+// kernel and in both backward kernels and must give the same bits there; every fused multiply-add is written out.
+#pragma clang fp contract(off)
+
 // MODE 0: full forward (writes the spectrum / mel cache when t.spec_cache is set); MODE 1: backward with a cache:
 // only the sample statistics are recomputed, spectrum and mel energies are read back (no FFT, no mel/DCT loops).
-// WANT_SPEC (the backward kernels): Xk[i] = the spectrum at bin lane + 64 i, in registers.
-// The transform's input and output stay out of the 16-byte LDS traffic where they can: the windowed frame is real and
-// zero beyond sample 399, so pass 1 takes it as 7 floats per lane (from L.samp, rewritten in place) instead of 8 complex
-// doubles; pass 3 leaves bins k1 + 8 c + 64 d (d < 4: the 256 bins that exist) in registers, and power, spectrum cache and
-// -- for the backward -- the gradient spectrum are computed from there without writing the transform back.
-template <int MODE, bool WANT_SPEC>
-__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds& tb, const LaneConst& lc, FrameLds& L,
-                                              const float (&raw)[7], int F, int b, int f, bool active, float scale,
-                                              const sg_dither& dz, int lane, FrameState& st, float& cep_out,
-                                              double2 (&Xk)[4]) {
+// Xk[d] = the spectrum at bin (lane >> 3) + 8 (lane & 7) + 64 d ("transform order", fft512t.h), d < 4: the 256 bins that
+// exist, in registers.  The transform's input stays out of LDS as well: the windowed frame is real and zero beyond sample
+// 399, so pass 1 takes it as 7 values per lane.  The spectrum cache keeps a frame's bins in transform order (element
+// 64 d + lane): written and read back as whole 512-byte rows.
+template <typename R, int MODE>
+__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT<R>& tb, const LaneConst& lc, FrameLdsT<R>& L,
+                                              const float (&raw)[7], const float (&win)[7], int F, int b, int f, float scale,
+                                              const sg_dither& dz, int lane, FrameState& st, float& cep_out, cx<R> (&Xk)[4]) {
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int n = lane + 64 * i;
         float v = 0.f;
-        if (active && n < kWin) {
+        if (n < kWin) {
             v = raw[i] * scale;
             if (dz.noise_dev) v += dz.noise_dev[((size_t)b * F + f) * kWin + n];
             else if (dz.dither != 0.f) {
@@ -202,16 +220,16 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
         const int n = lane + 64 * i;
         if (n < kWin) {
             st.s[i] -= mean;
-            e += st.s[i] * st.s[i];
+            e = __builtin_fmaf(st.s[i], st.s[i], e);
         }
     }
     st.energy = wave_sum(e);
     const size_t gfi = (size_t)b * F + f;
     if (MODE == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 c = t.spec_cache[gfi * 256 + lane + 64 * i];
-            Xk[i] = make_double2((double)c.x, (double)c.y);
+        for (int d = 0; d < 4; ++d) {
+            const float2 c = t.spec_cache[gfi * 256 + 64 * d + lane];
+            Xk[d] = cmk<R>((R)c.x, (R)c.y);
         }
         if (lane < 32) L.mel[lane] = t.mel_cache[gfi * 32 + lane];
         wave_sync();
@@ -220,51 +238,35 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
     }
     // pre-emphasis (replicate pad on the left), povey window -- in registers: sample n - 1 of n = lane + 64 i is the left
     // neighbour lane's s[i] (a whole-wave DPP shift), for lane 0 lane 63's s[i - 1] (sample 0: itself); and the windowed
-    // values w[i] ARE pass 1's inputs x[lane + 64 j] of this lane: no LDS round trip between the samples and the transform
-    float w[7];
+    // values ARE pass 1's inputs x[lane + 64 j] of this lane: no LDS round trip between the samples and the transform
+    cx<R> in[8], out[8];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const int n = lane + 64 * i;
         const float edge = i > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.s[i - 1]), 63)) : st.s[0];
         const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, st.s[i]),
                                                                                   0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-        w[i] = n < kWin ? (st.s[i] - 0.97f * prev) * tb.window[n] : 0.f;
+        in[i] = cmk<R>((R)((st.s[i] - 0.97f * prev) * win[i]), (R)0);  // (win = 0 beyond sample 399)
     }
-    double2 out[8];
-    if (!(t.ablate & 1)) {
-        const double2 z = make_double2(0.0, 0.0);
-        fft512_pass1_t(L.spec, tb.tw1, lane, -1.0, make_double2((double)w[0], 0.0), make_double2((double)w[1], 0.0),
-                       make_double2((double)w[2], 0.0), make_double2((double)w[3], 0.0), make_double2((double)w[4], 0.0),
-                       make_double2((double)w[5], 0.0), make_double2((double)w[6], 0.0), z);
-        fft512_pass2_t(L.spec, tb.tw2, lane, -1.0);
-        fft512_pass3(L.spec, lane, -1.0, out);
-    } else {
-#pragma unroll
-        for (int d = 0; d < 8; ++d) out[d] = make_double2(0.0, 0.0);
-    }
+    in[7] = cmk<R>((R)0, (R)0);
+    fft512T_regs<R>(L.spec, tb.tw1, tb.tw2, lane, (R)-1, in, out);
     {
-        const int kb = (lane >> 3) + 8 * (lane & 7);  // this lane's bins after pass 3: kb + 64 d
+        const int kb = (lane >> 3) + 8 * (lane & 7);  // this lane's bins: kb + 64 d
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int k = kb + 64 * d;
-            const double2 c = out[d];
-            L.power[k] = (float)(c.x * c.x + c.y * c.y);
-            if (t.spec_cache) t.spec_cache[gfi * 256 + k] = make_float2((float)c.x, (float)c.y);
-            if (WANT_SPEC) L.spec[SP(k)] = c;  // (the transform's buffer is free again: pass 3 ended with a fence)
+            const cx<R> c = out[d];
+            Xk[d] = c;
+            L.power[kb + 64 * d] = (float)fmaT(c.x, c.x, c.y * c.y);
+            if (t.spec_cache) t.spec_cache[gfi * 256 + 64 * d + lane] = make_float2((float)c.x, (float)c.y);
         }
     }
     wave_sync();
-    if (WANT_SPEC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Xk[i] = L.spec[SP(lane + 64 * i)];
-    }
     // 30 triangular mel filters, two lanes per filter (each sums half of the filter's bins); the weight
     // of bin k in filter m is bin_w0[k] if m is the lower of the two filters covering k, else bin_w1[k]
-    if (!(t.ablate & 2)) {
+    {
         const int m = lane >> 1, h = lane & 1;
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMelLaneBins; ++j) acc += L.power[min(lc.mel_k0 + j, 255)] * lc.mel_w[j];
+        for (int j = 0; j < kMelLaneBins; ++j) acc = __builtin_fmaf(L.power[min(lc.mel_k0 + j, 255)], lc.mel_w[j], acc);
         acc += __shfl_xor(acc, 1, 64);
         if (m < kMel && h == 0) {
             L.mel[m] = acc;
@@ -274,42 +276,52 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLds&
     }
     wave_sync();
     cep_out = 0.f;
-    if (lane < kCep && !(t.ablate & 2)) {
+    if (lane < kCep) {
         float v = 0.f;
 #pragma unroll
-        for (int m = 0; m < kMel; ++m) v += L.lmel[m] * lc.dct_col[m];
+        for (int m = 0; m < kMel; ++m) v = __builtin_fmaf(L.lmel[m], lc.dct_col[m], v);
         v *= tb.lifter[lane];
         if (lane == 0) v = logf(fmaxf(st.energy, kEps));
         cep_out = v;
     }
 }
 
-__global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
-                                                       const float* __restrict__ scale_p, sg_dither dz,
-                                                       float* __restrict__ feats) {
-    __shared__ FrameLds lds[kWavesPerBlock];
-    __shared__ TabLds tb;
-    stage_tables(t, tb);
+// the povey window at this lane's samples n = lane + 64 i (zero beyond sample 399)
+template <typename R>
+__device__ __forceinline__ void lane_window(const TabLdsT<R>& tb, int lane, float (&win)[7]) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) win[i] = lane + 64 * i < kWin ? tb.window[lane + 64 * i] : 0.f;
+}
+
+template <typename R>
+__global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_fwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
+                                                                          const float* __restrict__ scale_p, sg_dither dz,
+                                                                          float* __restrict__ feats) {
+    constexpr int kWaves = MfccCfg<R>::kWaves;
+    __shared__ FrameLdsT<R> lds[kWaves];
+    __shared__ TabLdsT<R> tb;
+    stage_tables<R>(t, tb);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
-    FrameLds& L = lds[wid];
+    FrameLdsT<R>& L = lds[wid];
     LaneConst lc;
-    lane_const_init(tb, lane, lc);
+    lane_const_init<R>(tb, lane, lc);
+    float win[7];
+    lane_window<R>(tb, lane, win);
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
-    const int total = B * F, stride = gridDim.x * kWavesPerBlock;
+    const int total = B * F, stride = gridDim.x * kWaves;
     float raw[7], nxt[7];
-    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt, t.rep_utts);
-    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += stride) {
+    load_frame(x, T, F, blockIdx.x * kWaves + wid, total, lane, nxt, t.rep_utts);
+    for (int gf = blockIdx.x * kWaves + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
-        const bool active = true;
 #pragma unroll
         for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
         load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
         FrameState st;
         float cep;
-        double2 Xk[4];
-        frame_forward<0, false>(t, tb, lc, L, raw, F, b, f, active, scale, dz, lane, st, cep, Xk);
-        if (active && lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
+        cx<R> Xk[4];
+        frame_forward<R, 0>(t, tb, lc, L, raw, win, F, b, f, scale, dz, lane, st, cep, Xk);
+        if (lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
 }
@@ -318,50 +330,53 @@ __global__ __launch_bounds__(256) void mfcc_fwd_kernel(MfccTables t, const float
 // already multiplied by `scale` (the int16 rescale of check_input_range, model/utils.py:14).
 // CACHED: the forward kernel of the same pass left spectrum + mel energies in t.spec_cache / t.mel_cache (the attack
 // loop); otherwise the forward is recomputed here (standalone sg_xv_mfcc_backward).  Two instantiations so that the
-// cached one does not carry the forward's lane constants (it would drop to one wave per SIMD).
-template <bool CACHED>
-__global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
-                                                       const float* __restrict__ scale_p, sg_dither dz,
-                                                       const float* __restrict__ dfeats, int ld,
-                                                       float* __restrict__ dframes) {
-    __shared__ FrameLds lds[kWavesPerBlock];
-    __shared__ TabLds tb;
-    stage_tables(t, tb);
+// cached one does not carry the forward's lane constants.
+template <typename R, bool CACHED>
+__global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_bwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
+                                                                          const float* __restrict__ scale_p, sg_dither dz,
+                                                                          const float* __restrict__ dfeats, int ld,
+                                                                          float* __restrict__ dframes) {
+    constexpr int kWaves = MfccCfg<R>::kWaves;
+    __shared__ FrameLdsT<R> lds[kWaves];
+    __shared__ TabLdsT<R> tb;
+    stage_tables<R>(t, tb);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
-    FrameLds& L = lds[wid];
+    FrameLdsT<R>& L = lds[wid];
     LaneConst lc;
-    if (!CACHED) lane_const_init(tb, lane, lc);
+    if (!CACHED) lane_const_init<R>(tb, lane, lc);
+    float win[7];
+    lane_window<R>(tb, lane, win);
     // backward-only lane constants: row `lane` of the DCT matrix, and the mel membership of this lane's four bins
+    // (transform order: bin kb + 64 d)
     float dct_row[kCep];
 #pragma unroll
     for (int c = 0; c < kCep; ++c) dct_row[c] = lane < kMel ? tb.dct[lane * kCep + c] : 0.f;
+    const int kb = (lane >> 3) + 8 * (lane & 7);
     int bin_m0[4];
     float bin_w0[4], bin_w1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bin_m0[i] = tb.bin_m0[lane + 64 * i];
-        bin_w0[i] = tb.bin_w0[lane + 64 * i];
-        bin_w1[i] = tb.bin_w1[lane + 64 * i];
+    for (int d = 0; d < 4; ++d) {
+        bin_m0[d] = tb.bin_m0[kb + 64 * d];
+        bin_w0[d] = tb.bin_w0[kb + 64 * d];
+        bin_w1[d] = tb.bin_w1[kb + 64 * d];
     }
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
-    const int total = B * F, stride = gridDim.x * kWavesPerBlock;
+    const int total = B * F, stride = gridDim.x * kWaves;
     float raw[7], nxt[7];
-    load_frame(x, T, F, blockIdx.x * kWavesPerBlock + wid, total, lane, nxt, t.rep_utts);
-    for (int gf = blockIdx.x * kWavesPerBlock + wid; gf < total; gf += stride) {
+    load_frame(x, T, F, blockIdx.x * kWaves + wid, total, lane, nxt, t.rep_utts);
+    for (int gf = blockIdx.x * kWaves + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
-        const bool active = true;
 #pragma unroll
         for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
         load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
-        const int fa = active ? f : 0;
         FrameState st;
         float cep;
-        double2 Xk[4];
-        frame_forward<CACHED ? 1 : 0, true>(t, tb, lc, L, raw, F, b, fa, active, scale, dz, lane, st, cep, Xk);
+        cx<R> Xk[4];
+        frame_forward<R, CACHED ? 1 : 0>(t, tb, lc, L, raw, win, F, b, f, scale, dz, lane, st, cep, Xk);
         // ---- cepstra -> log-mel
         float dc = 0.f;
-        if (active && lane < kCep) dc = dfeats[((size_t)b * F + fa) * ld + lane];
+        if (lane < kCep) dc = dfeats[((size_t)b * F + f) * ld + lane];
         const float denergy = __shfl(dc, 0, 64);
         if (lane < 32) L.tmp[lane] = (lane == 0 || lane >= kCep) ? 0.f : dc * tb.lifter[lane];
         wave_sync();
@@ -370,73 +385,62 @@ __global__ __launch_bounds__(256) void mfcc_bwd_kernel(MfccTables t, const float
             if (lane < kMel) {
                 float dl = 0.f;
 #pragma unroll
-                for (int c = 0; c < kCep; ++c) dl += L.tmp[c] * dct_row[c];
+                for (int c = 0; c < kCep; ++c) dl = __builtin_fmaf(L.tmp[c], dct_row[c], dl);
                 const float mel = L.mel[lane];
                 dm = mel > kEps ? dl / mel : 0.f;
             }
             L.lmel[lane] = dm;  // d loss / d mel energy (entries 30,31 = 0)
         }
         wave_sync();
-        // ---- mel -> power -> spectrum gradient G[k] = 2 X[k] dP[k] at this lane's bins k = lane + 64 i, i < 4 -- which are
-        //      exactly pass 1's inputs x[n2 + 64 j] of lane n2 (j >= 4: bins 256..511, zero): the gradient spectrum goes
-        //      into the inverse transform from registers.  Pass 3 leaves samples k1 + 8 c + 64 d in registers; their real
-        //      part times the window goes straight to L.samp (samples 0..399).
-        double2 g[4];
+        // ---- mel -> power -> spectrum gradient G[k] = 2 X[k] dP[k] at this lane's bins, in transform order -- the layout the
+        //      TRANSPOSED inverse network takes (d >= 4: bins 256..511, zero); it returns samples lane + 64 j in registers.
+        cx<R> v[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            g[i] = make_double2(0.0, 0.0);
-            const int m0 = bin_m0[i];
+        for (int d = 0; d < 4; ++d) {
+            v[d] = cmk<R>((R)0, (R)0);
+            const int m0 = bin_m0[d];
             if (m0 >= 0) {
-                const double dp = 2.0 * (double)(L.lmel[m0] * bin_w0[i] + L.lmel[m0 + 1] * bin_w1[i]);
-                g[i] = make_double2(Xk[i].x * dp, Xk[i].y * dp);
+                const R dp = (R)(2.f * __builtin_fmaf(L.lmel[m0], bin_w0[d], L.lmel[m0 + 1] * bin_w1[d]));
+                v[d] = cmk<R>(Xk[d].x * dp, Xk[d].y * dp);
             }
         }
-        {
-            double2 out[8];
-            if (!(t.ablate & 1)) {
-                const double2 z = make_double2(0.0, 0.0);
-                fft512_pass1_t(L.spec, tb.tw1, lane, 1.0, g[0], g[1], g[2], g[3], z, z, z, z);
-                fft512_pass2_t(L.spec, tb.tw2, lane, 1.0);
-                fft512_pass3(L.spec, lane, 1.0, out);
-            } else {
 #pragma unroll
-                for (int d = 0; d < 8; ++d) out[d] = make_double2(0.0, 0.0);
-            }
-            // ---- window, pre-emphasis, energy, DC removal
-            const int nb = (lane >> 3) + 8 * (lane & 7);
+        for (int d = 4; d < 8; ++d) v[d] = cmk<R>((R)0, (R)0);
+        fft512T_transposed<R>(L.spec, tb.tw1, tb.tw2, lane, (R)1, v);
+        // ---- window, pre-emphasis (sample n + 1 is the right neighbour lane's, lane 63: lane 0's next register), energy,
+        //      DC removal
+        float sw[8];
 #pragma unroll
-            for (int d = 0; d < 7; ++d) {
-                const int n = nb + 64 * d;
-                if (n < kWin) L.samp[n] = (float)out[d].x * tb.window[n];
-            }
-        }
-        wave_sync();
+        for (int i = 0; i < 7; ++i) sw[i] = (float)v[i].x * win[i];
+        sw[7] = 0.f;
         float ds[7];
         float sum = 0.f;
         const float einv = st.energy > kEps ? 2.f * denergy / st.energy : 0.f;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int n = lane + 64 * i;
-            float v = 0.f;
+            const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sw[i + 1]), 0));
+            const float next = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, sw[i]),
+                                                                                      0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+            float g = 0.f;
             if (n < kWin) {
-                v = L.samp[n] - (n + 1 < kWin ? 0.97f * L.samp[n + 1] : 0.f);
-                if (n == 0) v -= 0.97f * L.samp[0];
-                v += einv * st.s[i];
+                g = sw[i] - 0.97f * next;  // (sample 400 does not exist: its sw is 0)
+                if (n == 0) g -= 0.97f * sw[0];
+                g = __builtin_fmaf(einv, st.s[i], g);
             }
-            ds[i] = v;
-            sum += v;
+            ds[i] = g;
+            sum += g;
         }
         const float mean = wave_sum(sum) / (float)kWin;
-        if (active) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const int n = lane + 64 * i;
-                if (n < kWin) dframes[((size_t)b * F + f) * kWin + n] = (ds[i] - mean) * scale;
-            }
+        for (int i = 0; i < 7; ++i) {
+            const int n = lane + 64 * i;
+            if (n < kWin) dframes[((size_t)b * F + f) * kWin + n] = (ds[i] - mean) * scale;
         }
         wave_sync();
     }
 }
+#pragma clang fp contract(fast)
 
 // Deterministic overlap-add: sample n of utterance b gathers, in a fixed order, every frame
 // position that maps to it -- directly, or through the reflected edges of _get_strided.
@@ -532,22 +536,38 @@ __global__ __launch_bounds__(256) void frames_to_wave_kernel(const float* __rest
     }
 }
 
+template <typename R>
+static void mfcc_fwd_launch(const MfccTables& t, const float* x, int B, int T, int F, const float* scale, const sg_dither& d,
+                            float* feats, hipStream_t s) {
+    constexpr int kWaves = MfccCfg<R>::kWaves;
+    const int want = (B * F + kWaves - 1) / kWaves;
+    dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
+    hipLaunchKernelGGL(mfcc_fwd_kernel<R>, grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, feats);
+}
+
+template <typename R>
+static void mfcc_bwd_launch(const MfccTables& t, const float* x, int B, int T, int F, const float* scale, const sg_dither& d,
+                            const float* dfeats, float* dframes, hipStream_t s) {
+    constexpr int kWaves = MfccCfg<R>::kWaves;
+    const int want = (B * F + kWaves - 1) / kWaves;
+    dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
+    if (t.spec_cache) hipLaunchKernelGGL((mfcc_bwd_kernel<R, true>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
+    else hipLaunchKernelGGL((mfcc_bwd_kernel<R, false>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
+}
+
 hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, float* feats, hipStream_t s) {
     sg_dither d = dz ? *dz : sg_dither{0.f, 0, 0, nullptr};
-    const int want = (B * F + kWavesPerBlock - 1) / kWavesPerBlock;
-    dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
-    hipLaunchKernelGGL(mfcc_fwd_kernel, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, feats);
+    if (t.fft64) mfcc_fwd_launch<double>(t, x, B, T, F, scale, d, feats, s);
+    else mfcc_fwd_launch<float>(t, x, B, T, F, scale, d, feats, s);
     return hipGetLastError();
 }
 
 hipError_t launch_mfcc_bwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,
                            const sg_dither* dz, const float* dfeats, float* dframes, hipStream_t s) {
     sg_dither d = dz ? *dz : sg_dither{0.f, 0, 0, nullptr};
-    const int want = (B * F + kWavesPerBlock - 1) / kWavesPerBlock;
-    dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
-    if (t.spec_cache) hipLaunchKernelGGL(mfcc_bwd_kernel<true>, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
-    else hipLaunchKernelGGL(mfcc_bwd_kernel<false>, grid, dim3(256), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
+    if (t.fft64) mfcc_bwd_launch<double>(t, x, B, T, F, scale, d, dfeats, dframes, s);
+    else mfcc_bwd_launch<float>(t, x, B, T, F, scale, d, dfeats, dframes, s);
     return hipGetLastError();
 }
 

@@ -154,9 +154,6 @@ int build_tables(sg_ctx* ctx) {
     }
     MfccTables& t = ctx->tab;
     t.ablate = 0;
-#ifdef SG_EXP_ABLATE  // timing experiments (results become wrong): never in the shipped library
-    if (const char* e = getenv("SG_MFCC_ABLATE")) t.ablate = atoi(e);
-#endif
     int rc = 0;
     rc |= dev_upload(ctx, ctx->model_allocs, &t.window, window);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_w, melw);
@@ -506,6 +503,19 @@ int sg_set_streamk(sg_ctx* ctx, int32_t enable) {
 int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches) {
     if (!ctx || launches < 0) return SG_ERR_ARG;
     ctx->lose_handoffs = launches;
+    return SG_OK;
+}
+
+int sg_xv_configure(sg_ctx* ctx, int32_t fft_bits) {
+    if (!ctx) return SG_ERR_ARG;
+    if (fft_bits != 32 && fft_bits != 64) return fail(ctx, SG_ERR_ARG, "fft_bits must be 32 or 64");
+    ctx->tab.fft64 = fft_bits == 64;
+    return SG_OK;
+}
+
+int sg_debug_feco_epoch(sg_ctx* ctx, uint32_t epoch) {
+    if (!ctx) return SG_ERR_ARG;
+    ctx->feco_epoch = epoch;
     return SG_OK;
 }
 

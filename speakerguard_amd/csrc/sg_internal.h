@@ -155,9 +155,11 @@ struct MfccTables {          // device pointers
     float* lifter;           // [30]
     double2* twiddle;        // [256] exp(-2 pi i k / 512), fp64 (forward FFT runs in fp64)
     uint16_t* bitrev;        // [512]
-    int ablate;              // timing experiments (SG_MFCC_ABLATE): 1 skip FFTs, 2 skip mel/DCT loops
+    int ablate;              // (unused since round 6)
+    int fft64;               // sg_xv_configure: 0 = float32 transforms (default, the reference's precision), 1 = float64
     // spectrum hand-over forward -> backward within one pass (null: the backward recomputes the forward):
-    // bins 0..255 of every frame's FFT as float2 (computed in fp64, rounded once) and the 30 mel energies
+    // bins 0..255 of every frame's FFT as float2, in the transform's register order (bin (l >> 3) + 8 (l & 7) + 64 d at
+    // element 64 d + l), and the 30 mel energies
     float2* spec_cache;      // [B*F][256]
     float* mel_cache;        // [B*F][32]
     int rep_utts;            // > 0: rows are EOT repeats of rep_utts utterances (row = repeat * rep_utts + utterance):

@@ -12,9 +12,75 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU oracle (torch autograd through the restated models) is what the GPU suite spends its wall time on.  torch's default
+# is one OpenMP thread per core of the host: on the GPU boxes (256 cores) the oracle's small per-utterance operators then run
+# ~10x SLOWER than on 16 threads (bench.py's thread sweep: 16 -> 0.19 s, 128 -> 2.3 s for the same pass), which is what pushed
+# the round-5 suite past the driver's limit.  Pinned here, before any test imports the oracle.
+ORACLE_THREADS = max(1, min(16, os.cpu_count() or 1))
+for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(ORACLE_THREADS))
+import torch  # noqa: E402
 
+torch.set_num_threads(ORACLE_THREADS)
+try:
+    torch.set_num_interop_threads(1)
+except RuntimeError:  # (already started: another conftest / plugin touched torch first)
+    pass
+
+# per-test watchdog: a test that hangs (a kernel that never returns, a rendezvous that never completes) names itself with a
+# traceback of every thread and ends the run NON-ZERO instead of sitting there until the driver's limit kills the whole suite
+# without a word.  No re-exec, no signal games: faulthandler's own watchdog thread calls _exit(1).
+TEST_LIMIT_S = int(os.environ.get("SG_TEST_LIMIT_S", "300"))
+
+
+_WATCHDOG_FD = None
+
+
+@pytest.hookimpl(trylast=True)  # (after pytest's faulthandler plugin has made its copy)
 def pytest_configure(config):
+    global _WATCHDOG_FD
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:  # the copy of the terminal's stderr pytest's own faulthandler plugin keeps outside its output capture
+        from _pytest.faulthandler import fault_handler_stderr_fd_key
+        _WATCHDOG_FD = config.stash[fault_handler_stderr_fd_key]
+    except Exception:
+        _WATCHDOG_FD = None
+
+
+@pytest.fixture(autouse=True)
+def _watchdog(request):
+    import faulthandler
+    if _WATCHDOG_FD is None:
+        yield
+        return
+    os.write(_WATCHDOG_FD, b"")
+    faulthandler.dump_traceback_later(TEST_LIMIT_S, exit=True, file=_WATCHDOG_FD)
+    try:
+        yield
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+        # (pytest's plugin arms the same timer when faulthandler_timeout is set; it is not, so nothing to restore)
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """the test that is running, outside the capture: a kill from outside (the driver's limit) leaves the name in the log"""
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "current_test.txt"), "w") as f:
+            f.write(nodeid + "\n")
+    except OSError:
+        pass
+
+
+# ---- session-wide cache of oracle results ---------------------------------------------------------------------------------
+# Several tests attack the same (model, waveforms, parameters) through the oracle; the oracle is deterministic, so each
+# distinct workload is computed once per session.  Key: a tuple of plain values naming the workload completely.
+_ORACLE_CACHE = {}
+
+
+def oracle_cached(key, compute):
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = compute()
+    return _ORACLE_CACHE[key]
 
 
 def load_golden(name):

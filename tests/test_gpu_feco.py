@@ -144,7 +144,10 @@ def test_two_compute_units_per_instance_give_the_same_clustering():
                 assert torch.equal(a, b), (B, F, D, reps, mode)
         assert got["one"][0].min().item() >= 0 and got["one"][2].sum().item() == reps * B * F
     # the exchange words carry 15 bits of launch counter: past 2^15 launches of one context the buffers are wiped and the
-    # tags start over -- 33 000 small clusterings later the answer is still the one-block one
+    # tags start over.  The counter is parked just below the wrap (test hook sg_debug_feco_epoch; until round 5 this test
+    # spent 33 000 real launches to get there): the launches above used the tags 1, 2, ..., the launches after the wrap use
+    # them again, with the words of the earlier cycle still in the buffer if the wipe did not happen -- and the answer is
+    # still the one-block one.  Same across the wrap of the 32-bit counter itself (0 is never a launch id).
     feat = torch.from_numpy(rs.randn(2, 96, 8).astype(np.float32)).to(DEV)
     ids = torch.empty(2, 96, device=DEV, dtype=torch.int32)
     out = torch.empty(2, 48, 8, device=DEV)
@@ -155,13 +158,17 @@ def test_two_compute_units_per_instance_give_the_same_clustering():
     torch.cuda.synchronize()
     want = (ids.clone(), out.clone(), counts.clone())
     ctx.call("sg_feco_set_two_cu", -1)
-    for i in range(33000):
+    for i in range(24):  # a first cycle's words with the tags 1 .. 24 (+ whatever the shapes above left)
         ctx.call("sg_feco_kmeans_compress", *args)
-        if i % 8192 == 8191 or i == 32999:
+    for park in (0x7FF4, 0xFFF4, 0xFFFFFFF4):
+        ctx.call("sg_debug_feco_epoch", park)
+        for i in range(40):
+            ids.fill_(-1)
+            ctx.call("sg_feco_kmeans_compress", *args)
             torch.cuda.synchronize()
-            assert torch.equal(ids, want[0]) and torch.equal(out, want[1]) and torch.equal(counts, want[2]), i
+            assert torch.equal(ids, want[0]) and torch.equal(out, want[1]) and torch.equal(counts, want[2]), (hex(park), i)
     log("FeCo k-means on two compute units per instance: ids, means, counts equal to one block per instance, also with a silent partner "
-        "and across the wrap of the exchange tags (33 000 launches)")
+        "and across the wraps of the exchange tags and of the launch counter")
 
 
 def test_kmeans_refuses_what_does_not_fit():
