@@ -6,7 +6,7 @@ OBJ   := build/obj
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS))
 LIB   := speakerguard_amd/libspeakerguard_hip.so
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(EXTRA)
 
 ORACLE_SO := oracle/libconv_chain.so
 
@@ -38,7 +38,7 @@ ASAN_FLAGS := --cuda-host-only -O1 -g -std=c++17 -fPIC -fsanitize=address,undefi
 ASAN_OBJS  := $(patsubst $(CSRC)/%.hip,$(ASAN_DIR)/%.o,$(SRCS))
 ASAN_EXE   := $(ASAN_DIR)/abi_asan_driver
 
-$(ASAN_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h $(CSRC)/fft512.h $(CSRC)/loss_device.h include/speakerguard_hip.h
+$(ASAN_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/sg_internal.h $(CSRC)/fft512.h $(CSRC)/fft512t.h $(CSRC)/loss_device.h include/speakerguard_hip.h
 	@mkdir -p $(ASAN_DIR)
 	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
 

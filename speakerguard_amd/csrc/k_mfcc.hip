@@ -8,18 +8,17 @@
 //   c0 <- log-energy.
 //
 // One wave (64 lanes) owns one frame: the 400 samples are read coalesced from the waveform, the
-// 512-point FFT runs in LDS + registers (three radix-8 passes, table twiddles), reductions use wavefront
-// shuffles.  The FORWARD transform runs in fp64: a windowed speech frame has > 80 dB between its
-// strongest harmonic and the weak bins, and an fp32 FFT leaves a round-off floor of ~2e-7 of the
-// strongest bin on every bin -- a 1e-3 relative error on exactly the weak mel bands whose
-// 1/energy weights dominate d(log-mel)/dx; the inverse transform of the spectrum gradient has the
-// same problem in the other direction (an absolute error floor on every sample, which flips the
-// sign of small gradient entries).  Measured with fp32 transforms: 0.8 % gradient sign mismatches
-// against the oracle, whose own fp32-vs-fp64 noise is 0.03 %.
-// The backward kernel recomputes the forward of its frame (cheaper than storing 514 floats per
-// frame), then walks the stages in reverse; the spectrum gradient overwrites the spectrum in
-// place and is transformed back by the same FFT with conjugate twiddles.  It writes per-frame sample
-// gradients (B,F,400); frames_to_wave_kernel does the deterministic overlap-add.
+// 512-point FFT runs in LDS + registers (three radix-8 passes, table twiddles), reductions stay inside the wave (DPP).
+// Transform precision (round 6): float32 by default -- the reference's own: torchaudio 0.6's kaldi.mfcc is float32 end to
+// end, torch.rfft included -- with float64 transforms as the counterpart (sg_xv_configure).  Rounds 1-5 ran float64 only,
+// after a first float32 transform (radix-2, run-time twiddles) had shown 0.8 % gradient sign mismatches against the oracle.
+// With the radix-8 network and twiddles rounded once from float64 the float32 transform is as close to the oracle as the
+// float64 one (profiles/r06_mfcc_precision.txt: d loss / d wav sign mismatches 1.5e-4 vs 1.3e-4; the float32 oracle itself
+// differs from a float64 evaluation of the same model in 3.3e-4 of the samples), and 8-byte LDS elements + 78-100 VGPRs put
+// four waves on a SIMD where the float64 form has two.
+// The backward kernel reads the forward's spectrum and mel energies back (or recomputes the forward of its frame), then
+// walks the stages in reverse; the gradient spectrum is formed in registers and transformed back by the TRANSPOSED network.
+// It writes per-frame sample gradients (B,F,400); frames_to_wave_kernel does the deterministic overlap-add.
 #include "sg_internal.h"
 #include "fft512t.h"
 
@@ -39,8 +38,12 @@ constexpr int kMfccMaxBlocks = 512;  // 2 blocks (~60 KB LDS each) per CU x 256 
 //              counterpart (a windowed speech frame has > 80 dB between its strongest harmonic and the weak bins; a float32
 //              transform leaves a round-off floor of ~1e-7 of the strongest bin on every bin, float64 does not).
 template <typename R> struct MfccCfg;
-template <> struct MfccCfg<float> { static constexpr int kWaves = 8; };
-template <> struct MfccCfg<double> { static constexpr int kWaves = 4; };
+#ifndef SG_MFCC_F32_WAVES  // (tools/r06_mfcc_variants.sh builds the alternatives)
+#define SG_MFCC_F32_WAVES 8
+#define SG_MFCC_F32_OCC 4
+#endif
+template <> struct MfccCfg<float> { static constexpr int kWaves = SG_MFCC_F32_WAVES, kMinBlocks = SG_MFCC_F32_OCC; };  // (HIP: min waves per SIMD) 16 waves per CU: <= 128 VGPRs
+template <> struct MfccCfg<double> { static constexpr int kWaves = 4, kMinBlocks = 2; };
 
 template <typename R>
 struct FrameLdsT {
@@ -57,43 +60,42 @@ struct FrameLdsT {
 // independent waves at ~25 points per frame).
 // Constant tables staged once per block into LDS: every per-frame table access was a dependent global
 // load (L1/L2 hit, but ~0.3 us of latency each with few waves per SIMD to hide it).
+// Round 6: EVERY per-lane constant lives in the block's LDS table image (MfccLdsImage, sg_internal.h: the mel weights of a
+// lane's half filter, the DCT matrix in both orientations, window, twiddles): in registers they cost 55-60 VGPRs per lane and
+// held the kernels at 2 waves per SIMD -- latency-bound at ~40 % VALU and ~37 % LDS utilisation.  All of these reads are
+// lane-linear (conflict-free) and independent of the frame's data.
+static_assert(kMfccTw1 == kFftTw1 && kMfccTw2 == kFftTw2, "table sizes of fft512.h");
 template <typename R>
-struct TabLdsT {
-    cx<R> tw1[kFftTw1];  // pass-1 / pass-2 twiddles as the lanes read them (fft512.h), float64 values rounded once to R
-    cx<R> tw2[kFftTw2];
-    float window[kWin];
-    float dct[kMel * kCep];
-    float lifter[32];
-    int bin_m0[256];
-    float bin_w0[256];
-    float bin_w1[256];
-    int mel_lo[32];
-    int mel_hi[32];
+struct TabLdsT : MfccLdsImage<R> {
+    __device__ __forceinline__ const cx<R>* tw1c() const { return reinterpret_cast<const cx<R>*>(this->tw1); }
+    __device__ __forceinline__ const cx<R>* tw2c() const { return reinterpret_cast<const cx<R>*>(this->tw2); }
 };
+template <typename R> __device__ __forceinline__ const MfccLdsImage<R>* lds_image(const MfccTables& t);
+template <> __device__ __forceinline__ const MfccLdsImage<float>* lds_image<float>(const MfccTables& t) { return t.lds_f32; }
+template <> __device__ __forceinline__ const MfccLdsImage<double>* lds_image<double>(const MfccTables& t) { return t.lds_f64; }
 
 template <typename R>
 __device__ __forceinline__ void stage_tables(const MfccTables& t, TabLdsT<R>& tb) {
-    fft512_fill_tablesT<R>(t.twiddle, tb.tw1, tb.tw2);
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        tb.bin_m0[i] = t.bin_m0[i];
-        tb.bin_w0[i] = t.bin_w0[i];
-        tb.bin_w1[i] = t.bin_w1[i];
-    }
-    for (int i = threadIdx.x; i < kWin; i += blockDim.x) tb.window[i] = t.window[i];
-    for (int i = threadIdx.x; i < kMel * kCep; i += blockDim.x) tb.dct[i] = t.dct[i];
-    if (threadIdx.x < 32) {
-        tb.lifter[threadIdx.x] = threadIdx.x < kCep ? t.lifter[threadIdx.x] : 0.f;
-        tb.mel_lo[threadIdx.x] = threadIdx.x < kMel ? t.mel_lo[threadIdx.x] : 0;
-        tb.mel_hi[threadIdx.x] = threadIdx.x < kMel ? t.mel_hi[threadIdx.x] : 0;
-    }
+    const uint4* src = reinterpret_cast<const uint4*>(lds_image<R>(t));
+    uint4* dst = reinterpret_cast<uint4*>(&tb);
+    for (int i = threadIdx.x; i < (int)(sizeof(MfccLdsImage<R>) / 16); i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 
 
+// Sum over the 64 lanes, the same value in every lane: a butterfly inside each row of 16 lanes on DPP (quad permutes, then
+// the half-row and row mirrors pair the quads / halves), then the four row sums through scalar registers.  ~12 instructions
+// and no LDS traffic; the ds_bpermute butterfly of rounds 1-5 cost six dependent LDS round trips per sum.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Philox4x32-10 counter-based generator (Salmon et al. 2011); one 32-bit draw per (key, counter).
@@ -145,36 +147,12 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ x, int T, i
     }
 }
 
-// Table entries a lane needs for EVERY frame, hoisted into registers once per kernel: the weights of the bins
-// its half of a mel filter sums (ascending bin order, zero-padded: adding power * 0 leaves the sum unchanged, so
-// the result is bit-identical to a loop over the exact range), and its column of the DCT matrix.  Per frame the
-// mel and DCT loops then issue one LDS read per term (the spectrum / log-mel value) instead of four / two, all
-// independent, instead of a dependent chain of table look-ups.
-constexpr int kMelLaneBins = 24;  // >= bins per half filter (21 for 30 filters, 20-7600 Hz, 512-point FFT; host-checked)
-struct LaneConst {
-    int mel_k0;                 // first bin of this lane's half filter
-    float mel_w[kMelLaneBins];  // its weights
-    float dct_col[kMel];        // dct[m][lane] * 1 (lane < kCep)
-};
-
-template <typename R>
-__device__ __forceinline__ void lane_const_init(const TabLdsT<R>& tb, int lane, LaneConst& lc) {
-    const int m = lane >> 1, h = lane & 1;
-    int k0 = 0, cnt = 0;
-    if (m < kMel) {
-        const int lo = tb.mel_lo[m], hi = tb.mel_hi[m];
-        const int mid = lo + (hi - lo + 1) / 2;
-        k0 = h ? mid : lo;
-        cnt = (h ? hi : mid) - k0;
-    }
-    lc.mel_k0 = k0;
-#pragma unroll
-    for (int j = 0; j < kMelLaneBins; ++j) {
-        const int k = min(k0 + j, 255);
-        lc.mel_w[j] = j < cnt ? (tb.bin_m0[k] == m ? tb.bin_w0[k] : tb.bin_w1[k]) : 0.f;
-    }
-#pragma unroll
-    for (int mm = 0; mm < kMel; ++mm) lc.dct_col[mm] = lane < kCep ? tb.dct[mm * kCep + lane] : 0.f;
+// An offset the compiler cannot see through (always 0): table reads addressed with it are re-issued per frame instead of
+// being hoisted out of the frame loop into 30-60 registers per lane.
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
 }
 
 // No implicit contraction in the per-frame arithmetic (as in fft512t.h): the same functions are instantiated in the forward
@@ -187,9 +165,10 @@ __device__ __forceinline__ void lane_const_init(const TabLdsT<R>& tb, int lane, 
 // exist, in registers.  The transform's input stays out of LDS as well: the windowed frame is real and zero beyond sample
 // 399, so pass 1 takes it as 7 values per lane.  The spectrum cache keeps a frame's bins in transform order (element
 // 64 d + lane): written and read back as whole 512-byte rows.
-template <typename R, int MODE>
-__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT<R>& tb, const LaneConst& lc, FrameLdsT<R>& L,
-                                              const float (&raw)[7], const float (&win)[7], int F, int b, int f, float scale,
+// DZ: 0 = no dither, 1 = the kernel's own Philox draws, 2 = an explicit noise tensor (the hot loop carries only its own case)
+template <typename R, int MODE, int DZ>
+__device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT<R>& tb, int tz, FrameLdsT<R>& L,
+                                              const float (&raw)[7], int F, int b, int f, float scale,
                                               const sg_dither& dz, int lane, FrameState& st, float& cep_out, cx<R> (&Xk)[4]) {
     float sum = 0.f;
 #pragma unroll
@@ -198,8 +177,8 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT
         float v = 0.f;
         if (n < kWin) {
             v = raw[i] * scale;
-            if (dz.noise_dev) v += dz.noise_dev[((size_t)b * F + f) * kWin + n];
-            else if (dz.dither != 0.f) {
+            if (DZ == 2) v += dz.noise_dev[((size_t)b * F + f) * kWin + n];
+            else if (DZ == 1) {
                 // repeat r of the batched EOT passes draws from key seed + r * 0xC2B2AE3D27D4EB4F, like the r-th of the
                 // sequential passes it replaces (sg_xv_pgd_run); a caller that materialised the repeats itself
                 // (EOT.py:29) names their length in dz.rep_rows, and a row slice of a larger call its offset in
@@ -245,10 +224,10 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT
         const float edge = i > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.s[i - 1]), 63)) : st.s[0];
         const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, st.s[i]),
                                                                                   0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-        in[i] = cmk<R>((R)((st.s[i] - 0.97f * prev) * win[i]), (R)0);  // (win = 0 beyond sample 399)
+        in[i] = cmk<R>((R)((st.s[i] - 0.97f * prev) * tb.window[tz + lane + 64 * i]), (R)0);  // (window = 0 beyond sample 399)
     }
     in[7] = cmk<R>((R)0, (R)0);
-    fft512T_regs<R>(L.spec, tb.tw1, tb.tw2, lane, (R)-1, in, out);
+    fft512T_regs<R>(L.spec, tb.tw1c() + tz, tb.tw2c() + tz, lane, (R)-1, in, out);
     {
         const int kb = (lane >> 3) + 8 * (lane & 7);  // this lane's bins: kb + 64 d
 #pragma unroll
@@ -264,9 +243,10 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT
     // of bin k in filter m is bin_w0[k] if m is the lower of the two filters covering k, else bin_w1[k]
     {
         const int m = lane >> 1, h = lane & 1;
+        const int k0 = tb.mel_k0[tz + lane];
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMelLaneBins; ++j) acc = __builtin_fmaf(L.power[min(lc.mel_k0 + j, 255)], lc.mel_w[j], acc);
+        for (int j = 0; j < kMelLaneBins; ++j) acc = __builtin_fmaf(L.power[min(k0 + j, 255)], tb.melw_lane[tz + j * 64 + lane], acc);
         acc += __shfl_xor(acc, 1, 64);
         if (m < kMel && h == 0) {
             L.mel[m] = acc;
@@ -279,22 +259,15 @@ __device__ __forceinline__ void frame_forward(const MfccTables& t, const TabLdsT
     if (lane < kCep) {
         float v = 0.f;
 #pragma unroll
-        for (int m = 0; m < kMel; ++m) v = __builtin_fmaf(L.lmel[m], lc.dct_col[m], v);
+        for (int m = 0; m < kMel; ++m) v = __builtin_fmaf(L.lmel[m], tb.dct[tz + m * kCep + lane], v);
         v *= tb.lifter[lane];
         if (lane == 0) v = logf(fmaxf(st.energy, kEps));
         cep_out = v;
     }
 }
 
-// the povey window at this lane's samples n = lane + 64 i (zero beyond sample 399)
-template <typename R>
-__device__ __forceinline__ void lane_window(const TabLdsT<R>& tb, int lane, float (&win)[7]) {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) win[i] = lane + 64 * i < kWin ? tb.window[lane + 64 * i] : 0.f;
-}
-
-template <typename R>
-__global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_fwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
+template <typename R, int DZ>
+__global__ __launch_bounds__(MfccCfg<R>::kWaves * 64, MfccCfg<R>::kMinBlocks) void mfcc_fwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
                                                                           const float* __restrict__ scale_p, sg_dither dz,
                                                                           float* __restrict__ feats) {
     constexpr int kWaves = MfccCfg<R>::kWaves;
@@ -304,23 +277,20 @@ __global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_fwd_kernel(MfccT
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLdsT<R>& L = lds[wid];
-    LaneConst lc;
-    lane_const_init<R>(tb, lane, lc);
-    float win[7];
-    lane_window<R>(tb, lane, win);
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
     const int total = B * F, stride = gridDim.x * kWaves;
     float raw[7], nxt[7];
     load_frame(x, T, F, blockIdx.x * kWaves + wid, total, lane, nxt, t.rep_utts);
     for (int gf = blockIdx.x * kWaves + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
+        const int tz = opaque_zero();
 #pragma unroll
         for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
         load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
         FrameState st;
         float cep;
         cx<R> Xk[4];
-        frame_forward<R, 0>(t, tb, lc, L, raw, win, F, b, f, scale, dz, lane, st, cep, Xk);
+        frame_forward<R, 0, DZ>(t, tb, tz, L, raw, F, b, f, scale, dz, lane, st, cep, Xk);
         if (lane < kCep) feats[((size_t)b * F + f) * kCep + lane] = cep;
         wave_sync();
     }
@@ -331,8 +301,8 @@ __global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_fwd_kernel(MfccT
 // CACHED: the forward kernel of the same pass left spectrum + mel energies in t.spec_cache / t.mel_cache (the attack
 // loop); otherwise the forward is recomputed here (standalone sg_xv_mfcc_backward).  Two instantiations so that the
 // cached one does not carry the forward's lane constants.
-template <typename R, bool CACHED>
-__global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_bwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
+template <typename R, bool CACHED, int DZ>
+__global__ __launch_bounds__(MfccCfg<R>::kWaves * 64, CACHED ? MfccCfg<R>::kMinBlocks : 1) void mfcc_bwd_kernel(MfccTables t, const float* __restrict__ x, int B, int T, int F,
                                                                           const float* __restrict__ scale_p, sg_dither dz,
                                                                           const float* __restrict__ dfeats, int ld,
                                                                           float* __restrict__ dframes) {
@@ -343,23 +313,15 @@ __global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_bwd_kernel(MfccT
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = scale_p ? *scale_p : 1.f;
     FrameLdsT<R>& L = lds[wid];
-    LaneConst lc;
-    if (!CACHED) lane_const_init<R>(tb, lane, lc);
-    float win[7];
-    lane_window<R>(tb, lane, win);
-    // backward-only lane constants: row `lane` of the DCT matrix, and the mel membership of this lane's four bins
-    // (transform order: bin kb + 64 d)
-    float dct_row[kCep];
-#pragma unroll
-    for (int c = 0; c < kCep; ++c) dct_row[c] = lane < kMel ? tb.dct[lane * kCep + c] : 0.f;
+    // backward-only lane constants: the mel membership of this lane's four bins (transform order: bin kb + 64 d)
     const int kb = (lane >> 3) + 8 * (lane & 7);
     int bin_m0[4];
     float bin_w0[4], bin_w1[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        bin_m0[d] = tb.bin_m0[kb + 64 * d];
-        bin_w0[d] = tb.bin_w0[kb + 64 * d];
-        bin_w1[d] = tb.bin_w1[kb + 64 * d];
+        bin_m0[d] = t.bin_m0[kb + 64 * d];
+        bin_w0[d] = t.bin_w0[kb + 64 * d];
+        bin_w1[d] = t.bin_w1[kb + 64 * d];
     }
     // frames are dealt round-robin to the resident waves (grid sized to the chip, tables staged once)
     const int total = B * F, stride = gridDim.x * kWaves;
@@ -367,13 +329,14 @@ __global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_bwd_kernel(MfccT
     load_frame(x, T, F, blockIdx.x * kWaves + wid, total, lane, nxt, t.rep_utts);
     for (int gf = blockIdx.x * kWaves + wid; gf < total; gf += stride) {
         const int b = gf / F, f = gf - b * F;
+        const int tz = opaque_zero();
 #pragma unroll
         for (int i = 0; i < 7; ++i) raw[i] = nxt[i];
         load_frame(x, T, F, gf + stride, total, lane, nxt, t.rep_utts);
         FrameState st;
         float cep;
         cx<R> Xk[4];
-        frame_forward<R, CACHED ? 1 : 0>(t, tb, lc, L, raw, win, F, b, f, scale, dz, lane, st, cep, Xk);
+        frame_forward<R, CACHED ? 1 : 0, DZ>(t, tb, tz, L, raw, F, b, f, scale, dz, lane, st, cep, Xk);
         // ---- cepstra -> log-mel
         float dc = 0.f;
         if (lane < kCep) dc = dfeats[((size_t)b * F + f) * ld + lane];
@@ -385,7 +348,7 @@ __global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_bwd_kernel(MfccT
             if (lane < kMel) {
                 float dl = 0.f;
 #pragma unroll
-                for (int c = 0; c < kCep; ++c) dl = __builtin_fmaf(L.tmp[c], dct_row[c], dl);
+                for (int c = 0; c < kCep; ++c) dl = __builtin_fmaf(L.tmp[c], tb.dct_t[tz + c * 32 + lane], dl);
                 const float mel = L.mel[lane];
                 dm = mel > kEps ? dl / mel : 0.f;
             }
@@ -406,12 +369,12 @@ __global__ __launch_bounds__(MfccCfg<R>::kWaves * 64) void mfcc_bwd_kernel(MfccT
         }
 #pragma unroll
         for (int d = 4; d < 8; ++d) v[d] = cmk<R>((R)0, (R)0);
-        fft512T_transposed<R>(L.spec, tb.tw1, tb.tw2, lane, (R)1, v);
+        fft512T_transposed<R>(L.spec, tb.tw1c() + tz, tb.tw2c() + tz, lane, (R)1, v);
         // ---- window, pre-emphasis (sample n + 1 is the right neighbour lane's, lane 63: lane 0's next register), energy,
         //      DC removal
         float sw[8];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) sw[i] = (float)v[i].x * win[i];
+        for (int i = 0; i < 7; ++i) sw[i] = (float)v[i].x * tb.window[tz + lane + 64 * i];
         sw[7] = 0.f;
         float ds[7];
         float sum = 0.f;
@@ -542,7 +505,9 @@ static void mfcc_fwd_launch(const MfccTables& t, const float* x, int B, int T, i
     constexpr int kWaves = MfccCfg<R>::kWaves;
     const int want = (B * F + kWaves - 1) / kWaves;
     dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
-    hipLaunchKernelGGL(mfcc_fwd_kernel<R>, grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, feats);
+    if (d.noise_dev) hipLaunchKernelGGL((mfcc_fwd_kernel<R, 2>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, feats);
+    else if (d.dither != 0.f) hipLaunchKernelGGL((mfcc_fwd_kernel<R, 1>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, feats);
+    else hipLaunchKernelGGL((mfcc_fwd_kernel<R, 0>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, feats);
 }
 
 template <typename R>
@@ -551,8 +516,15 @@ static void mfcc_bwd_launch(const MfccTables& t, const float* x, int B, int T, i
     constexpr int kWaves = MfccCfg<R>::kWaves;
     const int want = (B * F + kWaves - 1) / kWaves;
     dim3 grid(want < kMfccMaxBlocks ? want : kMfccMaxBlocks);
-    if (t.spec_cache) hipLaunchKernelGGL((mfcc_bwd_kernel<R, true>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
-    else hipLaunchKernelGGL((mfcc_bwd_kernel<R, false>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes);
+#define SG_MFCC_BWD(CACHED, DZ) \
+    hipLaunchKernelGGL((mfcc_bwd_kernel<R, CACHED, DZ>), grid, dim3(kWaves * 64), 0, s, t, x, B, T, F, scale, d, dfeats, kCep, dframes)
+    const int dzk = d.noise_dev ? 2 : (d.dither != 0.f ? 1 : 0);
+    if (t.spec_cache) {
+        if (dzk == 2) SG_MFCC_BWD(true, 2); else if (dzk == 1) SG_MFCC_BWD(true, 1); else SG_MFCC_BWD(true, 0);
+    } else {
+        if (dzk == 2) SG_MFCC_BWD(false, 2); else if (dzk == 1) SG_MFCC_BWD(false, 1); else SG_MFCC_BWD(false, 0);
+    }
+#undef SG_MFCC_BWD
 }
 
 hipError_t launch_mfcc_fwd(const MfccTables& t, const float* x, int B, int T, int F, const float* scale,

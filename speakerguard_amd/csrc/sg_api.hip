@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <type_traits>
 
 #include "sg_internal.h"
 
@@ -115,7 +117,7 @@ int build_tables(sg_ctx* ctx) {
         }
         if (lo[m] > hi[m]) lo[m] = hi[m] = 0;
         // each of the two lanes of a filter keeps the weights of its half in registers (k_mfcc.hip: kMelLaneBins)
-        if ((hi[m] - lo[m] + 1) / 2 > 24) return fail(ctx, SG_ERR_STATE, "mel filter %d spans %d bins: more than the MFCC kernel holds", m, hi[m] - lo[m]);
+        if ((hi[m] - lo[m] + 1) / 2 > kMelLaneBins) return fail(ctx, SG_ERR_STATE, "mel filter %d spans %d bins: more than the MFCC kernel holds", m, hi[m] - lo[m]);
     }
     for (int k = 0; k < 256; ++k) {
         int first = -1, cnt = 0;
@@ -154,6 +156,43 @@ int build_tables(sg_ctx* ctx) {
     }
     MfccTables& t = ctx->tab;
     t.ablate = 0;
+    // the kernels' LDS table images (MfccLdsImage), one per transform precision
+    auto fill_image = [&](auto& img) {
+        using R = std::remove_reference_t<decltype(img.tw1[0])>;
+        std::memset(&img, 0, sizeof(img));
+        auto w512 = [&](int m, R* out) {  // W512^m from the half circle (W^(m + 256) = -W^m), rounded once to R
+            const double2 w = tw[m & 255];
+            const double f = (m & 256) ? -1.0 : 1.0;
+            out[0] = (R)(f * w.x);
+            out[1] = (R)(f * w.y);
+        };
+        for (int i = 0; i < kMfccTw1; ++i) w512((i / 64 + 1) * (i % 64), &img.tw1[2 * i]);
+        for (int i = 0; i < kMfccTw2; ++i) {
+            const int b = i / 9, c = i - 9 * b;
+            if (c < 8) w512(8 * b * c, &img.tw2[2 * i]);
+        }
+        for (int n = 0; n < kWin; ++n) img.window[n] = window[n];
+        for (int i = 0; i < kMel * kCep; ++i) img.dct[i] = dct[i];
+        for (int c = 0; c < kCep; ++c)
+            for (int m = 0; m < kMel; ++m) img.dct_t[c * 32 + m] = dct[m * kCep + c];
+        for (int c = 0; c < kCep; ++c) img.lifter[c] = lifter[c];
+        // the weights of the bins a lane's half of a mel filter sums (two lanes per filter), ascending bin order, zero-padded
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane >> 1, h = lane & 1;
+            if (m >= kMel) continue;
+            const int mid = lo[m] + (hi[m] - lo[m] + 1) / 2;
+            const int k0 = h ? mid : lo[m], cnt = (h ? hi[m] : mid) - k0;
+            img.mel_k0[lane] = k0;
+            for (int j = 0; j < kMelLaneBins && j < cnt; ++j) {
+                const int k = std::min(k0 + j, 255);
+                img.melw_lane[j * 64 + lane] = m0[k] == m ? w0[k] : w1[k];
+            }
+        }
+    };
+    auto img32 = std::make_unique<MfccLdsImage<float>>();
+    auto img64 = std::make_unique<MfccLdsImage<double>>();
+    fill_image(*img32);
+    fill_image(*img64);
     int rc = 0;
     rc |= dev_upload(ctx, ctx->model_allocs, &t.window, window);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_w, melw);
@@ -165,6 +204,16 @@ int build_tables(sg_ctx* ctx) {
     rc |= dev_upload(ctx, ctx->model_allocs, &t.dct, dct);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.lifter, lifter);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
+    {
+        std::vector<MfccLdsImage<float>> v32(1, *img32);
+        std::vector<MfccLdsImage<double>> v64(1, *img64);
+        MfccLdsImage<float>* d32 = nullptr;
+        MfccLdsImage<double>* d64 = nullptr;
+        rc |= dev_upload(ctx, ctx->model_allocs, &d32, v32);
+        rc |= dev_upload(ctx, ctx->model_allocs, &d64, v64);
+        t.lds_f32 = d32;
+        t.lds_f64 = d64;
+    }
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->range_scratch, 512);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->cw2_scratch, 1024 * 32);

@@ -143,7 +143,27 @@ struct AnWorkspace {
     std::vector<void*> allocs;
 };
 
+// The MFCC kernels' constant tables exactly as they sit in a block's LDS (k_mfcc.hip), built once on the host per transform
+// precision R and copied into LDS with 16-byte loads by every block (round 6; rounds 1-5 derived them per block from the raw
+// tables -- dependent global look-ups in front of the first frame).
+constexpr int kMfccTw1 = 7 * 64, kMfccTw2 = 72;  // = kFftTw1, kFftTw2 (fft512.h)
+constexpr int kMelLaneBins = 24;  // >= bins per half mel filter (21 for 30 filters, 20-7600 Hz, 512-point FFT; host-checked)
+template <typename R>
+struct MfccLdsImage {
+    R tw1[2 * kMfccTw1];                // (re, im) of W512^(j lane) at (j - 1) * 64 + lane, float64 values rounded once to R
+    R tw2[2 * kMfccTw2];                // W64^(b c) at 9 b + c
+    float window[kFft];                 // povey window, zero beyond sample 399
+    float dct[kMel * kCep + 64];        // [m][c] (forward: lane c reads dct[m][c])
+    float dct_t[kCep * 32];             // [c][m] (backward: lane m reads dct[m][c])
+    float lifter[32];
+    float melw_lane[kMelLaneBins * 64]; // [j][lane]: weight of bin mel_k0[lane] + j in the half filter of lane (0 beyond it)
+    int mel_k0[64];                     // first bin of lane's half filter (two lanes per filter)
+};
+static_assert(sizeof(MfccLdsImage<float>) % 16 == 0 && sizeof(MfccLdsImage<double>) % 16 == 0, "copied as 16-byte words");
+
 struct MfccTables {          // device pointers
+    const MfccLdsImage<float>* lds_f32;
+    const MfccLdsImage<double>* lds_f64;
     float* window;           // [400] povey
     float* mel_w;            // [30][256] dense triangular weights
     int* mel_lo;             // [30] first bin with non-zero weight

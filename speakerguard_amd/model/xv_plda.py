@@ -157,6 +157,13 @@ class xv_plda(EngineOps):
     def eval(self):
         return self
 
+    def configure_frontend(self, fft_bits=32):
+        """Precision of the MFCC's 512-point transforms on the engine (sg_xv_configure): 32 = float32, the reference's own
+        (torchaudio 0.6's kaldi.mfcc is float32 end to end, xv_plda.py:114-148) and the default; 64 = float64 transforms
+        around the same float32 stages, the form of rounds 1-5 kept as the counterpart."""
+        self.ctx.call("sg_xv_configure", int(fft_bits))
+        return self
+
     def to(self, device):
         if torch.device(device) != self.device and torch.device(device).index not in (None, self.device.index):
             raise N.NativeError("the engine context is bound to %s" % self.device)
