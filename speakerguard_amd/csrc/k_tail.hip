@@ -7,7 +7,7 @@
 //   PLDA log-likelihood-ratio against each enrolled speaker                      plda.py:140-190
 //   decision = argmax, rejected (-1) unless max > threshold                      iv_plda.py:182-194
 //   loss (attack/utils.py:7-102) and d loss/d scores, then the chain back to d loss/d fc1-output.
-// One block of 1024 threads per utterance; reductions are wavefront shuffles + a 16-entry LDS pass.
+// One block of 1024 threads per utterance; reductions are DPP wave sums + a 16-entry LDS pass.
 // The four matrix-vector products are bound by the LATENCY of the (L2-resident) matrix loads, not by bandwidth
 // (1.2 MB per utterance): un-unrolled they issued one dependent load at a time (157 us for the kernel), unrolled
 // 8-16x with 256 threads 97 us; with the K range of every product split over the four 256-thread quarters of the block
@@ -25,20 +25,35 @@ constexpr int kMaxD = 512;
 constexpr int kMaxS = kLossMaxS;
 
 struct TailModelDev {
-    const float *fc1_b, *emb_mean, *lda, *lda_t, *plda_mean, *plda_p, *plda_pt, *plda_psi, *enroll;
+    const float *fc1_b, *emb_mean, *lda, *lda_t, *plda_mean, *plda_p, *plda_pt, *plda_psi, *enroll, *pa;
     int D, S;
-    int Dp;  // D rounded up to a multiple of 4: row stride of lda_t / plda_p / plda_pt (zero-padded); lda rows are kLdaLd long
+    int Dp;  // D rounded up to a multiple of 4: row stride of lda_t / plda_p / plda_pt (zero-padded); lda / pa rows are kLdaLd long
     float threshold, logdet_given, logdet_without;
 };
 
 constexpr int kTailThreads = 1024;
 constexpr int kTailParts = kTailThreads / 256;
+constexpr int kTailEnrCache = 4096;  // floats of enrolled embeddings kept in LDS (S x D <= this: 10 x 200 in the recipes)
 static_assert(kTailThreads == 2 * kEmb && kTailParts >= 2, "step 1 splits the fc1 slabs over two half-blocks");
 
+// Sum over the 64 lanes, the same value in every lane: DPP butterfly inside the rows of 16 lanes, the four row sums
+// through scalar registers (k_mfcc.hip wave_sum) -- no LDS round trips.
+__device__ __forceinline__ float tail_wave_sum(float v) {
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Block sum: sixteen wave sums, combined in wave order.  Ends with a barrier; valid on every thread.
 __device__ __forceinline__ float block_sum(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();
+    v = tail_wave_sum(v);
+    __syncthreads();  // (red may still be read by an earlier phase)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     float r = 0.f;
@@ -84,7 +99,7 @@ __device__ __forceinline__ void matvec_cols4(const float* __restrict__ W, int ld
     __syncthreads();
 }
 
-// Touches every 128-byte line of the four back-end matrices once (see step 1 of the kernel).  A CU pulls only ~11 B/cycle
+// Touches every 128-byte line of the back-end matrices once (see step 1 of the kernel).  A CU pulls only ~11 B/cycle
 // from HBM (MI355X_MICROARCH.md, prologue burst), so the blocks that share an XCD (blockIdx % 8 -- a speed assumption
 // only) split the lines between them: block b takes every nq-th line starting at (b / 8) % nq, nq = blocks per XCD (<= 8).
 // Independent, clamped loads: all of a thread's lines are in flight at once.  Small batches get HELPER blocks (blockIdx >=
@@ -93,20 +108,30 @@ __device__ __forceinline__ float touch_matrices(const TailModelDev& m, int want_
     constexpr int NT = kTailThreads;
     const int D = m.D;
     const int nq = min(8, max(1, ((int)gridDim.x + 7) >> 3)), q = (b >> 3) % nq;
-    const size_t n_ldat = (size_t)(kEmb + 1) * m.Dp, n_lda = (size_t)D * kLdaLd, n_p = (size_t)D * m.Dp;
+    const size_t n_ldat = (size_t)(kEmb + 1) * m.Dp, n_pa = (size_t)D * kLdaLd, n_p = (size_t)D * m.Dp;
     const size_t step = (size_t)NT * nq * 32, first = ((size_t)tid * nq + q) * 32;
     // Independent, clamped loads: the first line of every matrix for every thread is in flight at once
-    const float pa = m.lda_t[min(first, n_ldat - 1)], pb = want_grad ? m.lda[min(first, n_lda - 1)] : 0.f;
-    const float pc = m.plda_pt[min(first, n_p - 1)], pd2 = want_grad ? m.plda_p[min(first, n_p - 1)] : 0.f;
+    const float pa = m.lda_t[min(first, n_ldat - 1)], pb = want_grad ? m.pa[min(first, n_pa - 1)] : 0.f;
+    const float pc = m.plda_pt[min(first, n_p - 1)];
     float sink = 0.f;
     for (size_t j = first + step; j < n_ldat; j += step) sink += m.lda_t[j];
-    for (size_t j = first + step; j < n_p; j += step) sink += m.plda_pt[j] + (want_grad ? m.plda_p[j] : 0.f);
+    for (size_t j = first + step; j < n_p; j += step) sink += m.plda_pt[j];
     if (want_grad)
-        for (size_t j = first + step; j < n_lda; j += step) sink += m.lda[j];
-    sink += (pa + pb) + (pc + pd2);
+        for (size_t j = first + step; j < n_pa; j += step) sink += m.pa[j];
+    sink += (pa + pb) + pc;
     return sink;
 }
 
+// Round 6: the tail is a chain of a dozen short dependent phases, and what it waited for between the four matrix-vector
+// products was latency, not work (phase times of block 0, SG_TAIL_TRACE: 29 us in all, 12.5 of them in the products):
+//  * the per-dimension vectors (psi, PLDA mean, LDA offset row) and the enrolled embeddings are fetched into LDS at the
+//    very start, together with the fc1 slabs -- every later phase that read them from global memory paid an L2 round
+//    trip of its own (~1 us each: normalisation, factor, scores, d scores);
+//  * block sums and the per-speaker dot products reduce on DPP instead of six ds_bpermute round trips each;
+//  * decision + loss + d loss / d scores run on ONE WAVE with the classes across the lanes (loss_and_dscores_wave: the 2 S
+//    expf of the cross-entropy side by side, the sum still in index order) -- one thread walking them was 3.5-4.5 us;
+//  * the backward applies P^T and LDA^T as ONE product with the matrix (P A) folded at load time (sg_xv_load, in float64,
+//    rounded once): d e1 = ratio (P A)^T dv, the product autograd computes as A^T (ratio (P^T dv)).
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, const float* __restrict__ fc1_part, int nsplit, int B,
                                                    const int64_t* __restrict__ y, sg_loss_spec ls, int want_grad,
                                                    float* __restrict__ tdnn_emb, float* __restrict__ emb_out,
@@ -118,8 +143,11 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     TSTAMP(0)
     __shared__ float e1[kEmb];
     __shared__ float e2[kMaxD], e4[kMaxD], e5[kMaxD], dv[kMaxD];
+    __shared__ float c_psi[kMaxD], c_pmean[kMaxD], c_off[kMaxD];
+    __shared__ float c_enr[kTailEnrCache];
     __shared__ float sc[kMaxS], dsc[kMaxS];
     __shared__ float red[kTailThreads / 64];
+    __shared__ int64_t c_y;
     __shared__ __attribute__((aligned(16))) float part[kTailPart];
     constexpr int NT = kTailThreads;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -132,9 +160,11 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     }
     const int D = m.D, S = m.S;
     const float sqrtD = sqrtf((float)D);
+    const bool enr_lds = (size_t)S * D <= (size_t)kTailEnrCache;
+    const float* enr = enr_lds ? c_enr : m.enroll;
     // 1. fc1 output = sum of the split-K slabs (+ folded bias), global-mean subtraction.  The block's two halves take
     //    half of the slabs each, all loads issued before the first add; halves are added in order.
-    //    Interleaved with it: the four matrices of the products below (1.2 MB at D = 200) were evicted from every XCD's
+    //    Interleaved with it: the matrices of the products below (1.2 MB at D = 200) were evicted from every XCD's
     //    L2 by the 2.6 ms of contractions since the last tail launch, and a mat-vec is a chain of dependent load
     //    batches, each of which would pay an HBM / Infinity-Cache round trip (measured 7.6 + 4.0 + 4.0 + 8.7 us for the
     //    four products).  Every 128-byte line of them is touched once here, AFTER the slab loads were issued (vmcnt
@@ -148,6 +178,15 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
 #pragma unroll
             for (int z = 0; z < kHalf; ++z) sv[z] = fc1_part[((size_t)(h * kHalf + z) * B + b) * kEmb + i];
         }
+        // the small per-dimension vectors, the enrolled embeddings, the label and this thread's bias / mean entries: once,
+        // all in flight together with the slabs, for every later phase
+        const int dd = min(tid, D - 1);
+        const float v_psi = m.plda_psi[dd], v_pm = m.plda_mean[dd], v_off = m.lda_t[(size_t)kEmb * m.Dp + dd];
+        const float v_b = m.fc1_b[i], v_mean = m.emb_mean[i];
+        const int64_t v_y = y ? y[b] : 0;
+        float v_enr[kTailEnrCache / NT];
+#pragma unroll
+        for (int z = 0; z < kTailEnrCache / NT; ++z) v_enr[z] = enr_lds ? m.enroll[min(tid + z * NT, S * D - 1)] : 0.f;
         const float sink = touch_matrices(m, want_grad, b, tid);
         if (nsplit == kFc1SplitK) {
 #pragma unroll
@@ -155,15 +194,23 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         } else if (h == 0) {
             for (int z = 0; z < nsplit; ++z) v += fc1_part[((size_t)z * B + b) * kEmb + i];
         }
-        part[h * kMaxD + i] = v;
+        if (h == 1) part[i] = v;
+        if (tid < kMaxD) {
+            c_psi[tid] = v_psi;
+            c_pmean[tid] = v_pm;
+            c_off[tid] = v_off;
+        }
+        if (tid == 0) c_y = v_y;
+#pragma unroll
+        for (int z = 0; z < kTailEnrCache / NT; ++z) c_enr[tid + z * NT] = v_enr[z];
         if (sink == 1.2345e38f && demb) demb[0] = sink;  // never true: keeps the prefetch loads alive
-    }
-    __syncthreads();
-    for (int i = tid; i < kEmb; i += NT) {
-        float v = part[i] + part[kMaxD + i];
-        v += m.fc1_b[i];
-        if (tdnn_emb) tdnn_emb[(size_t)b * kEmb + i] = v;
-        e1[i] = v - m.emb_mean[i];
+        __syncthreads();
+        if (h == 0) {  // halves added in order, then the folded bias, then the global mean (xvector_extract.py:42)
+            float e = v + part[i];
+            e += v_b;
+            if (tdnn_emb) tdnn_emb[(size_t)b * kEmb + i] = e;
+            e1[i] = e - v_mean;
+        }
     }
     __syncthreads();
     TSTAMP(1)
@@ -171,21 +218,21 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     matvec_cols4(m.lda_t, m.Dp, kEmb, m.Dp / 4, e1, e2, part);
     float n2 = 0.f;
     for (int d = tid; d < D; d += NT) {
-        const float acc = e2[d] + m.lda_t[(size_t)kEmb * m.Dp + d];
+        const float acc = e2[d] + c_off[d];
         e2[d] = acc;
         n2 += acc * acc;
     }
     TSTAMP(2)
     // 3. length normalisation (ratio is a constant for the backward pass)
     const float ratio = sqrtD / sqrtf(block_sum(n2, red));
-    for (int d = tid; d < D; d += NT) e2[d] = e2[d] * ratio - m.plda_mean[d];
+    for (int d = tid; d < D; d += NT) e2[d] = e2[d] * ratio - c_pmean[d];
     __syncthreads();
     TSTAMP(3)
     // 4. PLDA transform + normalisation factor
     matvec_cols4(m.plda_pt, m.Dp, D, m.Dp / 4, e2, e4, part);
     TSTAMP(4)
     float qp = 0.f;
-    for (int d = tid; d < D; d += NT) qp += e4[d] * e4[d] / (m.plda_psi[d] + 1.f);
+    for (int d = tid; d < D; d += NT) qp += e4[d] * e4[d] / (c_psi[d] + 1.f);
     const float q = block_sum(qp, red);
     const float fac = sqrtf((float)D / q);
     for (int d = tid; d < D; d += NT) {
@@ -199,35 +246,44 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
         const int lane = tid & 63, wid = tid >> 6;
         const float l2pi = logf(2.f * 3.1415926f) * (float)D;  // plda.py:179 (cancels in the ratio)
         float s0 = 0.f;  // sum e5^2 / (psi + 1)
-        for (int d = lane; d < D; d += 64) s0 += e5[d] * e5[d] * (1.f / (m.plda_psi[d] + 1.f));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+        for (int d = lane; d < D; d += 64) s0 += e5[d] * e5[d] * (1.f / (c_psi[d] + 1.f));
+        s0 = tail_wave_sum(s0);
         const float without = -0.5f * (m.logdet_without + l2pi + s0);
         for (int s = wid; s < S; s += NT / 64) {
             float s1 = 0.f;
             for (int d = lane; d < D; d += 64) {
-                const float psi = m.plda_psi[d];
+                const float psi = c_psi[d];
                 const float r = psi / (psi + 1.f);
-                const float df = e5[d] - r * m.enroll[(size_t)s * D + d];
+                const float df = e5[d] - r * enr[(size_t)s * D + d];
                 s1 += df * df * (1.f / (1.f + r));
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            s1 = tail_wave_sum(s1);
             if (lane == 0) {
                 const float given = -0.5f * (m.logdet_given + l2pi + s1);
-                sc[s] = given - without;
+                const float v = given - without;
+                sc[s] = v;
+                dsc[s] = 0.f;
+                if (scores_out) scores_out[(size_t)b * S + s] = v;
             }
         }
     }
     __syncthreads();
-    for (int s = tid; s < S; s += NT) {
-        if (scores_out) scores_out[(size_t)b * S + s] = sc[s];
-        dsc[s] = 0.f;
-    }
-    __syncthreads();
     TSTAMP(6)
-    // 6-8. decision, loss, d loss / d scores (serial: S is tiny)
-    {
+    // 6-8. decision, loss, d loss / d scores
+    if (S <= 64) {
+        if (tid < 64) {  // one wave, the classes across its lanes; nobody else touches sc / dsc / part until the barrier
+            int64_t dec = 0;
+            const float loss = loss_and_dscores_wave(sc, dsc, part, S, m.threshold, c_y, y != nullptr, ls, &dec, tid,
+                                                     ls.coef_dev ? ls.coef_dev + (size_t)(coef_rows > 0 ? b % coef_rows : b) * S : nullptr);
+            if (tid == 0) {
+                if (dec_out) dec_out[b] = dec;
+                if (dec_trace) dec_trace[b] = dec;
+                if (y && success) success[b] = ls.targeted ? (dec == c_y) : (dec != c_y);
+                if (loss_out) loss_out[b] = loss;
+                if (loss_trace) loss_trace[b] = loss;
+            }
+        }
+    } else {
         int64_t dec = 0;  // scratch: `part` (kTailPart floats >= kMaxS) and `red` (16 floats), both idle here
         const float loss = loss_and_dscores_block(sc, dsc, part, red, S, m.threshold, y ? y[b] : 0, y != nullptr, ls, &dec, tid, NT,
                                                   ls.coef_dev ? ls.coef_dev + (size_t)(coef_rows > 0 ? b % coef_rows : b) * S : nullptr);
@@ -245,30 +301,26 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(TailModelDev m, cons
     // 9. d/d e5 of the score combination
     float dotp = 0.f;
     for (int d = tid; d < D; d += NT) {
-        const float psi = m.plda_psi[d];
+        const float psi = c_psi[d];
         const float r = psi / (psi + 1.f);
         const float iv1 = 1.f / (1.f + r), iv0 = 1.f / (psi + 1.f);
         float g = 0.f;
         for (int s = 0; s < S; ++s) {
             const float w = dsc[s];
-            if (w != 0.f) g += w * (-(e5[d] - r * m.enroll[(size_t)s * D + d]) * iv1 + e5[d] * iv0);
+            if (w != 0.f) g += w * (-(e5[d] - r * enr[(size_t)s * D + d]) * iv1 + e5[d] * iv0);
         }
         dv[d] = g;
         dotp += g * e4[d];
     }
     TSTAMP(8)
-    // 10. through the PLDA normalisation factor (differentiable, plda.py:92-97)
+    // 10. through the PLDA normalisation factor (differentiable, plda.py:92-97), and the length-norm ratio
     const float dot = block_sum(dotp, red);
-    for (int d = tid; d < D; d += NT) dv[d] = fac * dv[d] - dot * (fac / q) * e4[d] / (m.plda_psi[d] + 1.f);
+    for (int d = tid; d < D; d += NT) dv[d] = (fac * dv[d] - dot * (fac / q) * e4[d] / (c_psi[d] + 1.f)) * ratio;
     __syncthreads();
     TSTAMP(9)
-    // 11-12. P^T, length-norm ratio
-    matvec_cols4(m.plda_p, m.Dp, D, m.Dp / 4, dv, e2, part);
+    // 11-13. (P A)^T: P^T and LDA^T in one product -> d loss / d fc1 output
     TSTAMP(10)
-    for (int j = tid; j < D; j += NT) e2[j] *= ratio;
-    __syncthreads();
-    // 13. LDA^T -> d loss / d fc1 output
-    matvec_cols4(m.lda, kLdaLd, D, kEmb / 4, e2, e1, part);
+    matvec_cols4(m.pa, kLdaLd, D, kEmb / 4, dv, e1, part);
     TSTAMP(11)
     for (int i = tid; i < kEmb; i += NT) demb[(size_t)b * kEmb + i] = e1[i];
     TSTAMP(12)
@@ -281,7 +333,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     if (x.D > kMaxD || S > kMaxS || S < 1) return hipErrorInvalidValue;
     TailModelDev m;
     m.fc1_b = x.fc1_b; m.emb_mean = x.emb_mean; m.lda = x.lda; m.lda_t = x.lda_t; m.plda_mean = x.plda_mean;
-    m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi;
+    m.plda_p = x.plda_p; m.plda_pt = x.plda_pt; m.plda_psi = x.plda_psi; m.pa = x.pa;
     m.enroll = x.enroll_override ? x.enroll_override : x.enroll;
     m.D = x.D; m.Dp = x.Dp; m.S = S; m.threshold = x.threshold;
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;

@@ -140,6 +140,45 @@ __device__ __forceinline__ float loss_and_dscores(const float* sc, float* dsc, i
     return loss_and_dscores_given(sc, dsc, S, threshold, yy, has_y, ls, dec_out, coef, mx, ja);
 }
 
+// One-wave form for S <= 64 (the x-vector tail: a handful of enrolled speakers), called by the 64 lanes of ONE wave; the
+// returned loss and *dec_out are valid on lane 0.  Bit-identical to loss_and_dscores: the arg-max is the serial scan (on lane
+// 0), the 2 S expf evaluations of the cross-entropy sit side by side on the lanes, the SUM of the other classes' terms stays
+// in index order on lane 0.  Every other loss is the serial function on lane 0 (no transcendental in them).
+// ex: >= 64 floats of LDS scratch.  The caller separates it from other users of sc / dsc / ex with block barriers.
+__device__ __forceinline__ float loss_and_dscores_wave(const float* sc, float* dsc, float* ex, int S, float threshold, int64_t yy,
+                                                       bool has_y, const sg_loss_spec& ls, int64_t* dec_out, int lane,
+                                                       const float* coef = nullptr) {
+    const bool ce = has_y && ls.loss == SG_LOSS_ENTROPY && ls.task == SG_TASK_CSI && yy >= 0;  // wave-uniform
+    if (!ce) {
+        float loss = 0.f;
+        if (lane == 0) loss = loss_and_dscores(sc, dsc, S, threshold, yy, has_y, ls, dec_out, coef);
+        return loss;
+    }
+    auto fence = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    float mx = 0.f;
+    int ja = 0;
+    if (lane == 0) argmax_in_order(sc, S, mx, ja);
+    mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+    ja = __builtin_amdgcn_readfirstlane(ja);
+    const float mine = lane < S ? sc[lane] : 0.f;
+    if (lane < S) ex[lane] = expf(mine - mx);
+    fence();
+    float loss = 0.f, lse = 0.f;
+    if (lane == 0) {
+        *dec_out = mx > threshold ? (int64_t)ja : (int64_t)-1;
+        const float so = sum_in_order_except(ex, S, ja);
+        lse = logf(1.f + so);
+        loss = lse - (sc[yy] - mx);
+    }
+    lse = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lse)));
+    if (lane < S) dsc[lane] = expf((mine - mx) - lse) - (lane == (int)yy ? 1.f : 0.f);
+    return loss;
+}
+
 // The same (maximum, first index holding it) by the whole block: per-thread scan in ascending index order, then merges
 // that prefer the larger value and, among equal values, the lower index -- order-independent, so the result is the serial
 // one whatever the reduction tree (scores are finite; -inf everywhere gives index 0 like the serial scan).  NaN scores: every

@@ -666,6 +666,20 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
                 p[(size_t)d * Dp + j] = w->plda_transform[(size_t)d * D + j];
                 pt[(size_t)j * Dp + d] = w->plda_transform[(size_t)d * D + j];
             }
+        // (P A)[d][i] = sum_j P[d][j] A[j][i]: the tail's backward applies P^T and LDA^T as one product (k_tail.hip)
+        std::vector<float> pa((size_t)D * kLdaLd, 0.f);
+        {
+            std::vector<double> row(kEmb);
+            for (int d = 0; d < D; ++d) {
+                std::fill(row.begin(), row.end(), 0.0);
+                for (int j = 0; j < D; ++j) {
+                    const double pdj = w->plda_transform[(size_t)d * D + j];
+                    const float* aj = w->lda + (size_t)j * (kEmb + 1);
+                    for (int i = 0; i < kEmb; ++i) row[i] += pdj * (double)aj[i];
+                }
+                for (int i = 0; i < kEmb; ++i) pa[(size_t)d * kLdaLd + i] = (float)row[i];
+            }
+        }
         double ldg = 0.0, ldw = 0.0;
         for (int d = 0; d < D; ++d) {
             const double psi = w->plda_psi[d];
@@ -680,6 +694,7 @@ int sg_xv_load(sg_ctx* ctx, const sg_xv_weights* w) {
         rc |= dev_upload(ctx, pool, &m.plda_mean, std::vector<float>(w->plda_mean, w->plda_mean + D));
         rc |= dev_upload(ctx, pool, &m.plda_p, p);
         rc |= dev_upload(ctx, pool, &m.plda_pt, pt);
+        rc |= dev_upload(ctx, pool, &m.pa, pa);
         rc |= dev_upload(ctx, pool, &m.plda_psi, std::vector<float>(w->plda_psi, w->plda_psi + D));
         rc |= dev_upload(ctx, pool, &m.enroll, std::vector<float>(w->enroll, w->enroll + (size_t)S * D));
     }

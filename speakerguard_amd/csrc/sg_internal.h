@@ -207,6 +207,7 @@ struct XvModel {
     float* plda_mean = nullptr; // [D]
     float* plda_p = nullptr;    // [D][Dp], zero-padded columns
     float* plda_pt = nullptr;   // [D][Dp] transposed, zero-padded columns
+    float* pa = nullptr;        // [D][kLdaLd]: (P A)[d][i], i < 512 -- the backward's P^T and LDA^T as one product (float64 product, rounded once)
     float* plda_psi = nullptr;  // [D]
     float* enroll = nullptr;    // [S][D]
     int enroll_cap = 0;         // speakers the enroll buffer holds (sg_xv_set_enroll reuses it)
