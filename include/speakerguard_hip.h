@@ -308,11 +308,13 @@ int sg_an_logmel(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, float* f
  * or shape differ, the forward is recomputed. */
 int sg_an_logmel_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const float* dfeats_dev, float* grad_dev,
                           int32_t reuse_forward, void* stream);
-/* How the log-mel front-end and its adjoint run on this context (round 5; defaults 32, 1, -1 = the fastest measured):
+/* How the log-mel front-end and its adjoint run on this context (defaults 32, -1, -1 = the library's choice by size):
  *   fft_bits 32 | 64: the scalar type of the STFT's transforms.  The reference computes its STFT in float32
  *     (model/_audionet/Preprocessor.py:100-105, torch.stft on a float32 signal); 64 is the form of rounds 1-4.
  *   spectrum_cache: the forward of a pass keeps every frame's packed spectrum (B x F x 4 KB) for the backward of the same
- *     pass instead of the backward transforming the frame again.
+ *     pass instead of the backward transforming the frame again: 1 / 0, or -1 = decided per call from B x F (it pays
+ *     everywhere except around 24-40 thousand frames).  An optional speed-up: when the buffer cannot be allocated the
+ *     passes run without it.
  *   fused_overlap_add: the adjoint adds the frames' gradients up on chip (and applies the attack's update there) instead
  *     of writing B x F x 800 floats for a second kernel; same sums in the same order, same bits.  1 / 0, or -1: the
  *     library decides per call from the batch (the fused form cuts utterances into runs with 5 halo frames each and pays

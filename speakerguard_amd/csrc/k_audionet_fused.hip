@@ -669,7 +669,10 @@ static int fz_plan(const int* Tin, const int* Tout, int Fnet, int rows, int num_
         }
         return (need + 3) & ~3;
     };
-    // cost model: rounds of blocks on the chip x rows a block works on (its share + ~4 rows of halo, in conv8 rows)
+    // cost model: rounds of blocks on the chip x time of a block, in conv8 rows: its share + 12 -- a block's time is not
+    // proportional to its rows (tools/an_trace.py, forward: 51 us at 2.2 rows, 79 us at 8.75, 163 us at 35: ~42 us + 3.6 us
+    // per row: halo, the layers' barriers and epilogues, the weight stream's start).  Until round 5 the constant was 4 and
+    // 129..255 utterances were cut too finely (192 utterances: 0.77 ms per PGD step against 0.67 at 256).
     int best = 0;
     double best_cost = 0.0;
     const int smax = std::min(T8, 16);
@@ -677,7 +680,7 @@ static int fz_plan(const int* Tin, const int* Tout, int Fnet, int rows, int num_
     for (int S = 1; S <= smax; ++S) {
         if ((size_t)demand(S) * 2 * sizeof(float) > (size_t)kLdsBudget) continue;
         const long blocks = (long)rows * S;
-        const double cost = (double)((blocks + cus - 1) / cus) * ((double)T8 / S + 4.0);
+        const double cost = (double)((blocks + cus - 1) / cus) * ((double)T8 / S + 12.0);
         if (!best || cost < best_cost - 1e-9) {
             best = S;
             best_cost = cost;

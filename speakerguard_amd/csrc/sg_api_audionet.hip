@@ -282,20 +282,44 @@ const float* an_layer_input(const AnWorkspace& w, int l) {
     return kAnPool[l - 1] ? w.pool[l - 1] : w.act[l - 1];
 }
 
+// Does the forward keep the frames' spectra for the adjoint of the same pass?  sg_an_configure: 1 / 0, or -1 = by size
+// (profiles/r06_an_frontend_ab.txt, PGD-20, float32 transforms): the cache wins at every size measured (2-6 % of a step)
+// except between 24 000 and 40 000 frames (80 .. 133 utterances of 3 s: -1 .. -6 %), where the chip is just full of
+// forward waves and the cache's write traffic costs the forward more than the second transform costs the adjoint.
+static bool an_use_spec_cache(const sg_ctx* ctx, int B, int F) {
+    if (ctx->an_cfg.spec_cache >= 0) return ctx->an_cfg.spec_cache != 0;
+    const long frames = (long)B * F;
+    return !(frames >= 24000 && frames < 40000);
+}
+
 // waveform -> log-mel features in ws.feats (the backward of the same pass starts from the stored mel energies)
 int an_frontend_forward(sg_ctx* ctx, const float* x, const AnDims& d, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     if (!d.keep_scale) AN_HIP(launch_input_scale(x, (int64_t)d.B * d.T, ctx->range_scratch, w.scale, 1, s));
     AnTables tab = ctx->an_tab;
     tab.mel_cache = w.mel_cache;
-    if (ctx->an_cfg.spec_cache) {
-        if (!w.spec_cache) {  // first use: room for the workspace's capacity
+    if (an_use_spec_cache(ctx, d.B, d.F)) {
+        // the cache is an optional speed-up: sized for this call (grown when a larger one comes), and a refused allocation
+        // leaves the pass on the backward's own transforms instead of failing it
+        const size_t need = (size_t)d.B * d.F * (kAnFft / 2) * sizeof(float2);
+        if (need > w.spec_cache_bytes && !w.spec_cache_refused) {
             void* p = nullptr;
-            AN_HIP(hipMalloc(&p, (size_t)w.B * w.F * (kAnFft / 2) * sizeof(float2)));
-            w.allocs.push_back(p);
-            w.spec_cache = static_cast<float2*>(p);
+            if (hipMalloc(&p, need) == hipSuccess) {
+                if (w.spec_cache) {
+                    AN_HIP(hipStreamSynchronize(s));  // (an earlier pass may still read the old buffer)
+                    (void)hipFree(w.spec_cache);
+                    w.allocs.erase(std::remove(w.allocs.begin(), w.allocs.end(), static_cast<void*>(w.spec_cache)), w.allocs.end());
+                }
+                w.allocs.push_back(p);
+                w.spec_cache = static_cast<float2*>(p);
+                w.spec_cache_bytes = need;
+            } else {
+                (void)hipGetLastError();
+                w.spec_cache_refused = true;
+                fprintf(stderr, "speakerguard: no room for the %zu MB spectrum cache of the log-mel front-end; the adjoint transforms again\n", need >> 20);
+            }
         }
-        tab.spec_cache = w.spec_cache;
+        if (need <= w.spec_cache_bytes) tab.spec_cache = w.spec_cache;
     }
     w.cache_x = x; w.cache_B = d.B; w.cache_T = d.T; w.cache_spec = tab.spec_cache != nullptr;
     AN_STAGE(SG_STAGE_AN_LOGMEL_FWD, launch_an_logmel_fwd(tab, x, d.B, d.T, d.F, w.scale, w.feats, ctx->an_cfg.fft32, s));
@@ -598,7 +622,7 @@ int sg_an_configure(sg_ctx* ctx, int32_t fft_bits, int32_t spectrum_cache, int32
     if (!ctx) return SG_ERR_ARG;
     if (fft_bits != 32 && fft_bits != 64) return an_fail(ctx, SG_ERR_ARG, "fft_bits must be 32 or 64");
     ctx->an_cfg.fft32 = fft_bits == 32;
-    ctx->an_cfg.spec_cache = spectrum_cache != 0;
+    ctx->an_cfg.spec_cache = spectrum_cache < 0 ? -1 : (spectrum_cache != 0);
     ctx->an_cfg.ola = fused_overlap_add < 0 ? -1 : (fused_overlap_add != 0);
     ctx->an_ws.cache_x = nullptr;  // what an earlier forward left behind was computed under the old settings
     ctx->an_ws.cache_spec = false;

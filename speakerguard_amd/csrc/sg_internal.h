@@ -78,7 +78,7 @@ struct AnTables {            // device pointers
 struct AnFrontCfg {
     // defaults = the fastest measured combination (profiles/r05_an_frontend_ab.txt)
     int fft32 = 1;       // transforms in float32 (the reference's precision) or float64
-    int spec_cache = 1;  // the forward keeps every frame's packed spectrum for the backward of the same pass
+    int spec_cache = -1;  // the forward keeps every frame's packed spectrum for the backward of the same pass: 1 / 0, -1 = by size
     int ola = -1;        // overlap-add (+ update) inside the log-mel adjoint: 1 / 0, -1 = where it pays (an_ola_pays: large batches)
 };
 struct AnOlaArgs {
@@ -134,7 +134,9 @@ struct AnWorkspace {
     float* trace_l = nullptr;    // (B * R) per-row loss / decision records of such a pass (reduced over the repeats afterwards)
     int64_t* trace_d = nullptr;
     float* mel_cache = nullptr;  // (B, F, 32) mel energies of the forward pass, kept for the backward of the same pass
-    float2* spec_cache = nullptr;  // (B, F, 512) packed spectra of the forward pass (allocated when sg_an_configure asks for it)
+    float2* spec_cache = nullptr;  // (B, F, 512) packed spectra of the forward pass (allocated on first use, grown on demand)
+    size_t spec_cache_bytes = 0;
+    bool spec_cache_refused = false;  // an allocation failed once: the passes run without the cache
     float* x_alt = nullptr;      // (B, T) the other half of the waveform ping-pong of the fused overlap-add update (on demand)
     // which input the mel cache belongs to (sg_an_logmel_backward(reuse_forward) checks pointer and shape, not contents)
     const float* cache_x = nullptr;

@@ -80,12 +80,13 @@ class audionet_csine(EngineOps):
     def eval(self):
         return self
 
-    def configure_frontend(self, fft_bits=32, spectrum_cache=True, fused_overlap_add=None):
+    def configure_frontend(self, fft_bits=32, spectrum_cache=None, fused_overlap_add=None):
         """How the STFT front-end runs on the engine (sg_an_configure): float32 transforms are the reference's own precision
         (_audionet/Preprocessor.py:100-105); 64 is the float64 form of rounds 1-4, kept as the counterpart.
-        fused_overlap_add None: the engine picks per call (large batches: inside the adjoint; small: the separate pair)."""
+        spectrum_cache / fused_overlap_add None: the engine picks per call from the batch's size."""
         ola = -1 if fused_overlap_add is None else int(bool(fused_overlap_add))
-        self.ctx.call("sg_an_configure", int(fft_bits), int(bool(spectrum_cache)), ola)
+        cache = -1 if spectrum_cache is None else int(bool(spectrum_cache))
+        self.ctx.call("sg_an_configure", int(fft_bits), cache, ola)
         return self
 
     def _prep(self, x, flag):

@@ -17,7 +17,7 @@ for B in batches:
     y = m.make_decision(x)[0]
     lo, hi = torch.clamp(x - 0.002, min=-1), torch.clamp(x + 0.002, max=1)
     for bits, cache, ola in cfgs:
-        m.configure_frontend(bits, bool(cache), None if ola < 0 else bool(ola))  # ola -1: the engine's own choice
+        m.configure_frontend(bits, None if cache < 0 else bool(cache), None if ola < 0 else bool(ola))  # -1: the engine's own choice
         m.pgd_run(x, y, lo, hi, spec, 0.0004, 3, 1)
         torch.cuda.synchronize()
         best = 1e9
