@@ -57,13 +57,16 @@ int sg_health(sg_ctx* ctx);
  * (attack/FGSM.py _run_batches), before they give up.  Default: enabled. */
 int sg_set_streamk(sg_ctx* ctx, int32_t enable);
 /* TEST HOOK (fault injection for the health path; no production use): the next `launches` stream-K launches of this
- * context publish no hand-off flags, so their waiting blocks time out (after a shortened bound) and raise the health word. */
+ * context publish no hand-off flags, so their waiting blocks time out (after a shortened bound) and raise the health word.
+ * Only launches that really run a stream-K kernel count (a contraction that ends up on a tile kernel does not use the
+ * budget up).  The two-unit k-means protocol below has a budget of its own, set to the same number by the same call. */
 int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches);
 /* The FeCo k-means (sg_feco_kmeans*) runs an instance on TWO compute units when the batch leaves room for it (2 x instances
  * <= compute units): both blocks compute the same clustering and share only the assignment step's work through device
  * memory, every wait bounded (20 us) -- a block whose partner does not show up (GPU shared with something else) computes
  * everything itself: same bits, the one-unit speed.  mode -1: where it fits (default); 0: never.
- * (sg_debug_lose_handoffs also covers this protocol: a launch it counts makes every second block publish nothing.) */
+ * (sg_debug_lose_handoffs also arms this protocol, with its own count: a paired launch it counts makes every second block
+ * publish nothing.) */
 int sg_feco_set_two_cu(sg_ctx* ctx, int32_t mode);
 /* TEST HOOK (no production use): parks the launch counter of the two-unit k-means protocol, so that a test reaches the wrap
  * of the exchange words' 15-bit launch tag (and of the 32-bit counter itself) in a handful of launches instead of 2^15.  The
@@ -332,7 +335,9 @@ int sg_an_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t c
 int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32_t B, int32_t T_or_F,
                     int32_t flag, const sg_loss_spec* loss, int64_t* decisions_dev, float* scores_dev,
                     float* loss_dev, float* grad_dev, void* stream);
-/* attack/FGSM.py:38-70 attack_batch on AudioNet, whole loop on the device (params->dither ignored) */
+/* attack/FGSM.py:38-70 attack_batch on AudioNet, whole loop on the device (params->dither ignored).
+ * On a non-zero return x_adv_dev is UNSPECIFIED (the loop steps between two buffers when the overlap-add runs inside the
+ * adjoint; an error in the middle leaves the caller's buffer on an earlier iterate): discard it with the error. */
 int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const float* lower_dev,
                   const float* upper_dev, int32_t B, int32_t T, const sg_pgd_params* params,
                   uint8_t* success_dev, int64_t* decisions_dev, float* scores_dev, float* loss_dev,

@@ -1012,7 +1012,7 @@ hipError_t launch_an_tail(const float* act8, int B, int T8, const float* fc_w, c
                           uint8_t* success, hipStream_t s, int coef_rows) {
     if (S < 1 || S > kLossMaxS) return hipErrorInvalidValue;
     // tuning aid: SG_AN_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
-    static const bool tr_on = getenv("SG_AN_TAIL_TRACE") != nullptr;
+    static const bool tr_on = sg_tune_env("SG_AN_TAIL_TRACE") != nullptr;
     static PerDeviceScratch tr_buf;
     unsigned long long* tr_dev = tr_on ? static_cast<unsigned long long*>(tr_buf.get(8 * 8)) : nullptr;
     hipLaunchKernelGGL(an_tail_kernel, dim3(B), dim3(256), 0, s, act8, T8, fc_w, fc_b, S, threshold, y, ls, want_grad, emb,

@@ -744,7 +744,7 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
     // two builds of each kernel (fz_mac): small slices -- three or more per utterance, one 32-row tile per wave -- take the
     // deep W ring, whole / half utterances the compact multiply loop with the straight-path epilogues.  Same bits.
     const bool small = S >= 3;
-    static const char* trace_file = getenv("SG_AN_TRACE");  // tuning aid: dump the per-block stage timestamps of every launch
+    static const char* trace_file = sg_tune_env("SG_AN_TRACE");  // tuning aid: dump the per-block stage timestamps of every launch
     static PerDeviceScratch trace_buf;
     const size_t nblk = (size_t)S * rows;
     a.trace = trace_file ? static_cast<unsigned long long*>(trace_buf.get(nblk * 16 * 8)) : nullptr;

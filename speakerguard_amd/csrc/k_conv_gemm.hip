@@ -1468,7 +1468,7 @@ __global__ __launch_bounds__(256) void conv_gemm_s16_kernel(ConvGemmArgs p, int 
 static hipError_t launch_s16(const ConvGemmArgs& a_in, int epi, hipStream_t s) {
     constexpr int R = 6;  // chunks in flight per thread (multiple of 3)
     ConvGemmArgs a = a_in;
-    static const bool tr_on = getenv("SG_S16_TRACE") != nullptr;  // tuning aid: cycle split of block 0 (synchronises)
+    static const bool tr_on = sg_tune_env("SG_S16_TRACE") != nullptr;  // tuning aid: cycle split of block 0 (synchronises)
     static PerDeviceScratch tr_buf;
     unsigned long long* tr_dev = tr_on ? static_cast<unsigned long long*>(tr_buf.get(64)) : nullptr;
     a.trace = tr_dev;
@@ -1511,7 +1511,7 @@ static hipError_t launch_tile_q(const ConvGemmArgs& a, int epi, hipStream_t s) {
     // A nearly empty chip (batch <= 8: fewer 64-row tiles than CUs) waits for the sequential k chain of one tile;
     // 32-row tiles halve the MFMAs per wave and chunk, so the chain -- and the launch -- takes half as long.
     static const int small_rows = [] {
-        const char* e = getenv("SG_TILE32");  // 0 = always 64-row tiles (tuning aid)
+        const char* e = sg_tune_env("SG_TILE32");  // 0 = always 64-row tiles (tuning aid)
         return e ? atoi(e) : 1;
     }();
     const int cus = a.num_cus > 0 ? a.num_cus : 256;
@@ -1565,7 +1565,7 @@ static int streamk_blocks_per_cu() {
 // returns hipErrorNotSupported when the shape does not qualify (caller falls back to the tile launch)
 static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, unsigned* flags, hipStream_t s) {
     static const int w16 = [] {
-        const char* e = getenv("SG_STREAMK_W16");  // 0 = two 8-wave 128x128 blocks per CU
+        const char* e = sg_tune_env("SG_STREAMK_W16");  // 0 = two 8-wave 128x128 blocks per CU
         return e ? atoi(e) : 1;
     }();
     int kind = !a.Wq ? 0 : ((w16 && a.force != 3) ? 2 : 1);
@@ -1576,17 +1576,17 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     // persistent launch to the 4-wave tile kernel at ~100 TFLOP/s.  128-row tiles still give every CU one: run the
     // 8-wave 128x128 kernel with ONE block per CU (2 waves per SIMD; the CU's MFMA rate is what a lone block needs).
     static const int mid = [] {
-        const char* e = getenv("SG_STREAMK_MID");  // 0 = off (tuning aid)
+        const char* e = sg_tune_env("SG_STREAMK_MID");  // 0 = off (tuning aid)
         return e ? atoi(e) : 1;
     }();
     static const int mid9 = [] {
-        const char* e = getenv("SG_STREAMK_MID9");  // 1 = 128-row tiles as four 64 x 64 computing waves (kind 9) instead of kind 5
+        const char* e = sg_tune_env("SG_STREAMK_MID9");  // 1 = 128-row tiles as four 64 x 64 computing waves (kind 9) instead of kind 5
         return e ? atoi(e) : 0;
     }();
     if (mid && kind == 2 && a.force == 0 && ((a.M + 255) / 256) * (a.N / 128) < cus) {
         // deep = 1 (default): the wave-specialised kinds 5 / 6 / 7 (ws_stage_segment / ws_compute_segment); 0: the all-in-one kinds 1 / 3 / 4
         static const int deep = [] {
-            const char* e = getenv("SG_STREAMK_DEEP");
+            const char* e = sg_tune_env("SG_STREAMK_DEEP");
             return e ? atoi(e) : 1;
         }();
         if (((a.M + 127) / 128) * (a.N / 128) >= cus) {
@@ -1607,13 +1607,13 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     }
     // the full batch (>= 256 tiles of 256 rows): kind 8, the 256-row tile with the roles split between waves (round 3)
     static const int ws256 = [] {
-        const char* e = getenv("SG_STREAMK_WS");  // 0 = the all-in-one 16-wave kernel (kind 2)
+        const char* e = sg_tune_env("SG_STREAMK_WS");  // 0 = the all-in-one 16-wave kernel (kind 2)
         return e ? atoi(e) : 1;
     }();
     // measured per layer at 64 utterances (profiles/r03_layers.txt): tdnn2 / tdnn3 (80 / 112 chunks per tile) gain 1-3 % from
     // the split, tdnn4 / tdnn5 (16 / 48 chunks) lose 4-8 %
     static const int ws256_min_chunks = [] {
-        const char* e = getenv("SG_STREAMK_WS_MINCHUNKS");
+        const char* e = sg_tune_env("SG_STREAMK_WS_MINCHUNKS");
         return e ? atoi(e) : 64;
     }();
 
@@ -1630,7 +1630,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
         }
     }
     static const int env_kind = [] {
-        const char* e = getenv("SG_STREAMK_KIND");  // tuning aid: 5 .. 9 = this wave-specialised kind wherever the shape qualifies
+        const char* e = sg_tune_env("SG_STREAMK_KIND");  // tuning aid: 5 .. 9 = this wave-specialised kind wherever the shape qualifies
         return e ? atoi(e) : 0;
     }();
     if (env_kind >= 5 && env_kind <= 9 && a.force == 0 && a.Wq) {
@@ -1658,7 +1658,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     // two workers and never lies strictly inside one range.
     // Very short K (tdnn1 forward: 5 chunks) is faster one block per tile (measured).
     static const int min_chunks = [] {
-        const char* e = getenv("SG_STREAMK_MINCHUNKS");
+        const char* e = sg_tune_env("SG_STREAMK_MINCHUNKS");
         return e ? atoi(e) : 16;  // >= 16 chunks (K >= 512): tdnn4 / tdnn5 gain 4-12 %, tdnn1 (5 chunks) loses
     }();
     if (!slabs || !flags || tiles < workers || ipw < a.total_chunks || a.total_chunks < min_chunks) return hipErrorNotSupported;
@@ -1672,11 +1672,16 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     static std::atomic<unsigned> launch_counter{0};
     unsigned epoch = ++launch_counter;
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
-    static const char* trace_file = getenv("SG_SK_TRACE");  // tuning aid: dump per-worker phase timestamps
+    static const char* trace_file = sg_tune_env("SG_SK_TRACE");  // tuning aid: dump per-worker phase timestamps
     static PerDeviceScratch trace_buf;
     unsigned long long* trace_dev = trace_file ? static_cast<unsigned long long*>(trace_buf.get((size_t)workers * 16 * 8)) : nullptr;
     ConvGemmArgs at = a;
     at.trace = trace_dev;
+    if (at.lose_counter && *at.lose_counter > 0) {  // fault injection: THIS stream-K launch publishes no hand-off flags
+        at.ablate |= 8;
+        --*at.lose_counter;
+    }
+    at.lose_counter = nullptr;
     dim3 grid(workers);
 #define a at
 #define SG_SK(EPI)                                                                                          \
@@ -1738,25 +1743,25 @@ int conv_gemm_tile_rows(int M, int N) {
 hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int splits, hipStream_t s) {
 #ifdef SG_EXP_ABLATE  // timing experiments (results become wrong): never in the shipped library
     static const int ablate = [] {
-        const char* e = getenv("SG_ABLATE");
+        const char* e = sg_tune_env("SG_ABLATE");
         return e ? atoi(e) : 0;
     }();
 #else
     constexpr int ablate = 0;
 #endif
     static const int use_streamk = [] {
-        const char* e = getenv("SG_STREAMK");  // 0 = always one block per tile
+        const char* e = sg_tune_env("SG_STREAMK");  // 0 = always one block per tile
         return e ? atoi(e) : 1;
     }();
     ConvGemmArgs a = a_in;
     a.ablate |= ablate;  // (a_in.ablate: the fault-injection bit of sg_debug_lose_handoffs)
     static const int sk_xcd = [] {
-        const char* e = getenv("SG_STREAMK_XCD");  // tuning aid, see the kernel
+        const char* e = sg_tune_env("SG_STREAMK_XCD");  // tuning aid, see the kernel
         return e ? atoi(e) : 2;
     }();
     a.sk_xcd = sk_xcd;
     static const int use_quad = [] {
-        const char* e = getenv("SG_QUADFEED");  // 0 = b32-fed 8-wave kernel even when packed weights exist
+        const char* e = sg_tune_env("SG_QUADFEED");  // 0 = b32-fed 8-wave kernel even when packed weights exist
         return e ? atoi(e) : 1;
     }();
     if (!use_quad || a.force == 2 || (a.ldw % 4) || (a.Kc % 4)) a.Wq = nullptr;
@@ -1771,7 +1776,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs& a_in, int tile, int epi, int spl
     a.w_bytes = (unsigned)w_bytes;
     // batch 1-4: so few 16 x 16 output blocks that every one can have a SIMD (almost) to itself
     static const long s16_max = [] {
-        const char* e = getenv("SG_S16_MAX_BLOCKS");  // 0 = never (tuning aid)
+        const char* e = sg_tune_env("SG_S16_MAX_BLOCKS");  // 0 = never (tuning aid)
         return e ? atol(e) : 2800L;
     }();
     if ((tile == 0 || tile == 2) && splits == 1 && a.Wq && (a.N % 32) == 0 &&

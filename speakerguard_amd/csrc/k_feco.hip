@@ -733,8 +733,8 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
     JC = JC > kFecoMaxChunks ? kFecoMaxChunks : JC;
     while (JC > 1 && JC * F > kFecoMergeCap) --JC;
 #ifdef SG_EXP_FECO_JC
-    if (const char* ev = getenv("SG_FECO_ABLATE")) { const int a = atoi(ev); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_ablate), &a, sizeof(a)); }
-    if (const char* ev = getenv("SG_FECO_JC")) { JC = atoi(ev); JC = JC < 1 ? 1 : (JC > ntc ? ntc : JC); while (JC > 1 && JC * F > kFecoMergeCap) --JC; }
+    if (const char* ev = sg_tune_env("SG_FECO_ABLATE")) { const int a = atoi(ev); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_ablate), &a, sizeof(a)); }
+    if (const char* ev = sg_tune_env("SG_FECO_JC")) { JC = atoi(ev); JC = JC < 1 ? 1 : (JC > ntc ? ntc : JC); while (JC > 1 && JC * F > kFecoMergeCap) --JC; }
 #endif
     // two CUs per instance (FecoPair): same units as one block would get (cutting them finer -- 30 units of 1-2 tiles for
     // the 32 waves -- measured 94.3 against 92.5 us per call: the SIMDs are throughput-bound, the merge grows)
@@ -784,9 +784,9 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
             pr.flags = ctx->feco_flags;
             pr.launch = ctx->feco_epoch;
             pr.tag0 = (ctx->feco_epoch & 0x7FFFu) << 6;
-            if (ctx->lose_handoffs > 0) {  // test hook (sg_debug_lose_handoffs): this launch's second halves publish nothing
+            if (ctx->lose_feco > 0) {  // test hook (sg_debug_lose_handoffs): this launch's second halves publish nothing
                 pr.drop = 1;
-                --ctx->lose_handoffs;
+                --ctx->lose_feco;
             }
         }
     }
@@ -836,7 +836,7 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
                            max_iter, seeded, seed, index_base, x_in_lds, fast_lists, JC, sched, pr, assign_dev, out_dev, counts_dev);
     e = hipGetLastError();
     if (e != hipSuccess) return feco_fail(ctx, SG_ERR_HIP, "sg_feco_kmeans: %s", hipGetErrorString(e));
-    static const bool tr_on = getenv("SG_FECO_TRACE") != nullptr;
+    static const bool tr_on = sg_tune_env("SG_FECO_TRACE") != nullptr;
     if (tr_on) {
         static bool armed[kMaxDevices] = {};  // the switch is a device symbol: one per device
         const int dslot = sg_device_slot();

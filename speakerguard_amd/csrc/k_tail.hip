@@ -338,7 +338,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     m.D = x.D; m.Dp = x.Dp; m.S = S; m.threshold = x.threshold;
     m.logdet_given = x.logdet_given; m.logdet_without = x.logdet_without;
     // tuning aid: SG_TAIL_TRACE=1 prints the phase timestamps (100 MHz) of block 0 after every launch (synchronises)
-    static const bool tr_on = getenv("SG_TAIL_TRACE") != nullptr;
+    static const bool tr_on = sg_tune_env("SG_TAIL_TRACE") != nullptr;
     static PerDeviceScratch tr_buf;
     unsigned long long* tr_dev = tr_on ? static_cast<unsigned long long*>(tr_buf.get(16 * 8)) : nullptr;
     const int grid = a.B < 64 ? 64 : a.B;  // small batches: helper blocks up to one full set of 8 per XCD (see touch_matrices)

@@ -459,7 +459,7 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
                                                     w.dfeats_raw, kCep, d.B, d.F, s));
         MfccTables tab = ctx->tab;
         static const bool use_cache = [] {
-            const char* e = getenv("SG_MFCC_CACHE");  // 0 = recompute the forward in the backward kernel
+            const char* e = sg_tune_env("SG_MFCC_CACHE");  // 0 = recompute the forward in the backward kernel
             return !e || atoi(e) != 0;
         }();
         if (use_cache) {
@@ -538,7 +538,7 @@ int sg_health(sg_ctx* ctx) {
         __atomic_store_n(ctx->err_host, 0u, __ATOMIC_RELAXED);
         return fail(ctx, SG_ERR_HIP, "a stream-K hand-off wait timed out inside an earlier contraction launch (partner block "
                     "not resident: CU mask or a competing kernel?); results produced since then are invalid. "
-                    "SG_STREAMK=0 selects the one-block-per-tile launches");
+                    "sg_set_streamk(ctx, 0) selects the one-block-per-tile launches");
     }
     return SG_OK;
 }
@@ -552,6 +552,7 @@ int sg_set_streamk(sg_ctx* ctx, int32_t enable) {
 int sg_debug_lose_handoffs(sg_ctx* ctx, int32_t launches) {
     if (!ctx || launches < 0) return SG_ERR_ARG;
     ctx->lose_handoffs = launches;
+    ctx->lose_feco = launches;
     return SG_OK;
 }
 
@@ -937,7 +938,7 @@ int sg_xv_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
         size_t per_utt = 0;
         for (int l = 0; l < kLayers; ++l) per_utt = std::max(per_utt, (size_t)Fl[l] * kCoutPad[l] * sizeof(float));
         long max_rows = (long)(0x7FFFFFFFull / per_utt);
-        if (const char* e = getenv("SG_EOT_MAX_ROWS")) max_rows = std::min<long>(max_rows, atol(e));  // tests: force groups
+        if (const char* e = sg_tune_env("SG_EOT_MAX_ROWS")) max_rows = std::min<long>(max_rows, atol(e));  // tests: force groups
         G = (int)std::min<long>(reps, std::max<long>(1, max_rows / B));
     }
     PassDims d;

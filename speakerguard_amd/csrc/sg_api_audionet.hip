@@ -331,13 +331,13 @@ int an_frontend_forward(sg_ctx* ctx, const float* x, const AnDims& d, hipStream_
 // SG_AN_FUSED=0: the per-layer launch sequence of rounds 1-3 (the fused kernels' bit-exact counterpart: tests compare the
 // two); SG_AN_SLICES=n: n time slices per utterance instead of the planner's choice.  Read per call (tests flip them).
 bool an_use_fused(sg_ctx* ctx, int rows, int Fnet) {
-    const char* e = getenv("SG_AN_FUSED");
+    const char* e = sg_tune_env("SG_AN_FUSED");
     if (e && atoi(e) == 0) return false;
     const AnWorkspace& w = ctx->an_ws;
     return an_fused_supported(w.Tin, w.Tout, Fnet, rows, ctx->num_cus);
 }
 int an_forced_slices() {
-    const char* e = getenv("SG_AN_SLICES");
+    const char* e = sg_tune_env("SG_AN_SLICES");
     return e ? atoi(e) : 0;
 }
 AnFusedArgs an_fused_args(sg_ctx* ctx, int Fnet) {

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -270,6 +271,7 @@ struct sg_ctx {
     unsigned* err_dev = nullptr;
     bool use_streamk = true;         // sg_set_streamk
     int lose_handoffs = 0;           // sg_debug_lose_handoffs: stream-K launches left that publish no hand-off flags
+    int lose_feco = 0;               // ... and paired k-means launches left whose second halves publish nothing (own budget)
     // FeCo k-means over two CUs per instance (k_feco.hip): exchange buffers + flags, the launch counter the flag values
     // are derived from, and the switch (sg_feco_set_two_cu: -1 where it fits, 0 never)
     unsigned long long* feco_xchg = nullptr;
@@ -347,11 +349,23 @@ struct ConvGemmArgs {
     float* sk_slabs;    // stream-K: [768][64*128] parked partial tiles (may be null -> tile launch)
     unsigned* sk_flags; // stream-K: [768] hand-off flags
     unsigned* err_word; // stream-K: device-visible health word (bit 0 = a hand-off wait timed out), may be null
+    int* lose_counter;  // HOST pointer (never dereferenced on the device): the context's fault-injection budget, may be null
 };
 
 // A process may hold one sg_ctx per GPU: whatever a launcher remembers between calls -- the > 64 KB dynamic-LDS opt-in of a
 // kernel, a tuning aid's device buffer -- is remembered PER DEVICE (index = the current device, which every entry point
 // sets from its context before launching).
+// Tuning, tracing and test knobs are environment variables that count ONLY when SG_TUNE=1 is set as well (INTEGRATION.md,
+// "Environment"): without it the library runs its own choices and a stray SG_* variable in a user's environment changes
+// nothing.  The gate is read once per process; the knobs keep their own read-once / read-per-call behaviour.
+inline const char* sg_tune_env(const char* name) {
+    static const bool on = [] {
+        const char* e = getenv("SG_TUNE");
+        return e && atoi(e) != 0;
+    }();
+    return on ? getenv(name) : nullptr;
+}
+
 constexpr int kMaxDevices = 64;
 inline int sg_device_slot() {
     int d = 0;
@@ -382,10 +396,9 @@ inline void conv_ctx_args(sg_ctx* ctx, ConvGemmArgs& a) {
     a.num_cus = ctx->num_cus;
     a.no_streamk = ctx->use_streamk ? 0 : 1;
     a.ablate = 0;
-    if (ctx->lose_handoffs > 0 && ctx->use_streamk) {  // test hook: this launch's stream-K hand-offs get lost
-        a.ablate = 8;
-        --ctx->lose_handoffs;
-    }
+    // test hook (sg_debug_lose_handoffs): launch_streamk takes a launch off this counter when it actually launches a
+    // stream-K kernel -- launches that end up on tile kernels (tdnn1, split-K, forced kinds) do not use the budget up
+    a.lose_counter = ctx->use_streamk ? &ctx->lose_handoffs : nullptr;
 }
 
 // tile: 0 = auto (stream-K 128x128 8-wave blocks when the shape qualifies, else 64x128), 1 = 128x32 (4x1 waves),

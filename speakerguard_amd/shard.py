@@ -218,7 +218,10 @@ class ShardedAttack:
         every chunk of ``batch_size`` utterances is cut over the ranks; the attacker's ``batch_mean`` hook all-gathers
         the chunk's per-utterance losses and takes the mean over the full chunk in the unsharded order, so all ranks
         stop where the unsharded run stops.  A rank without utterances in a chunk (chunk smaller than the world)
-        re-runs utterance 0 of the chunk and drops the result: every rank makes the same sequence of exchanges."""
+        re-runs utterance 0 of the chunk and drops the result: every rank makes the same sequence of exchanges.
+        With a batch-coupled model (``model.batch_coupled``: FeCo's `force = feat.shape[0] > 1`) a chunk of two or more
+        utterances is cut so that every rank's call holds at least two (``row_slices_coupled``), and a one-utterance chunk
+        stays a one-utterance call everywhere."""
         a = self.attacker
         world, rank = self._world()
         a._check_inputs(x, y)
@@ -231,7 +234,8 @@ class ShardedAttack:
         try:
             for batch_id, s in enumerate(range(0, n, bs)):
                 e = min(n, s + bs)
-                run, keep = row_slices(e - s, world)
+                # a batch-coupled model (FeCo) must not see one-utterance calls the unsharded run does not make
+                run, keep = row_slices_coupled(e - s, world) if self._batch_coupled() else row_slices(e - s, world)
                 lo, hi = s + run[rank][0], s + run[rank][1]
 
                 def mean_hook(loss, run=run, keep=keep):
@@ -262,6 +266,18 @@ def row_slices(n, world):
     row 0 and its result is dropped: every rank makes the same sequence of model calls, so per-call state (the
     front-end's noise draw counter) stays aligned over ranks."""
     return [(s, e) if e > s else (0, 1) for s, e in shard_bounds(n, world)], shard_bounds(n, world)
+
+
+def row_slices_coupled(n, world):
+    """``row_slices`` for a batch-coupled model: the model behaves differently on a call that holds ONE utterance, so a chunk
+    of n >= 2 utterances goes to min(world, n // 2) ranks with at least two each; the other ranks re-run rows 0 and 1 (a call of
+    two, like everybody's) and drop the result.  A one-utterance chunk is a one-utterance call in the unsharded run too:
+    plain ``row_slices``."""
+    if n < 2:
+        return row_slices(n, world)
+    active = min(world, n // 2)
+    keep = shard_bounds(n, active) + [(n, n)] * (world - active)
+    return [(s, e) if e > s else (0, 2) for s, e in keep], keep
 
 
 class QueryShardedModel:

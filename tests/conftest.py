@@ -19,6 +19,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 ORACLE_THREADS = max(1, min(16, os.cpu_count() or 1))
 for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, str(ORACLE_THREADS))
+# the library's tuning / test knobs (SG_AN_FUSED, SG_AN_SLICES, SG_STREAMK, SG_EOT_MAX_ROWS ...: tests flip them) count only
+# behind this gate (speakerguard_amd/csrc/sg_internal.h sg_tune_env, INTEGRATION.md "Environment")
+os.environ.setdefault("SG_TUNE", "1")
 import torch  # noqa: E402
 
 torch.set_num_threads(ORACLE_THREADS)

@@ -248,3 +248,46 @@ def test_batch_coupled_model_is_cut_without_new_single_utterance_calls(tmp_path)
         assert got["succ"] == list(ref_succ) and torch.equal(got["adv"], ref_adv), (n, bs, world)
         if n % bs == 1:  # the coupling is real: the lone utterance's result differs from the uncoupled model's
             assert not torch.equal(ref_adv[-1], plain_adv[-1])
+
+
+def _coupled_cw2(bs):
+    toy = ToyModel().eval()
+    for p in toy.parameters():
+        p.requires_grad_(False)
+    return CW2(_CoupledEngine(toy, per_row=True), initial_const=0.5, binary_search_steps=2, max_iter=9, stop_early=True,
+               stop_early_iter=3, lr=5e-3, batch_size=bs, verbose=0)
+
+
+def _coupled_cw2_worker(rank, world, port, n, bs, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    x, y = _data(n)
+    rec = _Recording(_coupled_cw2(bs))
+    adv, succ = ShardedAttack(rec).attack(x, y)
+    chunks = [None] * world
+    dist.all_gather_object(chunks, rec.seen)
+    if rank == 0:
+        torch.save({"adv": adv, "succ": succ, "chunks": chunks}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_coupled_model_under_the_mean_coupled_cut(tmp_path):
+    """CW2 with stop_early takes the mean-coupled path (every chunk cut over the ranks), which used to hand single
+    utterances of a larger chunk to ranks -- a FeCo-defended model then flips `force = feat.shape[0] > 1`.  With
+    row_slices_coupled every call of a chunk of >= 2 holds >= 2 utterances (5 utterances on 3 ranks: 3 + 2 + a dropped re-run of
+    two), a chunk of one stays a call of one, and the sharded attack equals the unsharded one."""
+    from speakerguard_amd.shard import row_slices_coupled
+    assert row_slices_coupled(5, 3) == ([(0, 3), (3, 5), (0, 2)], [(0, 3), (3, 5), (5, 5)])
+    assert row_slices_coupled(1, 2) == ([(0, 1), (0, 1)], [(0, 1), (1, 1)])
+    assert row_slices_coupled(4, 2) == ([(0, 2), (2, 4)], [(0, 2), (2, 4)])
+    for n, bs, world, want in ((5, 64, 3, [[3], [2], [2]]), (5, 4, 2, [[2, 1], [2, 1]])):
+        x, y = _data(n)
+        ref_adv, ref_succ = _coupled_cw2(bs).attack(x, y)
+        out = str(tmp_path / ("coupled_cw2_%d_%d_%d.pt" % (n, bs, world)))
+        mp.spawn(_coupled_cw2_worker, args=(world, _free_port(), n, bs, out), nprocs=world, join=True)
+        got = torch.load(out)
+        assert got["chunks"] == want, (n, bs, world, got["chunks"])
+        assert got["succ"] == list(ref_succ) and torch.allclose(got["adv"], ref_adv, atol=0, rtol=0), (n, bs, world)

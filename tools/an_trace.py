@@ -1,6 +1,7 @@
 """Stage times inside the fused AudioNet CNN kernels (SG_AN_TRACE: per-block timestamps at the stage boundaries, 100 MHz).
     python tools/an_trace.py B"""
-import os, sys, statistics
+import os, sys
+os.environ.setdefault("SG_TUNE", "1")  # the knobs below count only behind this gate, statistics
 TRACE = "/tmp/an_trace.txt"
 os.environ["SG_AN_TRACE"] = TRACE
 import torch

@@ -1,6 +1,7 @@
 """The AudioNet CNN alone (feature-level pass: no log-mel front-end): in-loop launch times from the library's stage trace,
 fused kernels (default) against the per-layer sequence (SG_AN_FUSED=0).  python tools/audionet_cnn_bench.py [B ...]"""
-import os, sys, statistics
+import os, sys
+os.environ.setdefault("SG_TUNE", "1")  # the knobs below count only behind this gate, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speakerguard_amd import synth

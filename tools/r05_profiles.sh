@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_feco -o feco -
 for B in 64 512; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_an$B -o an -- python3 tools/audionet_profile.py $B > $out/an_profile_b$B.log 2>&1
 done
-SG_FECO_TRACE=1 python tools/feco_an_profile.py 64 random 2> $out/feco_trace.txt | tail -1 >> $out/feco_trace.txt
+SG_TUNE=1 SG_FECO_TRACE=1 python tools/feco_an_profile.py 64 random 2> $out/feco_trace.txt | tail -1 >> $out/feco_trace.txt
 python tools/batch_sweep.py > $out/batch_sweep.txt 2>&1
 python tools/audionet_cnn_bench.py 64 128 512 > $out/audionet_cnn_bench.txt 2>&1
 python tools/config_bench.py > $out/config_bench.txt 2>&1
