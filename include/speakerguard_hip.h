@@ -387,7 +387,8 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
 #define SG_STAGE_AN_CONV_FWD 30
 #define SG_STAGE_AN_CONV_BWD 40
 #define SG_STAGE_AN_FUSED_FWD 50 /* the whole conv stack of a pass in one launch (round 4) */
-#define SG_STAGE_AN_FUSED_BWD 51
+#define SG_STAGE_AN_FUSED_BWD 51 /* (round 6: with the network's head inside, when a gradient follows) */
+#define SG_STAGE_AN_FUSED_FWDBWD 52 /* forward + head + backward of whole utterances in one launch (round 6) */
 int sg_trace_begin(sg_ctx* ctx, int32_t max_records);
 int sg_trace_end(sg_ctx* ctx, int32_t* tags_out, float* ms_out, int32_t capacity, int32_t* n_out);
 

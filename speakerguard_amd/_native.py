@@ -34,7 +34,7 @@ STAGE_NAMES.update({-l: "tdnn%d_dgrad" % l for l in range(1, 6)})
 # AudioNet (SG_STAGE_AN_*): conv block l = conv(l + 2) of audionet_csine.py
 STAGE_NAMES.update({20: "an_logmel_fwd", 21: "an_prefilter_fwd", 22: "an_pool_fwd", 23: "an_tail", 24: "an_pool_bwd",
                     25: "an_prefilter_bwd", 26: "an_logmel_bwd", 27: "an_overlap_add", 28: "an_feco_fwd", 29: "an_feco_bwd",
-                    50: "an_cnn_fwd", 51: "an_cnn_bwd"})
+                    50: "an_cnn_fwd", 51: "an_cnn_bwd", 52: "an_cnn_fwdbwd"})
 STAGE_NAMES.update({30 + l: "an_conv%d_fwd" % (l + 2) for l in range(7)})
 STAGE_NAMES.update({40 + l: "an_conv%d_dgrad" % (l + 2) for l in range(7)})
 

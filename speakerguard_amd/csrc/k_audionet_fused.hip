@@ -29,6 +29,7 @@
 
 #include <atomic>
 
+#include "loss_device.h"
 #include "sg_internal.h"
 
 namespace sg {
@@ -36,6 +37,7 @@ namespace sg {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kFzThreads = 512, kFzWaves = 8;
+constexpr int kFzHeadFloats = 4096;  // LDS scratch of the in-kernel head (fz_head): 3 x 1024 class slots + 872 small ones
 
 __host__ __device__ constexpr int fz_min(int a, int b) { return a < b ? a : b; }
 __host__ __device__ constexpr int fz_max(int a, int b) { return a > b ? a : b; }
@@ -423,11 +425,7 @@ __device__ __forceinline__ void fz_fwd_layer(const AnFusedArgs& p, const AnSlice
 }
 
 template <bool SMALL>
-__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
-    float* bufA = fz_lds;
-    float* bufB = fz_lds + p.buf_floats;
-    const int row = blockIdx.y;
+__device__ __forceinline__ void fz_forward_body(const AnFusedArgs& p, int row, float* bufA, float* bufB) {
     FZ_STAMP(0)
     AnSlice r;
     an_slice_fwd(p.Tin, p.Tout, p.Fnet, p.S, blockIdx.x, r);
@@ -491,13 +489,19 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p
     FZ_STAMP(8)
 }
 
+template <bool SMALL>
+__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwd_kernel(AnFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
+    fz_forward_body<SMALL>(p, blockIdx.y, fz_lds, fz_lds + p.buf_floats);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // backward layer L: d act[L] (Cout channels) in `in` -- LDS row 0 = row olo[L] + pad - 2 ... i.e. the window of rows
 // [wlo[L] + pad - 2, whi[L] + pad) of d act[L], zero outside the tensor --; the data gradient gives d (input of conv L)
 // rows [wlo[L], whi[L]); un-pooled / masked with the forward activations it becomes d act[L - 1] in `out` (LDS window
 // of the next data gradient), or d pre for L = 0.
 template <int L, bool SMALL>
-__device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice& r, int row, const float* in, float* out) {
+__device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice& r, int row, const float* in, float* out, const float* wq) {
     constexpr int K = kAnCout[L], N = kAnCin[L];
     constexpr bool FIRST = L == 0;
     constexpr bool INPOOL = !FIRST && kAnPool[L > 0 ? L - 1 : 0];  // conv L reads the pooled output of block L - 1
@@ -518,7 +522,7 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
     const float* aprev = FIRST ? nullptr : p.act[L > 0 ? L - 1 : 0] + (size_t)row * Tprev * N;
     // (epilogue structure as in the forward layer: wave-uniform straight path for whole tiles inside the next window, 32-bit
     // offsets, per-element checks only on ragged tiles)
-    fz_layer<K, N, true, SMALL>(in, p.wq[L], n_out, [](int) __attribute__((always_inline)) { return 0; },
+    fz_layer<K, N, true, SMALL>(in, wq, n_out, [](int) __attribute__((always_inline)) { return 0; },
                          [&](auto nvt, int m0, int th, int r0, int col, const auto& acc, int) __attribute__((always_inline)) {
         constexpr int NV = decltype(nvt)::value;  // (interface: see the forward layer)
         const bool full = !SMALL && m0 + th <= n_out;  // all rows of the tile are rows of d input-of-L to produce (SMALL: checked form only)
@@ -588,43 +592,135 @@ __device__ __forceinline__ void fz_bwd_layer(const AnFusedArgs& p, const AnSlice
     __syncthreads();
 }
 
-template <bool SMALL>
-__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
-    float* bufA = fz_lds;
-    float* bufB = fz_lds + p.buf_floats;
-    const int row = blockIdx.y;
-    FZ_STAMP(0)
+// The head of the network for the block's utterance (AnHeadArgs): scratch in `scr` (>= 6 K floats of the idle LDS buffer), the
+// window of d loss / d conv8 pre-activation rows [base, base + rows) -> `win` ([rows][32], fz_off<32>, zero outside the tensor).
+// Phase by phase an_tail_kernel's arithmetic (k_audionet.hip) on the first 256 threads where that kernel's 256 matter for
+// the order of a sum: the same bits.
+__device__ __forceinline__ void fz_head(const AnFusedArgs& p, int row, bool writes, float* scr, float* win, int base, int rows) {
+    const AnHeadArgs& h = p.head;
+    const int tid = threadIdx.x, T8 = p.Tout[kAnConv - 1], S = h.S;
+    float* sc = scr;                    // [1024]
+    float* dsc = scr + 1024;            // [1024]
+    float* ex = scr + 2048;             // [1024]
+    float* bc = scr + 3072;             // [8]
+    float* emb = scr + 3080;            // [32]
+    int* arg = reinterpret_cast<int*>(scr + 3112);   // [32]
+    float* demb = scr + 3144;           // [32]
+    float* pmx = scr + 3176;            // [8][32]
+    int* pat = reinterpret_cast<int*>(scr + 3432);   // [8][32]
+    float* part = scr + 3688;           // [8][32]
+    const float* a = p.act[kAnConv - 1] + (size_t)row * T8 * 32;
+    fz_zero(win, rows * 32);
+    if (tid < 256) {  // x.max(2): first maximum; eight time slices per channel, merged in time order with a strict >
+        const int c = tid & 31, sl = tid >> 5;
+        const int t0 = (int)((long long)T8 * sl / 8), t1 = (int)((long long)T8 * (sl + 1) / 8);
+        float mx = -INFINITY;
+        int at = t0;
+        for (int t = t0; t < t1; ++t) {
+            const float v = a[(size_t)t * 32 + c];
+            if (v > mx) { mx = v; at = t; }
+        }
+        pmx[sl * 32 + c] = mx;
+        pat[sl * 32 + c] = at;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float mx = pmx[tid];
+        int at = pat[tid];
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (pmx[i * 32 + tid] > mx) { mx = pmx[i * 32 + tid]; at = pat[i * 32 + tid]; }
+        emb[tid] = mx;
+        arg[tid] = at;
+        if (writes && h.emb_out) h.emb_out[(size_t)row * 32 + tid] = mx;
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += kFzThreads) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc += h.fc_w[(size_t)s * 32 + c] * emb[c];
+        acc += h.fc_b[s];
+        sc[s] = acc;
+        dsc[s] = 0.f;
+        if (writes && h.scores_out) h.scores_out[(size_t)row * S + s] = acc;
+    }
+    __syncthreads();
+    {
+        int64_t dec = 0;
+        const int64_t yy = h.y ? h.y[row] : 0;
+        const float loss = loss_and_dscores_block(sc, dsc, ex, bc, S, h.threshold, yy, h.y != nullptr, h.ls, &dec, tid, kFzThreads,
+                                                  h.ls.coef_dev ? h.ls.coef_dev + (size_t)(h.coef_rows > 0 ? row % h.coef_rows : row) * S : nullptr);
+        if (writes && tid == 0) {
+            if (h.dec_out) h.dec_out[row] = dec;
+            if (h.dec_trace) h.dec_trace[row] = dec;
+            if (h.y && h.success) h.success[row] = h.ls.targeted ? (dec == yy) : (dec != yy);
+            if (h.loss_out) h.loss_out[row] = loss;
+            if (h.loss_trace) h.loss_trace[row] = loss;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {  // d emb[c] = sum_s dsc[s] fc_w[s][c]: 8 class-strided partial sums per channel, combined in order
+        const int c = tid & 31, q = tid >> 5;
+        float acc = 0.f;
+        for (int s = q; s < S; s += 8) acc += dsc[s] * h.fc_w[(size_t)s * 32 + c];
+        part[q * 32 + c] = acc;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float r = part[tid];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) r += part[i * 32 + tid];
+        demb[tid] = r;
+    }
+    __syncthreads();
+    // gradient wrt the pre-activation of conv8: only the arg-max frame of each channel, if it is > 0
+    for (int idx = tid; idx < rows * 32; idx += kFzThreads) {
+        const int q = idx >> 5, c = idx & 31, t = base + q;
+        if (t >= 0 && t < T8) win[fz_off<32>(q, c)] = (t == arg[c] && emb[c] > 0.f) ? demb[c] : 0.f;
+    }
+    __syncthreads();
+}
+
+// BOTH: the backward half of the one-launch form (weights from p.wq_bwd, no stage stamps: the forward's own them)
+template <bool SMALL, bool HEAD, bool BOTH>
+__device__ __forceinline__ void fz_backward_body(const AnFusedArgs& p, int row, float* bufA, float* bufB) {
+#define FZ_BSTAMP(i) if constexpr (!BOTH) { FZ_STAMP(i) }
+    FZ_BSTAMP(0)
     AnSlice r;
     an_slice_bwd(p.Tin, p.Tout, p.Fnet, p.S, blockIdx.x, r);
-    // ---- d act[6] window from memory: rows [wlo[6] + pad - 2, whi[6] + pad) of (T8, 32), zero outside
+    // ---- d act[6] window: rows [wlo[6] + pad - 2, whi[6] + pad) of (T8, 32), zero outside -- from memory, or from the head
     {
         constexpr int L = kAnConv - 1;
         const int T8 = p.Tout[L], base = r.wlo[L] + kAnPad[L] - 2, rows = r.whi[L] - r.wlo[L] + 2;
-        fz_zero(bufA, rows * 32);
-        __syncthreads();
-        const float* src = p.dtop + (size_t)row * T8 * 32;
-        for (int idx = threadIdx.x; idx < rows * 32; idx += kFzThreads) {
-            const int q = idx >> 5, c = idx & 31, t = base + q;
-            if (t >= 0 && t < T8) bufA[fz_off<32>(q, c)] = src[(size_t)t * 32 + c];
+        if constexpr (HEAD) {
+            fz_head(p, row, blockIdx.x == 0, bufB, bufA, base, rows);
+        } else {
+            fz_zero(bufA, rows * 32);
+            __syncthreads();
+            const float* src = p.dtop + (size_t)row * T8 * 32;
+            for (int idx = threadIdx.x; idx < rows * 32; idx += kFzThreads) {
+                const int q = idx >> 5, c = idx & 31, t = base + q;
+                if (t >= 0 && t < T8) bufA[fz_off<32>(q, c)] = src[(size_t)t * 32 + c];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    FZ_STAMP(1)
-    fz_bwd_layer<6, SMALL>(p, r, row, bufA, bufB);
-    FZ_STAMP(2)
-    fz_bwd_layer<5, SMALL>(p, r, row, bufB, bufA);
-    FZ_STAMP(3)
-    fz_bwd_layer<4, SMALL>(p, r, row, bufA, bufB);
-    FZ_STAMP(4)
-    fz_bwd_layer<3, SMALL>(p, r, row, bufB, bufA);
-    FZ_STAMP(5)
-    fz_bwd_layer<2, SMALL>(p, r, row, bufA, bufB);
-    FZ_STAMP(6)
-    fz_bwd_layer<1, SMALL>(p, r, row, bufB, bufA);
-    FZ_STAMP(7)
-    fz_bwd_layer<0, SMALL>(p, r, row, bufA, bufB);
-    FZ_STAMP(8)
+    const float* const* wq = BOTH ? p.wq_bwd : p.wq;
+    FZ_BSTAMP(1)
+    fz_bwd_layer<6, SMALL>(p, r, row, bufA, bufB, wq[6]);
+    FZ_BSTAMP(2)
+    fz_bwd_layer<5, SMALL>(p, r, row, bufB, bufA, wq[5]);
+    FZ_BSTAMP(3)
+    fz_bwd_layer<4, SMALL>(p, r, row, bufA, bufB, wq[4]);
+    FZ_BSTAMP(4)
+    fz_bwd_layer<3, SMALL>(p, r, row, bufB, bufA, wq[3]);
+    FZ_BSTAMP(5)
+    fz_bwd_layer<2, SMALL>(p, r, row, bufA, bufB, wq[2]);
+    FZ_BSTAMP(6)
+    fz_bwd_layer<1, SMALL>(p, r, row, bufB, bufA, wq[1]);
+    FZ_BSTAMP(7)
+    fz_bwd_layer<0, SMALL>(p, r, row, bufA, bufB, wq[0]);
+    FZ_BSTAMP(8)
     // ---- transposed 5x5 pre-filter: d pre rows [plo, phi) in bufB (zero-bordered plain image) -> own rows of d features
     {
         float w[25];
@@ -645,7 +741,27 @@ __global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p
             dst[(size_t)t * 32 + m] = acc;
         }
     }
-    FZ_STAMP(9)
+    FZ_BSTAMP(9)
+#undef FZ_BSTAMP
+}
+
+template <bool SMALL, bool HEAD>
+__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_bwd_kernel(AnFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
+    fz_backward_body<SMALL, HEAD, false>(p, blockIdx.y, fz_lds, fz_lds + p.buf_floats);
+}
+
+// Forward, head and backward of one whole utterance per block in ONE launch (S = 1: no other block holds rows of the
+// utterance, so nothing crosses a block).  The backward reads the activations the forward wrote a moment ago through this
+// CU's own L1 / the XCD's L2 (its masks); between the two halves the block's stores are complete (vmcnt at the barrier) and
+// no line of them was cached here before the forward wrote it.
+__global__ __launch_bounds__(kFzThreads, 1) void an_cnn_fwdbwd_kernel(AnFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float fz_lds[];
+    fz_forward_body<false>(p, blockIdx.y, fz_lds, fz_lds + p.buf_floats);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    fz_backward_body<false, true, true>(p, blockIdx.y, fz_lds, fz_lds + p.buf_floats);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -699,8 +815,10 @@ static bool fz_device_ok() {
     const int d = sg_device_slot();
     int st = state[d].load(std::memory_order_relaxed);
     if (st == 0) {
-        const void* fns[4] = {reinterpret_cast<const void*>(an_cnn_fwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_fwd_kernel<true>),
-                              reinterpret_cast<const void*>(an_cnn_bwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true>)};
+        const void* fns[7] = {reinterpret_cast<const void*>(an_cnn_fwd_kernel<false>), reinterpret_cast<const void*>(an_cnn_fwd_kernel<true>),
+                              reinterpret_cast<const void*>(an_cnn_bwd_kernel<false, false>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true, false>),
+                              reinterpret_cast<const void*>(an_cnn_bwd_kernel<false, true>), reinterpret_cast<const void*>(an_cnn_bwd_kernel<true, true>),
+                              reinterpret_cast<const void*>(an_cnn_fwdbwd_kernel)};
         st = 1;
         for (const void* fn : fns)
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) st = -1;
@@ -737,6 +855,7 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
             if (fz_plan(a.Tin, a.Tout, a.Fnet, rows, num_cus, &S, &bf) != 0) return hipErrorNotSupported;
         }
     }
+    if (backward && a.head.on && bf < kFzHeadFloats) bf = kFzHeadFloats;  // the head's scratch lives in the second buffer
     a.S = S;
     a.buf_floats = bf;
     const size_t lds = (size_t)bf * 2 * sizeof(float);
@@ -749,9 +868,12 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
     const size_t nblk = (size_t)S * rows;
     a.trace = trace_file ? static_cast<unsigned long long*>(trace_buf.get(nblk * 16 * 8)) : nullptr;
     if (a.trace) (void)hipMemsetAsync(a.trace, 0, nblk * 16 * 8, s);
-    if (backward) {
-        if (small) hipLaunchKernelGGL(an_cnn_bwd_kernel<true>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
-        else hipLaunchKernelGGL(an_cnn_bwd_kernel<false>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    if (backward && a.head.on) {
+        if (small) hipLaunchKernelGGL((an_cnn_bwd_kernel<true, true>), dim3(S, rows), dim3(kFzThreads), lds, s, a);
+        else hipLaunchKernelGGL((an_cnn_bwd_kernel<false, true>), dim3(S, rows), dim3(kFzThreads), lds, s, a);
+    } else if (backward) {
+        if (small) hipLaunchKernelGGL((an_cnn_bwd_kernel<true, false>), dim3(S, rows), dim3(kFzThreads), lds, s, a);
+        else hipLaunchKernelGGL((an_cnn_bwd_kernel<false, false>), dim3(S, rows), dim3(kFzThreads), lds, s, a);
     } else {
         if (small) hipLaunchKernelGGL(an_cnn_fwd_kernel<true>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
         else hipLaunchKernelGGL(an_cnn_fwd_kernel<false>, dim3(S, rows), dim3(kFzThreads), lds, s, a);
@@ -769,6 +891,39 @@ hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backwa
             fclose(f);
         }
     }
+    return hipGetLastError();
+}
+
+// LDS floats per buffer that whole utterances (S = 1) need; 0: they do not fit
+static int fz_whole_utterance_floats(const int* Tin, const int* Tout, int Fnet) {
+    AnSlice f, b;
+    an_slice_fwd(Tin, Tout, Fnet, 1, 0, f);
+    an_slice_bwd(Tin, Tout, Fnet, 1, 0, b);
+    int need = std::max((f.phi - f.plo + 4) * (kAnMel + 4) + 4, (b.phi - b.plo + 4) * (kAnMel + 4) + 4);
+    for (int l = 0; l < kAnConv; ++l)
+        need = std::max(need, std::max((f.ohi[l] - f.olo[l] + 2) * kAnCin[l], (b.whi[l] - b.wlo[l] + 2) * kAnCout[l]));
+    need = (need + 3) & ~3;
+    return (size_t)need * 2 * sizeof(float) > 160 * 1024 - 512 ? 0 : need;
+}
+
+// the cut the fused launches will use: the planner's, or `force_slices` (tests) when that fits; 0: not supported
+int an_fused_slices(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus, int force_slices) {
+    int S = 0, bf = 0;
+    if (rows < 1 || rows > 65535 || Tout[kAnConv - 1] < 1 || !fz_device_ok()) return 0;
+    if (force_slices == 1 && fz_whole_utterance_floats(Tin, Tout, Fnet) > 0) return 1;
+    if (fz_plan(Tin, Tout, Fnet, rows, num_cus, &S, &bf) != 0) return 0;
+    return force_slices > 1 ? std::min(force_slices, Tout[kAnConv - 1]) : S;
+}
+
+hipError_t launch_an_cnn_fwdbwd(AnFusedArgs a, int rows, int num_cus, int force_slices, hipStream_t s) {
+    if (an_fused_slices(a.Tin, a.Tout, a.Fnet, rows, num_cus, force_slices) != 1) return hipErrorNotSupported;
+    int bf = fz_whole_utterance_floats(a.Tin, a.Tout, a.Fnet);
+    if (bf <= 0 || !a.head.on) return hipErrorNotSupported;
+    if (bf < kFzHeadFloats) bf = kFzHeadFloats;
+    a.S = 1;
+    a.buf_floats = bf;
+    a.trace = nullptr;
+    hipLaunchKernelGGL(an_cnn_fwdbwd_kernel, dim3(1, rows), dim3(kFzThreads), (size_t)bf * 2 * sizeof(float), s, a);
     return hipGetLastError();
 }
 

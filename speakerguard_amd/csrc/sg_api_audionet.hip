@@ -358,6 +358,63 @@ AnFusedArgs an_fused_args(sg_ctx* ctx, int Fnet) {
     return a;
 }
 
+// Where the network's head runs (round 6).  Default: inside the fused backward launch whenever a gradient follows (every
+// block computes its utterance's head: no an_tail launch, no d conv8 round trip) -- 3-5 % of a feature-level pass
+// (tools/an_head_ab.py: 188 -> 182 us at 64 utterances, 702 -> 665 at 512), neutral inside the device loops
+// (tools/an_head_loop_ab.py).  Forward + head + backward of whole utterances as ONE launch (S = 1) exists and is bit-equal,
+// but measured 3.5 % SLOWER inside the PGD loop at 256 / 512 utterances (profiles/r06_an_head_ab.txt): off unless
+// SG_AN_ONE=1.  SG_AN_HEAD=0 brings the separate an_tail launch back (both knobs behind SG_TUNE=1; the tests compare the
+// three forms bit for bit).
+static bool an_head_in_backward(sg_ctx* ctx, int rows, int Fnet) {
+    const char* e = sg_tune_env("SG_AN_HEAD");
+    if (e && atoi(e) == 0) return false;
+    return an_use_fused(ctx, rows, Fnet);
+}
+static bool an_one_launch(sg_ctx* ctx, int rows, int Fnet) {
+    const char* e = sg_tune_env("SG_AN_ONE");
+    if (!e || atoi(e) == 0) return false;
+    if (!an_head_in_backward(ctx, rows, Fnet)) return false;
+    AnWorkspace& w = ctx->an_ws;
+    an_layer_frames(Fnet, w.Tin, w.Tout);
+    return an_fused_slices(w.Tin, w.Tout, Fnet, rows, ctx->num_cus, an_forced_slices()) == 1;
+}
+static AnHeadArgs an_head_args(sg_ctx* ctx, const int64_t* y, const sg_loss_spec& ls, int coef_rows, float* scores, int64_t* decisions,
+                               float* loss, float* loss_trace, int64_t* dec_trace, uint8_t* success) {
+    AnHeadArgs h{};
+    h.on = 1;
+    h.fc_w = ctx->an.fc_w;
+    h.fc_b = ctx->an.fc_b;
+    h.S = ctx->an.S;
+    h.threshold = -INFINITY;
+    h.y = y;
+    h.ls = ls;
+    h.coef_rows = coef_rows;
+    h.scores_out = scores;
+    h.dec_out = decisions;
+    h.loss_out = loss;
+    h.loss_trace = loss_trace;
+    h.dec_trace = dec_trace;
+    h.success = success;
+    return h;
+}
+
+// features -> conv stack -> head -> d loss / d features, one launch (an_one_launch said yes)
+int an_net_forward_backward(sg_ctx* ctx, const float* feats, int B, int Fnet, const AnHeadArgs& head, float* dfeats_out, hipStream_t s) {
+    AnWorkspace& w = ctx->an_ws;
+    const AnModel& m = ctx->an;
+    an_layer_frames(Fnet, w.Tin, w.Tout);
+    AnFusedArgs a = an_fused_args(ctx, Fnet);
+    a.feats = feats;
+    a.dfeats = dfeats_out;
+    a.head = head;
+    for (int l = 0; l < kAnConv; ++l) {
+        a.wq[l] = m.wfq[l];
+        a.wq_bwd[l] = m.wbq[l];
+    }
+    AN_STAGE(SG_STAGE_AN_FUSED_FWDBWD, launch_an_cnn_fwdbwd(a, B, ctx->num_cus, an_forced_slices(), s));
+    return SG_OK;
+}
+
 int an_net_forward(sg_ctx* ctx, const float* feats, int B, int Fnet, hipStream_t s) {
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
@@ -407,13 +464,14 @@ int an_forward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, hipSt
 }
 
 // d loss / d conv8 pre-activation (ws.dact[6]) -> d loss / d features (B, Fnet, 32) in dfeats_out
-int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t s) {
+int an_net_backward(sg_ctx* ctx, int B, int Fnet, float* dfeats_out, hipStream_t s, const AnHeadArgs* head = nullptr) {
     AnWorkspace& w = ctx->an_ws;
     const AnModel& m = ctx->an;
     if (an_use_fused(ctx, B, Fnet)) {
         AnFusedArgs a = an_fused_args(ctx, Fnet);
         a.dtop = w.dact[kAnConv - 1];
         a.dfeats = dfeats_out;
+        if (head) a.head = *head;
         for (int l = 0; l < kAnConv; ++l) a.wq[l] = m.wbq[l];
         AN_STAGE(SG_STAGE_AN_FUSED_BWD, launch_an_cnn_fused(a, B, ctx->num_cus, true, an_forced_slices(), s));
         return SG_OK;
@@ -493,9 +551,10 @@ float* an_step_target(sg_ctx* ctx, const AnDims& d) {
 }
 
 int an_backward_net(sg_ctx* ctx, const float* x, const AnDims& d, int flag, float* grad_out, float* x_update, float* x_next,
-                    const float* lower, const float* upper, float step, int grad_sign, hipStream_t s) {
+                    const float* lower, const float* upper, float step, int grad_sign, hipStream_t s, const AnHeadArgs* head = nullptr,
+                    bool net_done = false) {
     AnWorkspace& w = ctx->an_ws;
-    int rc = an_net_backward(ctx, d.B, d.F, flag == 1 ? grad_out : w.dfeats, s);
+    int rc = net_done ? SG_OK : an_net_backward(ctx, d.B, d.F, flag == 1 ? grad_out : w.dfeats, s, head);
     if (rc || flag == 1) return rc;
     return an_frontend_backward(ctx, x, d, w.dfeats, grad_out, x_update, x_next, lower, upper, step, grad_sign, s);
 }
@@ -677,9 +736,23 @@ int sg_an_loss_grad(sg_ctx* ctx, const float* x_dev, const int64_t* y_dev, int32
     if (!x_dev || !y_dev || !loss) return an_fail(ctx, SG_ERR_ARG, "x, y and loss are required");
     if (loss->loss == SG_LOSS_LINEAR && !loss->coef_dev) return an_fail(ctx, SG_ERR_ARG, "SG_LOSS_LINEAR needs coef_dev");
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
     AnWorkspace& w = ctx->an_ws;
     const int L = kAnConv - 1;
+    if (grad_dev && an_head_in_backward(ctx, B, d.F)) {
+        const AnHeadArgs head = an_head_args(ctx, y_dev, *loss, 0, scores_dev, decisions_dev, loss_dev, nullptr, nullptr, nullptr);
+        if (an_one_launch(ctx, B, d.F)) {
+            const float* feats = x_dev;
+            if (flag == 0) {
+                if ((rc = an_frontend_forward(ctx, x_dev, d, s))) return rc;
+                feats = w.feats;
+            }
+            if ((rc = an_net_forward_backward(ctx, feats, B, d.F, head, flag == 1 ? grad_dev : w.dfeats, s))) return rc;
+            return an_backward_net(ctx, x_dev, d, flag, grad_dev, nullptr, nullptr, nullptr, nullptr, 0.f, 0, s, nullptr, true);
+        }
+        if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
+        return an_backward_net(ctx, x_dev, d, flag, grad_dev, nullptr, nullptr, nullptr, nullptr, 0.f, 0, s, &head);
+    }
+    if ((rc = an_forward_net(ctx, x_dev, d, flag, s))) return rc;
     AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, *loss,
                           grad_dev != nullptr, nullptr, scores_dev, decisions_dev, loss_dev, w.dact[L], nullptr, nullptr,
                           nullptr, s));
@@ -707,6 +780,23 @@ int sg_an_pgd_run(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, const flo
     for (int it = 0; it <= p->max_iter; ++it) {
         const bool last = it == p->max_iter;
         d.keep_scale = it > 0;  // iterates stay in [-1, 1]
+        if (!last && an_head_in_backward(ctx, B, d.F)) {
+            // a gradient step: the head runs inside the backward launch (whole utterances per block: inside the one launch)
+            const AnHeadArgs head = an_head_args(ctx, y_dev, p->loss, 0, nullptr, nullptr, nullptr,
+                                                 loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
+                                                 decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr, nullptr);
+            if (an_one_launch(ctx, B, d.F)) {
+                if ((rc = an_frontend_forward(ctx, xc, d, s))) return rc;
+                if ((rc = an_net_forward_backward(ctx, w.feats, B, d.F, head, w.dfeats, s))) return rc;
+                rc = an_backward_net(ctx, xc, d, 0, nullptr, xc, xn, lower_dev, upper_dev, p->step_size, p->grad_sign, s, nullptr, true);
+            } else {
+                if ((rc = an_forward_net(ctx, xc, d, 0, s))) return rc;
+                rc = an_backward_net(ctx, xc, d, 0, nullptr, xc, xn, lower_dev, upper_dev, p->step_size, p->grad_sign, s, &head);
+            }
+            if (rc) return rc;
+            if (xn != xc) std::swap(xc, xn);
+            continue;
+        }
         if ((rc = an_forward_net(ctx, xc, d, 0, s))) return rc;
         AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], B, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, y_dev, p->loss, !last,
                               nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
@@ -772,20 +862,31 @@ int sg_an_pgd_run_feco(sg_ctx* ctx, float* x_adv_dev, const int64_t* y_dev, cons
                                      w.feco_ids, w.feco_out, w.feco_cnt, s);
         if (rc) return rc;
         trace_mark(ctx, SG_STAGE_AN_FECO_FWD, s, 1);
-        if ((rc = an_net_forward(ctx, w.feco_out, rows, k, s))) return rc;
         // per-step records as the reference prints them (attack/FGSM.py:50-58): the loss averaged over the step's EOT
         // repeats, the decision voted over them
         const bool direct = R == 1, rec = loss_trace_dev || decision_trace_dev;
         float* ltr = !rec ? nullptr : (direct && loss_trace_dev ? loss_trace_dev + (size_t)it * B : w.trace_l);
         int64_t* dtr = !rec ? nullptr : (direct && decision_trace_dev ? decision_trace_dev + (size_t)it * B : w.trace_d);
-        AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], rows, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, w.y_rep, p->loss, !last,
-                              nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
-                              w.dact[L], ltr, dtr, last ? success_dev : nullptr, s, B));
+        const bool head_in = !last && an_head_in_backward(ctx, rows, k);
+        if (head_in) {  // the head inside the backward launch (or forward + head + backward as one launch)
+            const AnHeadArgs head = an_head_args(ctx, w.y_rep, p->loss, B, nullptr, nullptr, nullptr, ltr, dtr, nullptr);
+            if (an_one_launch(ctx, rows, k)) {
+                if ((rc = an_net_forward_backward(ctx, w.feco_out, rows, k, head, w.dfeco, s))) return rc;
+            } else {
+                if ((rc = an_net_forward(ctx, w.feco_out, rows, k, s))) return rc;
+                if ((rc = an_net_backward(ctx, rows, k, w.dfeco, s, &head))) return rc;
+            }
+        } else {
+            if ((rc = an_net_forward(ctx, w.feco_out, rows, k, s))) return rc;
+            AN_STAGE(SG_STAGE_AN_TAIL, launch_an_tail(w.act[L], rows, w.Tout[L], ctx->an.fc_w, ctx->an.fc_b, ctx->an.S, -INFINITY, w.y_rep, p->loss, !last,
+                                  nullptr, last ? scores_dev : nullptr, last ? decisions_dev : nullptr, last ? loss_dev : nullptr,
+                                  w.dact[L], ltr, dtr, last ? success_dev : nullptr, s, B));
+        }
         if (rec && !direct)
             AN_HIP(launch_eot_trace_reduce(w.trace_l, w.trace_d, R, B, loss_trace_dev ? loss_trace_dev + (size_t)it * B : nullptr,
                                            decision_trace_dev ? decision_trace_dev + (size_t)it * B : nullptr, s));
         if (last) break;
-        if ((rc = an_net_backward(ctx, rows, k, w.dfeco, s))) return rc;
+        if (!head_in && (rc = an_net_backward(ctx, rows, k, w.dfeco, s))) return rc;
         trace_mark(ctx, SG_STAGE_AN_FECO_BWD, s, 0);
         if ((rc = sg_feco_compress_backward_reps(ctx, w.dfeco, w.feco_ids, w.feco_cnt, B, d.F, kAnMel, k, 1, R, w.dfeats, s))) return rc;
         trace_mark(ctx, SG_STAGE_AN_FECO_BWD, s, 1);

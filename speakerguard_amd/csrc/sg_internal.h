@@ -453,7 +453,24 @@ hipError_t launch_loss_eval(const float* scores, const int64_t* y, int B, int S,
 hipError_t launch_eot_trace_reduce(const float* loss_rows, const int64_t* dec_rows, int R, int B, float* loss_out,
                                    int64_t* dec_out, hipStream_t s);
 
-// the AudioNet CNN of one pass in one launch per direction (k_audionet_fused.hip)
+// The network's head (max over time, fc, decision, loss, d loss / d conv8: what an_tail_kernel does in a launch of its own)
+// inside the fused backward launch: every block computes it for its utterance from act[6] -- a few microseconds of a
+// block's ~80-160 -- and slice 0 writes the per-utterance outputs.  Same arithmetic in the same order as an_tail_kernel.
+struct AnHeadArgs {
+    int on;                    // 0: d loss / d conv8 comes from AnFusedArgs::dtop
+    const float* fc_w;         // (S, 32)
+    const float* fc_b;
+    int S;
+    float threshold;
+    const int64_t* y;          // (rows)
+    sg_loss_spec ls;
+    int coef_rows;
+    float* emb_out; float* scores_out; int64_t* dec_out; float* loss_out;   // optional, per row
+    float* loss_trace; int64_t* dec_trace; uint8_t* success;                 // optional, per row
+};
+
+// the AudioNet CNN of one pass in one launch per direction (k_audionet_fused.hip), or -- whole utterances per block, S = 1 --
+// forward, head and backward in ONE launch (launch_an_cnn_fwdbwd)
 struct AnFusedArgs {
     // forward
     const float* feats;        // (rows, Fnet, 32)
@@ -461,6 +478,7 @@ struct AnFusedArgs {
     float* act[kAnConv];       // (rows, Tout, Cout) ReLU outputs
     float* pool[kAnConv];      // (rows, Tout / 2, Cout) where the block has a MaxPool
     const float* wq[kAnConv];  // k4-packed weights of the direction: [3 K / 4][N][4]
+    const float* wq_bwd[kAnConv];  // the data gradients' weights when one launch runs both directions
     const float* bias[kAnConv];
     const float* w25;
     float pre_bias;
@@ -470,11 +488,15 @@ struct AnFusedArgs {
     int Fnet, S, buf_floats;
     int Tin[kAnConv], Tout[kAnConv];
     unsigned long long* trace;  // tuning aid (SG_AN_TRACE): per block 16 timestamps (100 MHz) at the stage boundaries, or null
+    AnHeadArgs head;
 };
 // false: the utterance is too long for the LDS-resident form even in its finest cut (the per-layer sequence runs)
 bool an_fused_supported(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus);
 // force_slices > 0: that many time slices per utterance instead of the planner's choice (tests: same bits for any cut)
 hipError_t launch_an_cnn_fused(AnFusedArgs a, int rows, int num_cus, bool backward, int force_slices, hipStream_t s);
+// forward + head + backward of whole utterances in one launch; hipErrorNotSupported unless the planner's cut is S = 1
+hipError_t launch_an_cnn_fwdbwd(AnFusedArgs a, int rows, int num_cus, int force_slices, hipStream_t s);
+int an_fused_slices(const int* Tin, const int* Tout, int Fnet, int rows, int num_cus, int force_slices);  // the cut the fused launches use (0: not supported)
 hipError_t launch_an_logmel_fwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale, float* feats,
                                 int fft32, hipStream_t s);
 hipError_t launch_an_logmel_bwd(const AnTables& t, const float* x, int B, int T, int F, const float* scale,

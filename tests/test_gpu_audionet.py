@@ -304,6 +304,75 @@ def test_fused_cnn_equals_the_per_layer_sequence_bit_for_bit(hip, dev, monkeypat
         "(planned cut and 1/2/3/5/7 slices)" % (B, T))
 
 
+@pytest.mark.parametrize("B,T", [(3, 48000), (2, 20011), (5, 40000)])  # (whole utterances fit a block's LDS up to ~3.2 s)
+def test_head_in_the_backward_and_the_one_launch_form_equal_the_separate_launches(hip, dev, monkeypatch, B, T):
+    """Round 6: when a gradient follows, the network's head (max over time, fc, loss, d loss / d conv8) runs inside the fused
+    backward launch, and with whole utterances per block (S = 1, forced here through SG_AN_SLICES=1 -- the planner takes it from
+    ~256 utterances) forward + head + backward are ONE launch.  Both against the three separate launches (SG_AN_HEAD=0): scores,
+    decisions, loss, d loss / d wav, d loss / d log-mel bit for bit, and the stage trace names what ran."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy, SEC4SR_MarginLoss
+    x = torch.from_numpy(synth.make_waveforms(B, T, seed=160 + B)).to(dev)
+    y = (torch.arange(B, device=dev) * 11) % 251
+    feats = hip.compute_feat(x)
+    for spec in (SEC4SR_CrossEntropy(), SEC4SR_MarginLoss(targeted=False, task="CSI")):
+        def run():
+            return list(hip.loss_grad(x, y, spec)) + list(hip.loss_grad(feats, y, spec, flag=1))
+
+        monkeypatch.setenv("SG_AN_HEAD", "0")
+        monkeypatch.delenv("SG_AN_SLICES", raising=False)
+        ref = run()
+        tags = [t for t, _ in hip.trace_stages(lambda: hip.loss_grad(x, y, spec), max_records=256)]
+        assert tags.count("an_tail") == 1 and tags.count("an_cnn_bwd") == 1
+        monkeypatch.setenv("SG_AN_HEAD", "1")
+        for slices, one in ((0, "1"), (2, "1"), (1, "0"), (1, "1")):
+            monkeypatch.setenv("SG_AN_ONE", one)
+            if slices:
+                monkeypatch.setenv("SG_AN_SLICES", str(slices))
+            got = run()
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), (B, T, slices, one, (a.float() - b.float()).abs().max().item())
+            tags = [t for t, _ in hip.trace_stages(lambda: hip.loss_grad(x, y, spec), max_records=256)]
+            assert "an_tail" not in tags
+            if slices == 1 and one == "1":
+                assert tags.count("an_cnn_fwdbwd") == 1 and "an_cnn_fwd" not in tags and "an_cnn_bwd" not in tags, tags
+            else:
+                assert tags.count("an_cnn_fwd") == 1 and tags.count("an_cnn_bwd") == 1, tags
+        monkeypatch.delenv("SG_AN_SLICES", raising=False)
+        monkeypatch.delenv("SG_AN_ONE", raising=False)
+    log("audionet B=%d T=%d: head inside the fused backward launch, and forward + head + backward as one launch (whole utterances per block), "
+        "equal the three separate launches bit for bit (cross-entropy and margin loss)" % (B, T))
+
+
+def test_pgd_loops_with_the_head_inside_equal_the_separate_launches(hip, dev, monkeypatch):
+    """The device loops (sg_an_pgd_run) with the head inside the backward launch / the one-launch form against the separate
+    launches: adversarial audio, flags, decisions, per-step loss and decision records equal."""
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.PGD import PGD
+    x = torch.from_numpy(synth.make_waveforms(6, 32000, seed=171)).to(dev)
+    y = hip.make_decision(x)[0]
+
+    def run():
+        atk = PGD(hip, task="CSI", epsilon=0.002, step_size=0.0004, max_iter=5, batch_size=6, verbose=0)
+        adv, succ = atk.attack(x, y)
+        return adv.clone(), list(succ)
+
+    monkeypatch.setenv("SG_AN_HEAD", "0")
+    ref = run()
+    for head, slices, one in (("1", None, "1"), ("1", "1", "1"), ("1", "1", "0")):
+        monkeypatch.setenv("SG_AN_HEAD", head)
+        monkeypatch.setenv("SG_AN_ONE", one)
+        if slices:
+            monkeypatch.setenv("SG_AN_SLICES", slices)
+        got = run()
+        assert torch.equal(got[0], ref[0]) and got[1] == ref[1], (head, slices, one)
+        tags = [t for t, _ in hip.trace_stages(lambda: run(), max_records=1024)]
+        assert ("an_cnn_fwdbwd" in tags) == (slices == "1" and one == "1"), (tags, slices, one)
+        monkeypatch.delenv("SG_AN_SLICES", raising=False)
+    monkeypatch.delenv("SG_AN_HEAD", raising=False)
+    monkeypatch.delenv("SG_AN_ONE", raising=False)
+
+
 def test_fused_cnn_is_the_path_that_runs(hip, dev, monkeypatch):
     """The stage trace names what ran: one fused launch per direction and no per-layer contraction with the default
     setting; the per-layer tags with SG_AN_FUSED=0."""
