@@ -144,56 +144,6 @@ hipError_t launch_copy_cols(const float* in, int ld_in, float* out, int ld_out, 
     return hipGetLastError();
 }
 
-// The TDNN's activations are TIME-MAJOR (round 6): row t * B + b holds frame t of utterance b.  These two
-// move (B, F, ncol) batch-major caller tensors in and out of that layout.
-// out[(t B + b)][0..ld_out) = in[(b F + t)][0..ncol), zero padding
-__global__ __launch_bounds__(256) void copy_cols_tm_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
-                                                           int ld_out, int B, int F, int ncol) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)B * F * ld_out) return;
-    const int64_t r = i / ld_out;
-    const int c = (int)(i - r * ld_out);
-    const int t = (int)(r / B), b = (int)(r - (int64_t)t * B);
-    out[i] = c < ncol ? in[((int64_t)b * F + t) * ld_in + c] : 0.f;
-}
-hipError_t launch_copy_cols_tm(const float* in, int ld_in, float* out, int ld_out, int B, int F, int ncol, hipStream_t s) {
-    const int64_t n = (int64_t)B * F * ld_out;
-    hipLaunchKernelGGL(copy_cols_tm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, ld_in, out, ld_out, B, F, ncol);
-    return hipGetLastError();
-}
-// out[(b F + t)][0..ncol) = sum_z in[z][(t B + b)][0..ncol)  (split-K slabs, fixed order)
-__global__ __launch_bounds__(256) void sum_cols_tm_kernel(const float* __restrict__ in, int ld_in, int nsplit, long long slab_stride,
-                                                          float* __restrict__ out, int ld_out, int B, int F, int ncol) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)B * F * ncol) return;
-    const int64_t r = i / ncol;
-    const int c = (int)(i - r * ncol);
-    const int b = (int)(r / F), t = (int)(r - (int64_t)b * F);
-    float v = 0.f;
-    for (int z = 0; z < nsplit; ++z) v += in[(size_t)z * slab_stride + ((int64_t)t * B + b) * ld_in + c];
-    out[r * ld_out + c] = v;
-}
-hipError_t launch_sum_cols_tm(const float* in, int ld_in, int nsplit, long long slab_stride, float* out, int ld_out, int B, int F,
-                              int ncol, hipStream_t s) {
-    const int64_t n = (int64_t)B * F * ncol;
-    hipLaunchKernelGGL(sum_cols_tm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, ld_in, nsplit, slab_stride, out,
-                       ld_out, B, F, ncol);
-    return hipGetLastError();
-}
-// out (B, rows, C) batch-major <- act (rows, B, C) time-major, n floats of out at most (parity tests read activations)
-__global__ __launch_bounds__(256) void untm_kernel(const float* __restrict__ act, float* __restrict__ out, int B, int rows, int C, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int64_t r = i / C;
-    const int c = (int)(i - r * C);
-    const int b = (int)(r / rows), t = (int)(r - (int64_t)b * rows);
-    out[i] = act[((int64_t)t * B + b) * C + c];
-}
-hipError_t launch_untm(const float* act, float* out, int B, int rows, int C, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(untm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, out, B, rows, C, n);
-    return hipGetLastError();
-}
-
 // out[r][0..ncol) = sum_z in[z][r][0..ncol)  (split-K slabs, fixed order)
 __global__ __launch_bounds__(256) void sum_cols_kernel(const float* __restrict__ in, int ld_in, int nsplit,
                                                        long long slab_stride, float* __restrict__ out, int ld_out,
@@ -237,13 +187,11 @@ __device__ __forceinline__ void cmvn_window(int t, int F, int& start, int& end) 
 // version (256 threads, 8 partials: 23 us per launch for 2.3 MB).
 constexpr int kCmvnThreads = 1024;
 constexpr int kCmvnParts = kCmvnThreads / 32;
-// out_tm: the output rows are time-major (row t B + b; B = gridDim.x) -- the TDNN's input -- else batch-major like the input
 __global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
-                                                       int ld_out, int F, int out_tm) {
+                                                       int ld_out, int F) {
     const int b = blockIdx.x;
     const float* x = in + (size_t)b * F * ld_in;
-    float* y = out_tm ? out + (size_t)b * ld_out : out + (size_t)b * F * ld_out;
-    const size_t ys = out_tm ? (size_t)gridDim.x * ld_out : (size_t)ld_out;  // row stride of this utterance's output
+    float* y = out + (size_t)b * F * ld_out;
     __shared__ double total[kCep];
     __shared__ double part[kCmvnParts][32];
     if (F <= kCmnWindow) {
@@ -276,12 +224,12 @@ __global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < kRows; ++j) {
                 const int t = r + j * kCmvnParts;
-                if (t < F) y[(size_t)t * ys + d] = d < kCep ? v[j] - mean : 0.f;
+                if (t < F) y[(size_t)t * ld_out + d] = d < kCep ? v[j] - mean : 0.f;
             }
         }
         for (int i = threadIdx.x; i < F * (ld_out - 32); i += kCmvnThreads) {  // (row stride above 32: the rest of the zero padding)
             const int t = i / (ld_out - 32), dd = 32 + i - t * (ld_out - 32);
-            y[(size_t)t * ys + dd] = 0.f;
+            y[(size_t)t * ld_out + dd] = 0.f;
         }
     } else {
         for (int i = threadIdx.x; i < F * ld_out; i += kCmvnThreads) {
@@ -294,7 +242,7 @@ __global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __r
                 for (int u = s; u < e; ++u) acc += (double)x[(size_t)u * ld_in + d];
                 v = x[(size_t)t * ld_in + d] - (float)(acc / (double)(e - s));
             }
-            y[(size_t)t * ys + d] = v;
+            y[i] = v;
         }
     }
 }
@@ -306,15 +254,13 @@ __global__ __launch_bounds__(kCmvnThreads) void cmvn_fwd_kernel(const float* __r
 template <int NS>
 __global__ __launch_bounds__(kCmvnThreads) void cmvn_bwd_kernel(const float* __restrict__ dout, int ld_dout, int nsplit_rt,
                                                        long long slab_stride, float* __restrict__ din, int ld_din,
-                                                       int F, int in_tm) {
-    // in_tm: the incoming gradient rows are time-major (row t B + b; B = gridDim.x): the tdnn1 data gradient's slabs
+                                                       int F) {
     const int b = blockIdx.x;
-    const float* g = in_tm ? dout + (size_t)b * ld_dout : dout + (size_t)b * F * ld_dout;
-    const size_t gs = in_tm ? (size_t)gridDim.x * ld_dout : (size_t)ld_dout;
+    const float* g = dout + (size_t)b * F * ld_dout;
     float* y = din + (size_t)b * F * ld_din;
     const int nsplit = NS > 0 ? NS : nsplit_rt;
     auto gsum = [&](int t, int d) __attribute__((always_inline)) {
-        const float* src = g + (size_t)t * gs + d;
+        const float* src = g + (size_t)t * ld_dout + d;
         if (NS > 0) {
             float part[NS > 0 ? NS : 1];
 #pragma unroll
@@ -376,29 +322,27 @@ __global__ __launch_bounds__(kCmvnThreads) void cmvn_bwd_kernel(const float* __r
     }
 }
 
-hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, int out_tm, hipStream_t s) {
-    hipLaunchKernelGGL(cmvn_fwd_kernel, dim3(B), dim3(kCmvnThreads), 0, s, in, ld_in, out, ld_out, F, out_tm);
+hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, hipStream_t s) {
+    hipLaunchKernelGGL(cmvn_fwd_kernel, dim3(B), dim3(kCmvnThreads), 0, s, in, ld_in, out, ld_out, F);
     return hipGetLastError();
 }
 hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long slab_stride, float* din, int ld_din,
-                           int B, int F, int in_tm, hipStream_t s) {
+                           int B, int F, hipStream_t s) {
     if (nsplit == kL1BwdSplitK)
-        hipLaunchKernelGGL(cmvn_bwd_kernel<kL1BwdSplitK>, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F, in_tm);
+        hipLaunchKernelGGL(cmvn_bwd_kernel<kL1BwdSplitK>, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
     else
-        hipLaunchKernelGGL(cmvn_bwd_kernel<0>, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F, in_tm);
+        hipLaunchKernelGGL(cmvn_bwd_kernel<0>, dim3(B), dim3(kCmvnThreads), 0, s, dout, ld_dout, nsplit, slab_stride, din, ld_din, F);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- statistics pooling (xvecTDNN.py:62)
 // stats = cat(mean_t, std_t (unbiased)) over the tdnn5 relu output (BatchNorm folded into fc1).
 // grid (kPoolC/64, B), block 256: lane = channel, the 4 waves split the frames.
-// act is time-major: frame t of utterance b at row t B + b (B = gridDim.y)
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ act, int Tc, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
-    const float* a = act + (size_t)b * kPoolC + c;
-    const size_t rs = (size_t)gridDim.y * kPoolC;  // row stride of one utterance's frames
+    const float* a = act + (size_t)b * Tc * kPoolC + c;
     __shared__ float red[4][64];
     // two-pass variance (like torch.std); the <= 96 frames a wave owns stay in registers between the
     // passes so the activation tensor is read once (longer utterances re-read from L2)
@@ -410,11 +354,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < kKeep; ++i) {
             const int t = wid + 4 * i;
-            keep[i] = t < Tc ? a[(size_t)t * rs] : 0.f;
+            keep[i] = t < Tc ? a[(size_t)t * kPoolC] : 0.f;
             s += keep[i];
         }
     } else {
-        for (int t = wid; t < Tc; t += 4) s += a[(size_t)t * rs];
+        for (int t = wid; t < Tc; t += 4) s += a[(size_t)t * kPoolC];
     }
     red[wid][lane] = s;
     __syncthreads();
@@ -429,7 +373,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
         }
     } else {
         for (int t = wid; t < Tc; t += 4) {
-            const float d = a[(size_t)t * rs] - mean;
+            const float d = a[(size_t)t * kPoolC] - mean;
             q += d * d;
         }
     }
@@ -475,17 +419,15 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const float sd = stats[(size_t)b * kStats + kPoolC + c];
     const float beta = sd > 0.f ? dstd / ((float)(Tc - 1) * sd) : 0.f;
     const float alpha = dmean / (float)Tc;
-    // act / dact are time-major: frame t of utterance b at row t B + b
-    const float* a = act + (size_t)b * kPoolC + c;
-    float* d = dact + (size_t)b * kPoolC + c;
-    const size_t rs = (size_t)B * kPoolC;
+    const float* a = act + (size_t)b * Tc * kPoolC + c;
+    float* d = dact + (size_t)b * Tc * kPoolC + c;
     // elementwise from here on: the frames are dealt over the blocks of grid.z (small batches: 24 x 8 blocks of a 68-step
     // loop left most CUs idle, 15 us at 8 utterances) -- any split gives the same bits
     const int per = (Tc + (int)gridDim.z - 1) / (int)gridDim.z;
     const int t0 = (int)blockIdx.z * per, t1 = min(Tc, t0 + per);
     for (int t = t0 + wid; t < t1; t += 4) {
-        const float v = a[(size_t)t * rs];
-        d[(size_t)t * rs] = v > 0.f ? alpha + beta * (v - mean) : 0.f;
+        const float v = a[(size_t)t * kPoolC];
+        d[(size_t)t * kPoolC] = v > 0.f ? alpha + beta * (v - mean) : 0.f;
     }
 }
 

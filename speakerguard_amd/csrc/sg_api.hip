@@ -239,7 +239,6 @@ int ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
     Workspace& w = ctx->ws;
     if (B <= w.B && F <= w.F && T <= w.T && w.scale) {
         layer_frames(F, w.Fl);
-        w.last_B = B;
         return SG_OK;
     }
     (void)hipDeviceSynchronize();
@@ -281,7 +280,6 @@ int ensure_workspace(sg_ctx* ctx, int B, int T, int F) {
         return SG_ERR_HIP;
     }
     layer_frames(F, w.Fl);
-    w.last_B = B;
     return SG_OK;
 }
 
@@ -304,25 +302,13 @@ int run_frontend(sg_ctx* ctx, const float* x, const PassDims& d, int flag, const
         tab.mel_cache = want_grad ? w.mel_cache : nullptr;
         tab.rep_utts = d.Bu;
         SG_STAGE(SG_STAGE_MFCC_FWD, launch_mfcc_fwd(tab, x, d.B, d.T, d.F, w.scale, dz, w.feats_raw, s));
-        SG_STAGE(SG_STAGE_CMVN_FWD, launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, 1, s));
+        SG_STAGE(SG_STAGE_CMVN_FWD, launch_cmvn_fwd(w.feats_raw, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else if (flag == SG_FLAG_RAW) {
-        SG_HIP(launch_cmvn_fwd(x, kCep, w.feats, kFeatPad, d.B, d.F, 1, s));
+        SG_HIP(launch_cmvn_fwd(x, kCep, w.feats, kFeatPad, d.B, d.F, s));
     } else {
-        SG_HIP(launch_copy_cols_tm(x, kCep, w.feats, kFeatPad, d.B, d.F, kCep, s));
+        SG_HIP(launch_copy_cols(x, kCep, w.feats, kFeatPad, (int64_t)d.B * d.F, kCep, s));
     }
     return SG_OK;
-}
-
-// The TDNN's activations are TIME-MAJOR (round 6): row t B + b holds frame t of utterance b.  To the
-// contraction kernels that is ONE utterance of Ta B rows whose taps are B times as far apart -- the per-row (utterance,
-// frame) bookkeeping and the zero rows at utterance boundaries reduce to the bounds of the whole tensor -- and a tile of
-// rows covers a narrow range of frames, which is what lets the stream-K launcher drop the taps that fall outside the
-// utterances for a whole tile (the data gradients' edge frames).
-inline void conv_time_major(ConvGemmArgs& a, int B) {
-    a.Ta *= B;
-    a.Tc *= B;
-    a.tap_step *= B;
-    a.tap_base *= B;
 }
 
 ConvGemmArgs fwd_layer_args(sg_ctx* ctx, int l, int B, int F) {
@@ -347,7 +333,6 @@ ConvGemmArgs fwd_layer_args(sg_ctx* ctx, int l, int B, int F) {
     a.total_chunks = a.taps * (a.Kc / 32);
     a.chunks_per_split = a.total_chunks;
     a.split_stride = 0;
-    conv_time_major(a, B);
     conv_ctx_args(ctx, a);
     return a;
 }
@@ -404,7 +389,6 @@ int run_tdnn_backward(sg_ctx* ctx, const PassDims& d, hipStream_t s) {
         a.total_chunks = a.taps * (a.Kc / 32);
         a.chunks_per_split = a.total_chunks;
         a.split_stride = 0;
-        conv_time_major(a, d.B);
         conv_ctx_args(ctx, a);
         int splits = 1, tile = 0;
         if (l == 0) {  // 32 output columns: 148 tiles at B = 64 -- split K per tap to fill the chip
@@ -465,14 +449,14 @@ int run_backward_to_input(sg_ctx* ctx, const float* x, const PassDims& d, int fl
     int rc = run_tdnn_backward(ctx, d, s);
     if (rc) return rc;
     if (flag == SG_FLAG_CMVN) {
-        SG_HIP(launch_sum_cols_tm(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep, d.B, d.F,
-                                  kCep, s));
+        SG_HIP(launch_sum_cols(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep,
+                               (int64_t)d.B * d.F, kCep, s));
     } else if (flag == SG_FLAG_RAW) {
         SG_HIP(launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad, grad_out, kCep, d.B,
-                               d.F, 1, s));
+                               d.F, s));
     } else {
         SG_STAGE(SG_STAGE_CMVN_BWD, launch_cmvn_bwd(w.dfeats, kFeatPad, kL1BwdSplitK, (long long)d.B * d.F * kFeatPad,
-                                                    w.dfeats_raw, kCep, d.B, d.F, 1, s));
+                                                    w.dfeats_raw, kCep, d.B, d.F, s));
         MfccTables tab = ctx->tab;
         static const bool use_cache = [] {
             const char* e = sg_tune_env("SG_MFCC_CACHE");  // 0 = recompute the forward in the backward kernel
@@ -778,7 +762,7 @@ int sg_xv_mfcc(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, const floa
 
 int sg_xv_cmvn(sg_ctx* ctx, const float* feats_dev, int32_t B, int32_t F, float* out_dev, void* stream) {
     if (!ctx || !feats_dev || !out_dev || B < 1 || F < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
-    SG_HIP(launch_cmvn_fwd(feats_dev, kCep, out_dev, kCep, B, F, 0, (hipStream_t)stream));
+    SG_HIP(launch_cmvn_fwd(feats_dev, kCep, out_dev, kCep, B, F, (hipStream_t)stream));
     return SG_OK;
 }
 
@@ -797,7 +781,7 @@ int sg_xv_mfcc_backward(sg_ctx* ctx, const float* x_dev, int32_t B, int32_t T, c
 
 int sg_xv_cmvn_backward(sg_ctx* ctx, const float* dout_dev, int32_t B, int32_t F, float* din_dev, void* stream) {
     if (!ctx || !dout_dev || !din_dev || B < 1 || F < 1) return fail(ctx, SG_ERR_ARG, "bad argument");
-    SG_HIP(launch_cmvn_bwd(dout_dev, kCep, 1, 0, din_dev, kCep, B, F, 0, (hipStream_t)stream));
+    SG_HIP(launch_cmvn_bwd(dout_dev, kCep, 1, 0, din_dev, kCep, B, F, (hipStream_t)stream));
     return SG_OK;
 }
 
@@ -833,9 +817,7 @@ int sg_xv_debug_activation(sg_ctx* ctx, int32_t layer, float* out_dev, int64_t c
         layer_frames(w.F, cap_fl);
         const size_t held = (size_t)w.B * (size_t)(cap_fl[l] > 0 ? cap_fl[l] : 1) * kCoutPad[l];
         const size_t n = std::min<size_t>((size_t)capacity_floats, held);
-        // (the workspace keeps activations time-major; the caller gets (B, rows, channels))
-        SG_HIP(launch_untm(w.act[l], out_dev, w.last_B, w.Fl[l], kCoutPad[l], (int64_t)std::min<size_t>(n, (size_t)w.last_B * w.Fl[l] * kCoutPad[l]),
-                           (hipStream_t)stream));
+        SG_HIP(hipMemcpyAsync(out_dev, w.act[l], n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return SG_OK;
 }
@@ -1120,7 +1102,6 @@ int sg_xv_time_layer(sg_ctx* ctx, int32_t layer, int32_t B, int32_t T, int32_t i
         a.Ta = w.Fl[l]; a.Tc = l == 0 ? F : w.Fl[l - 1]; a.M = B * a.Tc; a.N = kCinPad[l]; a.Kc = kCoutPad[l];
         a.lda = kCoutPad[l]; a.ldw = kCinPad[l]; a.ldc = kCinPad[l]; a.taps = kTaps[l]; a.tap_step = -kDil[l];
         a.total_chunks = a.taps * (a.Kc / 32); a.chunks_per_split = a.total_chunks;
-        conv_time_major(a, B);
         conv_ctx_args(ctx, a);
         tile = l == 0 ? 1 : 0;
         epi = l == 0 ? EPI_NONE : EPI_RELU_MASK;

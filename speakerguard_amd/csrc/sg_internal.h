@@ -223,13 +223,12 @@ struct XvModel {
 
 struct Workspace {
     int B = 0, T = 0, F = 0;          // capacity the buffers were sized for
-    int last_B = 0;                    // rows of the last pass (the activations are time-major: row t * last_B + b)
     int Fl[kLayers] = {};              // TDNN output frames per layer
     float* scale = nullptr;            // [1]
     float* feats_raw = nullptr;        // [B][F][30]
     float* feats = nullptr;            // [B][F][32] CMVN output, zero padded
-    float* act[kLayers] = {};          // relu outputs [Fl][B][CoutPad] (time-major, round 6)
-    float* dact[kLayers] = {};         // d loss / d pre-activation [Fl][B][CoutPad]
+    float* act[kLayers] = {};          // relu outputs [B][Fl][CoutPad]
+    float* dact[kLayers] = {};         // d loss / d pre-activation [B][Fl][CoutPad]
     float* dfeats = nullptr;           // [kL1BwdSplitK][B][F][32] split-K slabs of the tdnn1 data gradient
     float* dfeats_raw = nullptr;       // [B][F][30]
     float* dframes = nullptr;          // [B][F][400]
@@ -427,13 +426,9 @@ hipError_t launch_pgd_update(float* x, const float* g, const float* lo, const fl
 hipError_t launch_copy_cols(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int ncol, hipStream_t s);
 hipError_t launch_sum_cols(const float* in, int ld_in, int nsplit, long long slab_stride, float* out, int ld_out,
                            int64_t rows, int ncol, hipStream_t s);
-hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, int out_tm, hipStream_t s);
-hipError_t launch_copy_cols_tm(const float* in, int ld_in, float* out, int ld_out, int B, int F, int ncol, hipStream_t s);
-hipError_t launch_sum_cols_tm(const float* in, int ld_in, int nsplit, long long slab_stride, float* out, int ld_out, int B, int F,
-                              int ncol, hipStream_t s);
-hipError_t launch_untm(const float* act, float* out, int B, int rows, int C, int64_t n, hipStream_t s);
+hipError_t launch_cmvn_fwd(const float* in, int ld_in, float* out, int ld_out, int B, int F, hipStream_t s);
 hipError_t launch_cmvn_bwd(const float* dout, int ld_dout, int nsplit, long long slab_stride, float* din, int ld_din,
-                           int B, int F, int in_tm, hipStream_t s);
+                           int B, int F, hipStream_t s);
 hipError_t launch_pool_fwd(const float* act5, int B, int Tc, float* stats, hipStream_t s);
 hipError_t launch_pool_bwd(const float* act5, const float* stats, const float* dstats_part, int nsplit,
                            int B, int Tc, float* dact5, hipStream_t s);
