@@ -329,7 +329,7 @@ def main():
     if rank == 0:
         ms_iso, flops_iso, _ = model.time_layer(3, primary_b, T_SAMPLES, iters=20)
         traffic, traffic_src = None, None
-        for name in ("r05_pmc_tdnn3.json", "r04_pmc_tdnn3.json", "r03_pmc_tdnn3.json", "r02_pmc_tdnn3.json", "r01_pmc_tdnn3.json"):  # latest committed passes of this kernel
+        for name in ("r06_pmc_tdnn3.json", "r05_pmc_tdnn3.json", "r04_pmc_tdnn3.json", "r03_pmc_tdnn3.json", "r02_pmc_tdnn3.json", "r01_pmc_tdnn3.json"):  # latest committed passes of this kernel
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 with open(pmc) as f:
