@@ -164,6 +164,10 @@ int main() {
     EXPECT(sg_xv_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, &nod, dec.data(), scores.data(), loss.data(), grad.data(), nullptr) == SG_OK);
     EXPECT(sg_xv_loss_grad(ctx, feats.data(), y.data(), B, F, 2, &ce, nullptr, dec.data(), scores.data(), loss.data(), gfeat.data(), nullptr) == SG_OK);
     EXPECT(sg_xv_loss_grad(ctx, x.data(), nullptr, B, T, 0, &ce, &nod, dec.data(), scores.data(), loss.data(), grad.data(), nullptr) != SG_OK);
+    // round 6: the same pass on the float64 transforms (the launch selection of both instantiations runs under the sanitizer)
+    EXPECT(sg_xv_configure(ctx, 64) == SG_OK);
+    EXPECT(sg_xv_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, &nod, dec.data(), scores.data(), loss.data(), grad.data(), nullptr) == SG_OK);
+    EXPECT(sg_xv_configure(ctx, 32) == SG_OK);
     sg_loss_spec lin{};
     lin.loss = SG_LOSS_LINEAR;  // needs a coefficient table
     EXPECT(sg_xv_loss_grad(ctx, x.data(), y.data(), B, T, 0, &lin, &nod, dec.data(), scores.data(), loss.data(), grad.data(), nullptr) != SG_OK);
@@ -332,6 +336,13 @@ int main() {
             EXPECT(sg_an_loss_grad(ctx, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
             EXPECT(sg_set_streamk(nullptr, 0) == SG_ERR_ARG && sg_set_streamk(ctx2, 0) == SG_OK && sg_set_streamk(ctx2, 1) == SG_OK);
             EXPECT(sg_debug_lose_handoffs(ctx2, -1) == SG_ERR_ARG && sg_debug_lose_handoffs(ctx2, 0) == SG_OK);
+            // round 6: the x-vector front-end's transform precision, the k-means launch counter's test hook, the automatic
+            // spectrum cache (-1)
+            EXPECT(sg_xv_configure(nullptr, 32) == SG_ERR_ARG && sg_xv_configure(ctx2, 48) == SG_ERR_ARG);
+            EXPECT(sg_xv_configure(ctx2, 64) == SG_OK && sg_xv_configure(ctx2, 32) == SG_OK);
+            EXPECT(sg_debug_feco_epoch(nullptr, 1) == SG_ERR_ARG && sg_debug_feco_epoch(ctx2, 0x7FFEu) == SG_OK);
+            EXPECT(sg_an_configure(ctx2, 32, -1, -1) == SG_OK);
+            EXPECT(sg_an_loss_grad(ctx2, x.data(), y.data(), B, T, 0, &ce, dec.data(), sc.data(), loss.data(), grad.data(), nullptr) == SG_OK);
             EXPECT(sg_sync(ctx2, nullptr) == SG_OK);
             sg_destroy(ctx2);
         }

@@ -92,6 +92,46 @@ def test_mfcc_matches_independent_implementation(hip_model, dev, tag):
     assert got.shape == want.shape and err < 1e-3   # fp32 table rounding alone: 3e-4 (trap 1)
 
 
+def test_float32_transforms_against_the_float64_counterpart(xv_weights, oracle_model, dev):
+    """Round 6: the MFCC's 512-point transforms run in float32 by default -- the reference's own precision (torchaudio 0.6's
+    kaldi.mfcc is float32 end to end, xv_plda.py:114-148) -- with the float64 form of rounds 1-5 behind sg_xv_configure.
+    Both forms against each other and against the oracle: cepstra, decisions, d loss / d wav (the sign-mismatch statistic
+    next to the float64 one)."""
+    from oracle import attacks as oatk
+    from oracle import kaldi_mfcc
+    from speakerguard_amd import _native as N
+    from speakerguard_amd import synth
+    from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy
+    from speakerguard_amd.model.xv_plda import xv_plda
+    m = xv_plda.from_weights(xv_weights, device=dev, dither=0.0)
+    with pytest.raises(N.NativeError, match="fft_bits"):
+        m.configure_frontend(48)
+    x = torch.from_numpy(synth.make_waveforms(3, 48000, seed=22))
+    want = kaldi_mfcc.mfcc_batch(x * 32768.0)
+    with torch.no_grad():
+        y = oracle_model.make_decision(x)[0]
+    xin = x.clone().requires_grad_(True)
+    oatk.cross_entropy_loss(oracle_model.make_decision(xin)[1], y).backward(torch.ones(3))
+    g_ref = xin.grad.numpy()
+    got = {}
+    for bits in (32, 64):
+        m.configure_frontend(bits)
+        feats = m.compute_feat(x.to(dev), flag=1).cpu()
+        dec, scores, loss, grad = m.loss_grad(x.to(dev), y.to(dev), SEC4SR_CrossEntropy())
+        g = grad.cpu().numpy()
+        got[bits] = (feats, dec.cpu(), g)
+        np.testing.assert_allclose(feats.numpy(), want.numpy(), rtol=1e-4, atol=5e-3)
+        assert dec.cpu().tolist() == y.tolist()
+        mism = float((np.sign(g) != np.sign(g_ref)).mean())
+        err = np.abs(g - g_ref).max() / np.abs(g_ref).max()
+        log("xv front-end with float%d transforms: cepstra max abs err vs oracle %.3e; d loss / d wav max err / max %.3e, sign mismatch %.3e"
+            % (bits, (feats - want).abs().max().item(), err, mism))
+        assert err < 3e-3 and mism < 5e-3
+    m.configure_frontend(32)
+    assert (got[32][0] - got[64][0]).abs().max().item() < 2e-4  # cepstra up to 33: float32 round-off of the spectrum
+    assert float((np.sign(got[32][2]) != np.sign(got[64][2])).mean()) < 2e-3
+
+
 def test_mfcc_int16_range_left_alone(hip_model, dev):
     """check_input_range: a batch already in int16 scale is NOT multiplied again (model/utils.py:11)."""
     from oracle import kaldi_mfcc
