@@ -83,7 +83,6 @@ int build_tables(sg_ctx* ctx) {
     std::vector<float> window(kWin), melw(kMel * 256, 0.f), dct(kMel * kCep), lifter(kCep), w0(256, 0.f), w1(256, 0.f);
     std::vector<int> lo(kMel), hi(kMel), m0(256, -1);
     std::vector<double2> tw(256);
-    std::vector<uint16_t> br(kFft);
     {   // torch.hann_window(400, periodic=False): arange * (2 pi / 399) -> cos -> * -0.5 + 0.5; then pow 0.85
         const float step = (float)(PI * 2.0 / (double)(kWin - 1));
         for (int n = 0; n < kWin; ++n) {
@@ -148,14 +147,7 @@ int build_tables(sg_ctx* ctx) {
         for (int c = 0; c < kCep; ++c) lifter[c] = 1.0f + 11.0f * sinf(((float)PI * (float)c) / 22.0f);
     }
     for (int k = 0; k < 256; ++k) tw[k] = make_double2(std::cos(2.0 * PI * k / kFft), -std::sin(2.0 * PI * k / kFft));
-    for (int i = 0; i < kFft; ++i) {
-        int r = 0;
-        for (int bit = 0; bit < 9; ++bit)
-            if (i & (1 << bit)) r |= 1 << (8 - bit);
-        br[i] = (uint16_t)r;
-    }
     MfccTables& t = ctx->tab;
-    t.ablate = 0;
     // the kernels' LDS table images (MfccLdsImage), one per transform precision
     auto fill_image = [&](auto& img) {
         using R = std::remove_reference_t<decltype(img.tw1[0])>;
@@ -194,16 +186,9 @@ int build_tables(sg_ctx* ctx) {
     fill_image(*img32);
     fill_image(*img64);
     int rc = 0;
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.window, window);
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_w, melw);
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_lo, lo);
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.mel_hi, hi);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bin_m0, m0);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bin_w0, w0);
     rc |= dev_upload(ctx, ctx->model_allocs, &t.bin_w1, w1);
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.dct, dct);
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.lifter, lifter);
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.twiddle, tw);
     {
         std::vector<MfccLdsImage<float>> v32(1, *img32);
         std::vector<MfccLdsImage<double>> v64(1, *img64);
@@ -214,7 +199,6 @@ int build_tables(sg_ctx* ctx) {
         t.lds_f32 = d32;
         t.lds_f64 = d64;
     }
-    rc |= dev_upload(ctx, ctx->model_allocs, &t.bitrev, br);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->range_scratch, 512);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->cw2_scratch, 1024 * 32);
     rc |= dev_alloc(ctx, ctx->model_allocs, &ctx->sk_slabs, (size_t)512 * 128 * 128);  // >= 768 * 64 * 128

@@ -167,18 +167,9 @@ static_assert(sizeof(MfccLdsImage<float>) % 16 == 0 && sizeof(MfccLdsImage<doubl
 struct MfccTables {          // device pointers
     const MfccLdsImage<float>* lds_f32;
     const MfccLdsImage<double>* lds_f64;
-    float* window;           // [400] povey
-    float* mel_w;            // [30][256] dense triangular weights
-    int* mel_lo;             // [30] first bin with non-zero weight
-    int* mel_hi;             // [30] one past the last
-    int* bin_m0;             // [256] lower mel index touching this bin (-1: none)
+    int* bin_m0;             // [256] lower mel index touching this bin (-1: none)   (the adjoint's per-bin mel membership)
     float* bin_w0;           // [256] weight into mel bin_m0
     float* bin_w1;           // [256] weight into mel bin_m0+1 (0 if none)
-    float* dct;              // [30 mel][30 cep]
-    float* lifter;           // [30]
-    double2* twiddle;        // [256] exp(-2 pi i k / 512), fp64 (forward FFT runs in fp64)
-    uint16_t* bitrev;        // [512]
-    int ablate;              // (unused since round 6)
     int fft64;               // sg_xv_configure: 0 = float32 transforms (default, the reference's precision), 1 = float64
     // spectrum hand-over forward -> backward within one pass (null: the backward recomputes the forward):
     // bins 0..255 of every frame's FFT as float2, in the transform's register order (bin (l >> 3) + 8 (l & 7) + 64 d at
