@@ -511,3 +511,28 @@ def test_float32_transforms_against_float64(sd, dev):
         "d loss/d wav %.2e of max, sign mismatch %.2e" % ((f32 - f64).abs().max().item(), (s32 - s64).abs().max().item(),
                                                           bool(torch.equal(d32, d64)), gerr, sign))
     assert (f32 - f64).abs().max().item() < 2e-3 and torch.equal(d32, d64) and gerr < 1e-3
+
+
+def test_environment_knobs_count_only_behind_sg_tune(tmp_path):
+    """Round 6 (hygiene): the library reads no SG_* variable unless SG_TUNE=1 is set -- a stray knob in a user's
+    environment changes nothing.  A child process with SG_AN_FUSED=0 in its environment still runs the fused CNN launches
+    without the gate, and the per-layer sequence with it ("Environment")."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from speakerguard_amd import synth\n"
+        "from speakerguard_amd.attack.utils import SEC4SR_CrossEntropy\n"
+        "from speakerguard_amd.model.audionet_csine import audionet_csine\n"
+        "dev = torch.device('cuda:0')\n"
+        "m = audionet_csine.from_weights(synth.make_audionet_state_dict(seed=0, num_class=251), device=dev)\n"
+        "x = torch.from_numpy(synth.make_waveforms(2, 32000, seed=3)).to(dev)\n"
+        "y = torch.zeros(2, dtype=torch.int64, device=dev)\n"
+        "tags = [t for t, _ in m.trace_stages(lambda: m.loss_grad(x, y, SEC4SR_CrossEntropy()), max_records=256)]\n"
+        "print('FUSED' if 'an_cnn_fwd' in tags else 'PERLAYER')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("SG_")}
+    for env, want in ((dict(base, SG_AN_FUSED="0"), "FUSED"), (dict(base, SG_AN_FUSED="0", SG_TUNE="1"), "PERLAYER")):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == want, (want, r.stdout, r.stderr[-500:])
