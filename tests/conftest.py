@@ -74,18 +74,6 @@ def pytest_runtest_logstart(nodeid, location):
         pass
 
 
-# ---- session-wide cache of oracle results ---------------------------------------------------------------------------------
-# Several tests attack the same (model, waveforms, parameters) through the oracle; the oracle is deterministic, so each
-# distinct workload is computed once per session.  Key: a tuple of plain values naming the workload completely.
-_ORACLE_CACHE = {}
-
-
-def oracle_cached(key, compute):
-    if key not in _ORACLE_CACHE:
-        _ORACLE_CACHE[key] = compute()
-    return _ORACLE_CACHE[key]
-
-
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     out = {k: d[k] for k in d.files if k != "meta"}
