@@ -1673,8 +1673,24 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     unsigned epoch = ++launch_counter;
     if (epoch == 0) epoch = ++launch_counter;  // 0 is the value of never-written flags
     static const char* trace_file = sg_tune_env("SG_SK_TRACE");  // tuning aid: dump per-worker phase timestamps
+    // ... of the launches [SG_SK_TRACE_SKIP, SG_SK_TRACE_SKIP + SG_SK_TRACE_COUNT) only (default: all of them): a traced launch
+    // is followed by a synchronisation, so tracing every launch never sees the chip at the clock of a long loop
+    static const long trace_skip = [] {
+        const char* e = sg_tune_env("SG_SK_TRACE_SKIP");
+        return e ? atol(e) : 0L;
+    }();
+    static const long trace_count = [] {
+        const char* e = sg_tune_env("SG_SK_TRACE_COUNT");
+        return e ? atol(e) : (1L << 60);
+    }();
+    static std::atomic<long> trace_seen{0};
     static PerDeviceScratch trace_buf;
-    unsigned long long* trace_dev = trace_file ? static_cast<unsigned long long*>(trace_buf.get((size_t)workers * 16 * 8)) : nullptr;
+    bool trace_this = trace_file != nullptr;
+    if (trace_this) {
+        const long idx = trace_seen.fetch_add(1, std::memory_order_relaxed);
+        trace_this = idx >= trace_skip && idx - trace_skip < trace_count;
+    }
+    unsigned long long* trace_dev = trace_this ? static_cast<unsigned long long*>(trace_buf.get((size_t)workers * 16 * 8)) : nullptr;
     ConvGemmArgs at = a;
     at.trace = trace_dev;
     if (at.lose_counter && *at.lose_counter > 0) {  // fault injection: THIS stream-K launch publishes no hand-off flags
@@ -1703,7 +1719,7 @@ static hipError_t launch_streamk(const ConvGemmArgs& a, int epi, float* slabs, u
     }
 #undef SG_SK
 #undef a
-    if (trace_file && trace_dev) {
+    if (trace_this && trace_dev) {
         std::vector<unsigned long long> h((size_t)workers * 16);
         if (hipStreamSynchronize(s) == hipSuccess &&
             hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {

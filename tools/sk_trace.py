@@ -3,6 +3,8 @@
 
     SG_SK_TRACE=gpurun_out/sk.bin python tools/layer_bench.py --layers 5 --iters 2 --repeats 1
     python tools/sk_trace.py gpurun_out/sk.bin
+    python tools/sk_trace.py gpurun_out/sk.bin --all     one line per traced launch: shape, busy time, shader clock, chunk time
+                                                         (with SG_SK_TRACE_SKIP / SG_SK_TRACE_COUNT: launches inside a long loop)
 """
 import struct
 import sys
@@ -17,6 +19,32 @@ while pos < len(data):
     n = hdr[0] * 16
     t = np.frombuffer(data[pos:pos + 8 * n], dtype=np.uint64).reshape(hdr[0], 16).copy(); pos += 8 * n
     recs.append((hdr, t))
+if "--all" in sys.argv:
+    for hdr, t in recs:
+        workers, M, N, C, ipw, tiles, epi, _ = hdr
+        xcc = ((t[:, 15] >> np.uint64(32)).astype(np.int64)) & 0xF
+        ts = t[:, :15].astype(np.float64) * 0.01
+        def colr(i):
+            v = ts[:, i].copy(); v[t[:, i] == 0] = np.nan; return v
+        start = colr(0)
+        end = np.nanmax(np.stack([colr(i) for i in (2, 4, 6, 8, 12)]), axis=0)
+        busy = end - start
+        cyc = t[:, 14].astype(np.float64) - t[:, 13].astype(np.float64)
+        okc = (t[:, 13] != 0) & (t[:, 14] > t[:, 13]) & ~np.isnan(busy) & (busy > 0)
+        mhz = np.median(cyc[okc] / busy[okc]) if okc.sum() > 8 else float("nan")
+        whole = colr(5) - colr(4)  # second whole tile: slots 4 (end of tile 0's epilogue) -> 5 (end of tile 1's chunks)
+        whole = whole[~np.isnan(whole) & (whole > 0)]
+        if not whole.size:          # long tiles: the first whole tile, from the end of the parked head piece (or the start)
+            t0 = np.where(np.isnan(colr(2)), colr(0), colr(2))
+            whole = colr(3) - t0
+            whole = whole[~np.isnan(whole) & (whole > 0)]
+        per_chunk = np.median(whole) / C if whole.size else float("nan")
+        tile_rows = M * 1.0 / (tiles / (N // 128))
+        flop_chunk = 2.0 * round(tile_rows / 32) * 32 * 128 * 32
+        ideal = flop_chunk / (256 * mhz) if mhz == mhz else float("nan")  # 157.3 TFLOP/s = 256 CUs x 256 flop per clock at 2.4 GHz
+        print("M %6d N %5d chunks/tile %3d epi %d workers %d: busy median %7.1f us  clock %4.0f MHz  whole tile %.3f us per chunk (ideal at that clock %.3f: %.1f %%)" % (
+            M, N, C, epi, workers, np.nanmedian(busy), mhz, per_chunk, ideal, 100 * ideal / per_chunk if per_chunk == per_chunk else float("nan")))
+    sys.exit(0)
 hdr, t = recs[-1]
 workers, M, N, C, ipw, tiles, epi, _ = hdr
 print("launch: workers %d  M %d N %d  chunks/tile %d  chunks/worker %d  tiles %d  epi %d" % (workers, M, N, C, ipw, tiles, epi))
