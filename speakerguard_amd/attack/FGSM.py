@@ -162,7 +162,7 @@ class FGSM(Attack):
         base = getattr(self.model, 'base_model', self.model)
         if hasattr(base, 'check_health'):
             base.check_health()
-        return torch.cat(adver, 0), success
+        return (adver[0] if len(adver) == 1 else torch.cat(adver, 0)), success  # (one batch: attack_batch's own output tensor)
 
     def _check_inputs(self, x, y):
         lower, upper = -1, 1
