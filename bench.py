@@ -268,7 +268,7 @@ def main():
                 adv, succ = ShardedAttack(pgd(k), gather_audio=False).attack(x, y)
                 return adv, torch.tensor(succ, dtype=torch.uint8, device=dev)
             adv, succ = pgd(k).attack(x, y)
-            flags = torch.tensor(succ, dtype=torch.uint8, device=dev)
+            flags = torch.tensor(succ, dtype=torch.uint8, device=dev if world > 1 else "cpu")  # (one rank: nothing to exchange)
             return adv, (gather_flags(flags, dist, world) if gather else flags)
         return attack
 

@@ -85,7 +85,7 @@ class FGSM(Attack):
             target = y_batch.detach().cpu().numpy()
             for it in range(self.max_iter + 1):
                 print("batch:{} iter:{} loss: {} predict: {}, target: {}".format(batch_id, it, ltr[it].tolist(), dtr[it], target))
-        return x_adv, success.bool().tolist()
+        return x_adv, [bool(v) for v in success.tolist()]  # (one device round trip, no conversion launch)
 
     # ---- step-by-step loop (FGSM.py:38-70) ---------------------------------------------------
     def attack_batch(self, x_batch, y_batch, lower, upper, batch_id):
