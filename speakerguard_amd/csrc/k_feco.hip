@@ -52,16 +52,21 @@ int feco_fail(sg_ctx* ctx, int code, const char* fmt, ...) {
 // tuning aid (SG_FECO_TRACE=1): phase timestamps (100 MHz) of block (0, 0): per iteration [start, after the assignment,
 // after the member lists, after the update] for the first 16 iterations, then [loop end, kernel end, kernel start]
 constexpr int kFecoTraceIters = 16;
-__device__ unsigned long long g_feco_trace[4 * kFecoTraceIters + 4 + 24];  // + detail stamps (set-up, iteration 0) + cycle counts
-__device__ int g_feco_trace_on;
+// (ONE device object: hipcc places separate device globals of a file in an order that is not stable from one build to the
+// next -- the same source gave two different code objects, equal but for the addresses of these two)
+struct FecoTraceDev {
+    unsigned long long t[4 * kFecoTraceIters + 4 + 24];  // + detail stamps (set-up, iteration 0) + cycle counts
+    int on;
+};
+__device__ FecoTraceDev g_feco_tr;
 #ifdef SG_EXP_FECO_JC
 __device__ int g_feco_ablate;  // experiment builds only (never the shipped library): 1 no MFMAs, 2 no per-tile maxima, 4 no B operand loads
 #endif
 #define FECO_STAMP(i) \
-    if (g_feco_trace_on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_feco_trace[i] = __builtin_amdgcn_s_memrealtime();
+    if (g_feco_tr.on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_feco_tr.t[i] = __builtin_amdgcn_s_memrealtime();
 #define FECO_DETAIL(i) FECO_STAMP(4 * kFecoTraceIters + 4 + (i))
 #define FECO_CYCLES(i) \
-    if (g_feco_trace_on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_feco_trace[4 * kFecoTraceIters + 4 + (i)] = __builtin_readcyclecounter();
+    if (g_feco_tr.on && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_feco_tr.t[4 * kFecoTraceIters + 4 + (i)] = __builtin_readcyclecounter();
 
 constexpr int kFecoMaxD = 64;
 constexpr int kFecoThreads = 1024;
@@ -842,11 +847,11 @@ static int feco_kmeans_impl(sg_ctx* ctx, const float* feats_dev, int32_t B, int3
         const int dslot = sg_device_slot();
         if (!armed[dslot]) {
             const int one = 1;
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_trace_on), &one, sizeof(one));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feco_tr), &one, sizeof(one), offsetof(FecoTraceDev, on));
             armed[dslot] = true;
         } else if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
             unsigned long long h[4 * kFecoTraceIters + 4 + 24];
-            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_feco_trace), sizeof(h)) == hipSuccess) {
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_feco_tr), sizeof(h), offsetof(FecoTraceDev, t)) == hipSuccess) {
                 fprintf(stderr, "feco k-means phases (us), block (0, 0): set-up %.2f;", (h[0] - h[4 * kFecoTraceIters + 2]) * 0.01);
                 for (int it = 0; it < max_iter && it < kFecoTraceIters && h[4 * it + 1] > h[4 * it]; ++it)
                     fprintf(stderr, " it%d assign %.2f lists %.2f update %.2f;", it, (h[4 * it + 1] - h[4 * it]) * 0.01,
